@@ -1,0 +1,58 @@
+// Shared declarations for the gfx950 TRPL kernels and the C-ABI glue.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace trpl {
+
+constexpr int kMaxCurves = 16;
+
+// Per-curve constants, computed on the host exactly as pvSim does (pvSimPCR.py:314-331,
+// :393) so that the in-kernel products X[s][i] * scales[i] round like numpy's.
+struct CurveConst {
+    double scales[12];   // dx3,dx3,dt/dx2,dt/dx2,dt/dx3,dt/dx,dt/dx,dt/dx6,dt/dx6,1/dt,1/dt,1/dx
+    double dx3;          // excitation scale (pvSimPCR.py:356)
+    double plnorm;       // dx^2 * dt        (pvSimPCR.py:393)
+    int64_t n_obs;       // likelihood mode: number of PL columns compared (<= T/plT + 1)
+};
+
+// Kernel argument block of the time-stepper (passed by value; ~2.4 KB).
+struct StepArgs {
+    const double *X;        // [S][xld]   physical units; columns 0..11 = matPar, 12 = mag offset
+    const double *dN;       // [C][L]     excitation, nm^-3
+    const double *obs;      // [C][obs_ld] log10 observations (likelihood mode) or nullptr
+    void *pl;               // [C*S][pl_ld] PL out (solve mode) or nullptr
+    double *sse;            // [C][S] out (likelihood mode) or nullptr
+    int32_t *status;        // [C][S] out or nullptr
+    int64_t *iters_total;   // [C][S] out or nullptr
+    int64_t S;
+    int64_t T;
+    int64_t pl_ld;
+    int64_t obs_ld;
+    double TOL;             // 10^-tol (pvSimPCR.py:112)
+    int32_t xld;            // 12 or 13
+    int32_t C;
+    int32_t L;
+    int32_t plT;
+    int32_t MAX;
+    int32_t pl_bytes;       // 4 or 8
+    uint32_t flags;         // TRPL_FLAG_*
+    CurveConst curve[kMaxCurves];
+};
+
+// Launchers (one translation unit per arithmetic mode, see stepper_strict.hip / stepper_fast.hip).
+hipError_t launch_stepper_strict(const StepArgs &a, hipStream_t stream);
+hipError_t launch_stepper_fast(const StepArgs &a, hipStream_t stream);
+
+// likelihood.hip
+hipError_t launch_log10_clamp(void *x, int elem_bytes, int64_t rows, int64_t cols, int64_t ld, double mn,
+                              hipStream_t stream);
+hipError_t launch_sse_accumulate(double *P, const void *pl, int elem_bytes, int64_t rows, int64_t n_obs,
+                                 int64_t ld, const double *values, const double *mag, hipStream_t stream);
+hipError_t launch_reduce_curves(double *P, const double *sse, int64_t S, int C, hipStream_t stream);
+
+// pcr_batched.hip
+hipError_t launch_pcr_batched(const void *ld, const void *d, const void *ud, const void *b, void *x, int64_t S,
+                              int L, int elem_bytes, uint32_t flags, hipStream_t stream);
+
+}  // namespace trpl

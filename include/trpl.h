@@ -1,0 +1,149 @@
+/*
+ * trpl.h -- C ABI of libtrpl_hip.so: the MI355X (gfx950) drop-in for the batched TRPL
+ * drift-diffusion solve + log-likelihood hot path of HagesLab/Bayesian-Inference-TRPL.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and sizes, returns an int status
+ * (TRPL_OK = 0) and never throws; the message for the last failure on the calling thread is
+ * returned by trpl_last_error().  Each declaration cites the reference interface it
+ * replaces (file:line in the reference checkout).  The Python-side binding a maintainer of
+ * the reference would add is shown in INTEGRATION.md; this repo's own binding is
+ * bayesian-inference-trpl_amd/_abi.py.
+ *
+ * Two families:
+ *   host-buffer calls   (trpl_solve_pl, trpl_log10_clamp, trpl_sse_accumulate, trpl_loglik):
+ *       borrow caller-owned host memory for the duration of the call, exactly like the
+ *       reference's numpy-in / numpy-in-place callables; device memory is allocated, used
+ *       and released inside the call (pvSimPCR.py:365-384, probs.py:53-60, :80-83).
+ *   device-resident calls (`*_dev`): every pointer is a HIP device pointer on the current
+ *       device and `stream` is a hipStream_t (NULL = default stream); nothing is allocated,
+ *       copied or synchronised -- the caller owns residency and ordering.
+ *
+ * Data layout (all row-major, C-contiguous):
+ *   matpar  [S][12] fp64, physical units nm / ns / V, column order
+ *           N0, P0, DN, DP, rate, sr0, srL, CN, CP, tauN, tauP, Lambda   (pvSimPCR.py:97-108)
+ *   X       [S][13] fp64 = matpar columns + mag_offset                  (bayeslib.py:144,:195)
+ *   excitation dN [C][L] fp64, nm^-3, node n at x = (n + 1/2) dx        (pvSimPCR.py:355-356)
+ *   PL      [rows][ld] fp32 or fp64 (elem_bytes 4 / 8), column t/plT    (pvSimPCR.py:281)
+ */
+#ifndef TRPL_H
+#define TRPL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRPL_ABI_VERSION 1
+
+/* status codes */
+#define TRPL_OK 0
+#define TRPL_ERR_ARG 1          /* invalid argument (message says which) */
+#define TRPL_ERR_HIP 2          /* a HIP runtime call failed */
+#define TRPL_ERR_NODEVICE 3     /* no usable gfx950 device */
+#define TRPL_ERR_UNSUPPORTED 4  /* valid request this build has no kernel for */
+
+/* flags for the solver entry points */
+#define TRPL_FLAG_STRICT 0x1      /* bit-reproducible arithmetic: no FMA contraction, IEEE divides, the
+                                     reference's operation order (state is bit-identical to the
+                                     sequentially executed reference); slower */
+#define TRPL_FLAG_PL_F32 0x2      /* trpl_loglik*: round PL and log10 PL through fp32 exactly where the
+                                     reference's float32 plI buffer does (bayeslib.py:137) */
+#define TRPL_FLAG_NORMALIZE 0x4   /* trpl_loglik*: self-normalise each PL curve to its t = 0 value
+                                     (bayeslib.py:150-154) */
+
+int trpl_abi_version(void);
+const char *trpl_last_error(void);
+/* number of visible HIP devices (0 with none); never fails */
+int trpl_device_count(void);
+
+/* ---------------------------------------------------------------------------------------
+ * trpl_solve_pl -- replaces pvSimPCR.pvSim(plI, plN, plP, plE, matPar, simPar, iniPar, TPB,
+ * BPG, max_sims_per_block, init_mode="points")  (pvSimPCR.py:309-401; kernel tEvol :227-306,
+ * iterate :93-225, pcreduce :42-81, norm2 :14-40).
+ *
+ * Time-steps S independent systems (one curve) for t = 0..T with the reference's
+ * variable-order BDF / Newton-Picard / PCR scheme and writes PL(t) = B dx sum_i (N_i P_i -
+ * n0 p0) for t % plT == 0 into plI[s][t/plT] in the buffer's dtype, re-dimensionalised
+ * (pvSimPCR.py:393).
+ *   status[s]      0, or 1+t when iterate() reached max_iter at step t (pvSimPCR.py:269);
+ *                  that system stops there and its remaining PL entries are NaN (the
+ *                  reference leaves them uninitialised and stops the whole launch).
+ *   iters_total[s] (nullable) inner iterations summed over the steps taken.
+ *   seconds        (nullable) kernel time, like pvSim's return value (pvSimPCR.py:378-381).
+ * L must be a power of two, 4 <= L <= 512.
+ * ------------------------------------------------------------------------------------- */
+int trpl_solve_pl(const double *matpar, int64_t S, double length_nm, double time_ns, int32_t L,
+                  int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN,
+                  void *plI, int32_t pl_elem_bytes, int64_t pl_ld, int32_t *status,
+                  int64_t *iters_total, uint32_t flags, int32_t device, double *seconds);
+
+int trpl_solve_pl_dev(const double *matpar, int64_t S, double length_nm, double time_ns,
+                      int32_t L, int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter,
+                      const double *dN, void *plI, int32_t pl_elem_bytes, int64_t pl_ld,
+                      int32_t *status, int64_t *iters_total, uint32_t flags, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * trpl_log10_clamp -- replaces probs.fastlog(plI, MIN, TPB, BPG)  (probs.py:64-85):
+ * x <- log10(max(x, min)) in place, in the buffer's dtype.
+ * ------------------------------------------------------------------------------------- */
+int trpl_log10_clamp(void *x, int32_t elem_bytes, int64_t rows, int64_t cols, int64_t ld,
+                     double min, int32_t device, double *seconds);
+int trpl_log10_clamp_dev(void *x, int32_t elem_bytes, int64_t rows, int64_t cols, int64_t ld,
+                         double min, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * trpl_sse_accumulate -- replaces probs.prob(P, plI, values, uncertainty, mag_grid, TPB, BPG)
+ * (probs.py:20-62):  P[j] -= sum_i (plI[j][i] + mag[j] - values[i])^2, fp64 accumulation in
+ * index order.  `uncertainty` is not part of the ABI because the reference never reads it
+ * (probs.py:40).
+ * ------------------------------------------------------------------------------------- */
+int trpl_sse_accumulate(double *P, const void *plI, int32_t elem_bytes, int64_t rows,
+                        int64_t n_obs, int64_t ld, const double *values, const double *mag,
+                        int32_t device, double *seconds);
+int trpl_sse_accumulate_dev(double *P, const void *plI, int32_t elem_bytes, int64_t rows,
+                            int64_t n_obs, int64_t ld, const double *values, const double *mag,
+                            void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * trpl_loglik -- the fused path: replaces the body of bayeslib.simulate (bayeslib.py:117-201)
+ * for one experiment whose observation times are the first n_obs[c] points of the simulation
+ * grid: for every sample s and curve c it time-steps the system, and accumulates
+ *     sse[c][s] = sum_{i < n_obs[c]} ( log10(max(PL_{s,c}(t_i), DBL_MIN)) + X[s][12] - obs[c][i] )^2
+ * without ever materialising PL in memory; then P[s] -= sse[0][s] + ... + sse[C-1][s] in
+ * curve order (probs.py:44,:60).  A system that does not converge gets sse = +inf.
+ *   lengths [C] host doubles (per-curve thickness, bayeslib.py:109-119)
+ *   dN      [C][L], obs [C][obs_ld] log10 observations, n_obs [C] host int64 (<= T/plT + 1)
+ *   sse     [C][S] out;  status [C][S] out (nullable);  iters_total [C][S] out (nullable)
+ * C <= 16 per call.
+ * ------------------------------------------------------------------------------------- */
+int trpl_loglik(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns,
+                int32_t L, int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter,
+                const double *dN, const double *obs, int64_t obs_ld, const int64_t *n_obs,
+                double *P, double *sse, int32_t *status, int64_t *iters_total, uint32_t flags,
+                int32_t device, double *seconds);
+
+int trpl_loglik_dev(const double *X, int64_t S, int32_t C, const double *lengths_nm /*host*/,
+                    double time_ns, int32_t L, int64_t T, int32_t plT, int32_t tol_exp,
+                    int32_t max_iter, const double *dN, const double *obs, int64_t obs_ld,
+                    const int64_t *n_obs /*host*/, double *P, double *sse, int32_t *status,
+                    int64_t *iters_total, uint32_t flags, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * trpl_pcr_solve_batched_dev -- the stand-alone batched tridiagonal solve (unit U1 of the
+ * measurement plan): S independent systems  ld[i] x[i-1] + d[i] x[i] + ud[i] x[i+1] = b[i],
+ * i < L, by parallel cyclic reduction with pcreduce's elimination order (pvSimPCR.py:42-81),
+ * operands and result in HBM, arrays [S][L], elem_bytes 8 (fp64) or 4 (fp32).  Inputs are
+ * not modified.  Algorithmic traffic 5 * L * elem_bytes per system.
+ * ------------------------------------------------------------------------------------- */
+int trpl_pcr_solve_batched_dev(const void *ld, const void *d, const void *ud, const void *b,
+                               void *x, int64_t S, int32_t L, int32_t elem_bytes, uint32_t flags,
+                               void *stream);
+int trpl_pcr_solve_batched(const void *ld, const void *d, const void *ud, const void *b, void *x,
+                           int64_t S, int32_t L, int32_t elem_bytes, uint32_t flags,
+                           int32_t device, double *seconds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRPL_H */

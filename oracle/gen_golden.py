@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE'S OWN code in this container.
+
+TEST INFRASTRUCTURE.  Development-container only: it needs /root/reference (read-only)
+and refuses to run without it.  Nothing from the reference is copied: the script imports
+the reference modules where they lie, with oracle/refshim (a sequential stand-in for the
+absent `numba`) first on sys.path, calls the reference functions, and stores *data only*
+(inputs and the outputs they produced).
+
+Reference entry points exercised (file:line):
+  pvSimPCR.pcreduce :42-81, pvSimPCR.norm2 :14-40          -> pcr_norm.npz
+  pvSimPCR.pvSim :309-401 (tEvol :227-306, iterate :93-225) -> pvsim_*.npz
+  probs.fastlog :78-85, probs.prob :49-62                   -> probs.npz
+  bayeslib.random_grid :18-32, bayeslib.bayes :207-252      -> bayes_e2e.npz, sampler.npz
+  pvSim_fallback.pvSim_cpu_fallback :80-117 (as shipped)    -> fallback.npz
+
+Usage:  python oracle/gen_golden.py [case ...]     (default: all cases)
+"""
+import os
+import sys
+import time
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("TRPL_REFERENCE", "/root/reference")
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+if not os.path.isfile(os.path.join(REF, "pvSimPCR.py")):
+    sys.exit("gen_golden.py: reference checkout not found at %s -- refusing to run" % REF)
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(HERE, "refshim"))
+os.environ.setdefault("SLURM_ARRAY_TASK_ID", "0")          # bayeslib.py:231
+
+import numpy as np  # noqa: E402
+
+import bayeslib  # noqa: E402  (reference)
+import probs  # noqa: E402  (reference)
+import pvSimPCR  # noqa: E402  (reference)
+from bayes_io import get_initpoints  # noqa: E402  (reference)
+
+EXC_POWER = os.path.join(REF, "Example Data", "Power_scan_Excitations.csv")
+EXC_TWO = os.path.join(REF, "Example Data", "Twothick_Excitations.csv")
+
+# parallel_bayes_gpu.py:27-33 (values restated; they are physical constants of the config)
+UNIT = np.array([(1e7) ** -3, (1e7) ** -3, (1e7) ** 2 / (1e9) * .02569257,
+                 (1e7) ** 2 / (1e9) * .02569257, (1e7) ** 3 / (1e9), (1e7) / (1e9), (1e7) / (1e9),
+                 (1e7) ** 6 / (1e9), (1e7) ** 6 / (1e9), 1, 1, 704.3, 1])
+DO_LOG = np.array([1, 1, 0, 0, 1, 1, 1, 1, 1, 0, 0, 1, 0])              # :86
+MINX = np.array([1e8, 1e14, 0, 0, 1e-11, 0.1, 0.1, 1e-30, 1e-30, 1, 1, 10 ** -1, 0])   # :91
+MAXX = np.array([1e8, 1e16, 50, 50, 1e-9, 100, 100, 1e-28, 1e-28, 1000, 2000, 10 ** -1, 0])  # :92
+# marked point of Visualization/config.txt:57-68
+MARK = np.array([1e8, 3e15, 20, 20, 4.8e-11, 2, 2, 4.4e-29, 4.4e-29, 511, 871, 0.1, 0])
+PT = (0, 1, 3, 10, 30, 100)
+
+
+def draw(S, seed=42):
+    np.random.seed(seed)                                                 # parallel_bayes_gpu.py:35
+    return bayeslib.random_grid(MINX * UNIT, MAXX * UNIT, DO_LOG, S)
+
+
+class IterRecorder:
+    """Wrap pvSimPCR.iterate (module global looked up at call time) to log its returns."""
+
+    def __enter__(self):
+        self.log = []
+        self.orig = pvSimPCR.iterate
+
+        def rec(N, P, E, matPar, par, p, t):
+            r = self.orig(N, P, E, matPar, par, p, t)
+            self.log.append((int(p), int(t), int(r)))
+            return r
+        pvSimPCR.iterate = rec
+        return self
+
+    def __exit__(self, *a):
+        pvSimPCR.iterate = self.orig
+
+
+def run_pvsim(mat12, length, time_ns, L, T, ini, dtype, tol=7, MAX=10000, plT=1):
+    S = len(mat12)
+    simPar = [length, time_ns, L, T, plT, PT, tol, MAX]
+    plI = np.empty((S, T // plT + 1), dtype=dtype)
+    dummyN = np.empty((S, 2, L)); dummyE = np.empty((S, 2, L + 1))
+    with IterRecorder() as rec:
+        pvSimPCR.pvSim(plI, dummyN, dummyN.copy(), dummyE, mat12, simPar, ini, (1,), max(S, 1), 1,
+                       init_mode="points")
+    it = np.zeros((S, T + 1), dtype=np.int32)
+    for p, t, r in rec.log:
+        it[p, t] = r
+    return plI, it
+
+
+def case_pcr_norm():
+    rng = np.random.default_rng(1234)
+    out = {}
+    for N in (4, 8, 32, 128, 512):
+        nsys = 6
+        ld = rng.uniform(-1, 1, (nsys, N)); ud = rng.uniform(-1, 1, (nsys, N))
+        d = rng.uniform(2.5, 4, (nsys, N)) * rng.choice([-1, 1], (nsys, 1))
+        ld[:, 0] = 0; ud[:, -1] = 0
+        B = rng.normal(size=(nsys, N)); cprev = rng.normal(size=(nsys, N))
+        x = np.zeros((nsys, N)); err = np.zeros(nsys)
+        for s in range(nsys):
+            a2 = ld[s].copy()[:, None]; a1 = d[s].copy()[:, None]; a0 = ud[s].copy()[:, None]
+            b = B[s].copy()[:, None]; c = cprev[s].copy()[:, None]
+            buf = np.zeros((4 * N, 1)); e = np.zeros(1)
+            pvSimPCR.norm2(a0, a1, a2, b, c, buf, e, 1, 1)               # pvSimPCR.py:172 call form
+            err[s] = e[0]
+            pvSimPCR.pcreduce(a2, a1, a0, b, c, buf, 1, 1)               # pvSimPCR.py:175 call form
+            x[s] = c[:, 0]
+        out.update({f"ld{N}": ld, f"d{N}": d, f"ud{N}": ud, f"B{N}": B, f"c{N}": cprev,
+                    f"x{N}": x, f"err{N}": err})
+    np.savez_compressed(os.path.join(OUT, "pcr_norm.npz"), **out)
+
+
+def case_pvsim_power():
+    """Power_scan: 3 excitations, Length 2000 nm, L=128, dt=0.025 ns."""
+    ini = get_initpoints(EXC_POWER, {"select_obs_sets": None})
+    X = np.vstack([draw(4), MARK * UNIT])
+    T = 160
+    pls, its = [], []
+    for c in range(3):
+        p, i = run_pvsim(X[:, :-1], 2000, T * 0.025, 128, T, ini[c], np.float64)
+        pls.append(p); its.append(i)
+    p32, _ = run_pvsim(X[:2, :-1], 2000, 40 * 0.025, 128, 40, ini[2], np.float32)
+    np.savez_compressed(os.path.join(OUT, "pvsim_power.npz"), X=X, ini=ini, length=2000.0,
+                        time=T * 0.025, L=128, T=T, tol=7, MAX=10000, plI=np.array(pls),
+                        iters=np.array(its), plI32=p32, T32=40)
+
+
+def case_pvsim_twothick():
+    """Twothick rows 0 (311 nm) and 1 (2000 nm); 311 nm / high power stresses the iteration."""
+    ini = get_initpoints(EXC_TWO, {"select_obs_sets": None})
+    X = np.vstack([draw(2), MARK * UNIT])
+    T = 60
+    lengths = [311, 2000, 311, 2000, 311, 2000]                         # parallel_bayes_gpu.py:71
+    sel = [0, 1, 4]
+    pls, its = [], []
+    for c in sel:
+        p, i = run_pvsim(X[:, :-1], lengths[c], T * 0.025, 128, T, ini[c], np.float64)
+        pls.append(p); its.append(i)
+    np.savez_compressed(os.path.join(OUT, "pvsim_twothick.npz"), X=X, ini=ini[sel],
+                        lengths=np.array([lengths[c] for c in sel], dtype=float), time=T * 0.025,
+                        L=128, T=T, tol=7, MAX=10000, plI=np.array(pls), iters=np.array(its))
+
+
+def case_pvsim_small():
+    """Other grid sizes / tolerances / plT, and a forced non-convergence (MAX small)."""
+    out = {}
+    X = np.vstack([draw(2), MARK * UNIT])
+    for L in (8, 32, 64):
+        x = (np.arange(L) + 0.5) * (500.0 / L)
+        ini = 1e17 * 1e-21 * np.exp(-6e-3 * x)
+        p, i = run_pvsim(X[:, :-1], 500, 30 * 0.05, L, 30, ini, np.float64, tol=6)
+        out[f"plI_L{L}"] = p; out[f"it_L{L}"] = i; out[f"ini_L{L}"] = ini
+    x = (np.arange(32) + 0.5) * (500.0 / 32)
+    ini = 1e17 * 1e-21 * np.exp(-6e-3 * x)
+    p, i = run_pvsim(X[:, :-1], 500, 40 * 0.05, 32, 40, ini, np.float64, tol=6, plT=4)
+    out["plI_plT4"] = p; out["it_plT4"] = i
+    # forced non-convergence: one sample, MAX = 3, high injection on a thin film
+    x = (np.arange(32) + 0.5) * (311.0 / 32)
+    ini_hi = 1.6e18 * 1e-21 * np.exp(-6e-3 * x)
+    pl = np.full((1, 11), -777.0)
+    simPar = [311, 10 * 0.025, 32, 10, 1, PT, 7, 3]
+    d = np.empty((1, 2, 32))
+    with IterRecorder() as rec:
+        pvSimPCR.pvSim(pl, d, d.copy(), np.empty((1, 2, 33)), X[2:3, :-1], simPar, ini_hi, (1,), 1, 1,
+                       init_mode="points")
+    out["nc_plI"] = pl; out["nc_log"] = np.array(rec.log); out["nc_ini"] = ini_hi
+    np.savez_compressed(os.path.join(OUT, "pvsim_small.npz"), X=X, **out)
+
+
+def case_probs():
+    rng = np.random.default_rng(7)
+    rows, cols = 5, 37
+    pl64 = rng.lognormal(-8, 3, (rows, cols)); pl64[1, 3] = 0.0; pl64[2, 5] = -1e-9
+    pl32 = pl64.astype(np.float32); pl32[1, 3] = 1e-30; pl32[2, 5] = 1e-38      # keep > 0 (see note)
+    MIN = sys.float_info.min                                                    # bayeslib.py:157
+    l64 = pl64.copy(); probs.fastlog(l64, MIN, 1, 3)
+    l32 = pl32.copy(); probs.fastlog(l32, MIN, 1, 3)
+    values = rng.uniform(-12, -4, cols); mag = rng.uniform(-1, 1, rows)
+    P64 = rng.normal(size=rows); P64_in = P64.copy()
+    probs.prob(P64, l64, values, np.ones(cols), mag, 1, 3)
+    P32 = np.zeros(rows)
+    probs.prob(P32, l32, values, np.ones(cols), mag, 1, 3)
+    np.savez_compressed(os.path.join(OUT, "probs.npz"), pl64=pl64, pl32=pl32, log64=l64, log32=l32,
+                        values=values, mag=mag, P64_in=P64_in, P64=P64, P32=P32, MIN=MIN)
+
+
+def case_sampler():
+    out = {}
+    for S in (4, 64):
+        out[f"X{S}"] = draw(S)
+    np.savez_compressed(os.path.join(OUT, "sampler.npz"), minX=MINX, maxX=MAXX, do_log=DO_LOG, unit=UNIT,
+                        **out)
+
+
+def case_bayes_e2e():
+    """bayeslib.bayes(pvSim, ...) GPU branch end to end: 3 Power_scan curves, two experiments:
+    exp 0 on the simulation grid (bypass, bayeslib.py:182-183), exp 1 on a prefix of it
+    (per-row griddata, :184-191)."""
+    ini = get_initpoints(EXC_POWER, {"select_obs_sets": None})
+    S, T, dt = 6, 48, 0.025
+    simPar = [2000, T * dt, 128, T, 1, PT, 7, 10000]
+    tgrid = np.linspace(0, T * dt, T + 1)
+    # synthetic observations: the reference's own solver at the marked point, + fixed offsets
+    plm = []
+    for c in range(3):
+        p, _ = run_pvsim((MARK * UNIT)[None, :-1], 2000, T * dt, 128, T, ini[c], np.float64)
+        plm.append(np.log10(p[0]))
+    rng = np.random.default_rng(99)
+    obs0 = [v + rng.normal(0, 0.02, v.shape) for v in plm]
+    npre = 31
+    obs1 = [v[:npre] + 0.1 for v in plm]
+    e_data = [([tgrid] * 3, obs0, [np.ones(T + 1)] * 3),
+              ([tgrid[:npre]] * 3, obs1, [np.ones(npre)] * 3)]
+    sim_flags = {"load_PL_from_file": False, "override_equal_auger": False, "override_equal_mu": False,
+                 "override_equal_s": False, "log_pl": True, "self_normalize": False,
+                 "random_sample": True, "num_points": S}
+    gpu_info = {"sims_per_gpu": 4, "num_gpus": 1, "has_GPU": True, "threads_per_block": (1,),
+                "max_sims_per_block": 1}
+    minX = MINX * UNIT; maxX = MAXX * UNIT
+    minX[-1] = -0.5; maxX[-1] = 0.5                  # exercise the mag_offset column (linear)
+    np.random.seed(42)
+    N, P, X = bayeslib.bayes(pvSimPCR.pvSim, np.array([0]), None, minX, maxX, DO_LOG, ini, simPar,
+                             e_data, sim_flags, gpu_info, logger=None)
+    np.savez_compressed(os.path.join(OUT, "bayes_e2e.npz"), X=X, P=P, ini=ini, T=T, time=T * dt,
+                        length=2000.0, L=128, tol=7, MAX=10000, obs0=np.array(obs0), obs1=np.array(obs1),
+                        tgrid=tgrid, npre=npre, minX=minX, maxX=maxX, do_log=DO_LOG, sims_per_gpu=4)
+
+
+def case_fallback():
+    """The reference CPU model exactly as shipped (no stand-in involved): scipy BDF +
+    Simpson PL (pvSim_fallback.py:80-117).  Timing-baseline fixture, not a parity target
+    for the GPU path (different quadrature)."""
+    from pvSim_fallback import pvSim_cpu_fallback
+    ini = get_initpoints(EXC_POWER, {"select_obs_sets": None})
+    X = np.vstack([draw(2), MARK * UNIT])
+    T = 400
+    simPar = [2000, T * 0.025, 128, T, 1, PT, 7, 10000]
+    pl = np.empty((3, len(X), T + 1)); secs = []
+    for c in range(3):
+        secs.append(pvSim_cpu_fallback(pl[c], X, simPar, ini[c]))
+    np.savez_compressed(os.path.join(OUT, "fallback.npz"), X=X, ini=ini, T=T, time=T * 0.025,
+                        length=2000.0, L=128, plI=pl, seconds=np.array(secs))
+
+
+CASES = {"pcr_norm": case_pcr_norm, "probs": case_probs, "sampler": case_sampler,
+         "pvsim_small": case_pvsim_small, "pvsim_power": case_pvsim_power,
+         "pvsim_twothick": case_pvsim_twothick, "bayes_e2e": case_bayes_e2e,
+         "fallback": case_fallback}
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    names = sys.argv[1:] or list(CASES)
+    for n in names:
+        t0 = time.time()
+        CASES[n]()
+        print("golden %-16s %.1f s" % (n, time.time() - t0), flush=True)
