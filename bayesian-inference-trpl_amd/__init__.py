@@ -1,0 +1,18 @@
+"""MI355X (gfx950) drop-in for the batched TRPL drift-diffusion solve + log-likelihood hot path
+of HagesLab/Bayesian-Inference-TRPL (reference pvSimPCR.py + probs.py behind bayeslib.simulate).
+
+The directory name carries hyphens, so import it through the repo-root alias `trpl_amd`
+(trpl_amd.py) or importlib.  Everything computes on the GPU through libtrpl_hip.so
+(include/trpl.h); there is no CPU fallback.
+"""
+from . import _abi  # noqa: F401
+from ._abi import FLAG_NORMALIZE, FLAG_PL_F32, FLAG_STRICT, TrplError  # noqa: F401
+from . import device, dist, workloads  # noqa: F401
+from .driver import almost_equal, bayes, interp_rows, is_grid_prefix, loglik, simulate  # noqa: F401
+from .likelihood import fastlog, prob  # noqa: F401
+from .model import pvSim, solve_pl  # noqa: F401
+from .sampler import (DEFAULT_DO_LOG, DEFAULT_MAXX, DEFAULT_MINX, PARAM_NAMES, UNIT_CONVERSIONS,  # noqa: F401
+                      default_box, make_grid, random_grid)
+
+__all__ = ["pvSim", "solve_pl", "fastlog", "prob", "simulate", "bayes", "loglik", "random_grid", "make_grid",
+           "TrplError"]

@@ -1,0 +1,59 @@
+// Stand-alone batched tridiagonal solve (measurement unit U1): S systems of L unknowns,
+// operands and result in HBM ([S][L] arrays), one wavefront per system, the elimination order
+// of pcreduce (pvSimPCR.py:42-81).  Bound: HBM bandwidth, 5*L*sizeof(T) algorithmic bytes per
+// system (read ld, d, ud, b; write x).
+#pragma once
+#include "stepper_impl.hpp"
+
+namespace trpl {
+
+template <typename T, int L>
+__global__ void __launch_bounds__(256) pcr_batched_kernel(const T *__restrict__ ld, const T *__restrict__ d,
+                                                          const T *__restrict__ ud, const T *__restrict__ b,
+                                                          T *__restrict__ x, int64_t S)
+{
+    constexpr int W = L < 64 ? L : 64;
+    constexpr int NR = L / W;
+    const int lane = threadIdx.x & 63;
+    const int ln = lane & (W - 1);
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t s = wave; s < S; s += nwaves) {
+        const int64_t base = s * L;
+        T vl[NR], vd[NR], vu[NR], vb[NR], vx[NR];
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            const int64_t o = base + ln + W * j;
+            vl[j] = ld[o]; vd[j] = d[o]; vu[j] = ud[o]; vb[j] = b[o];
+        }
+        pcr_solve<T, NR, W, L>(vl, vd, vu, vb, vx, ln);
+        if (lane < W) {
+#pragma unroll
+            for (int j = 0; j < NR; j++) x[base + ln + W * j] = vx[j];
+        }
+    }
+}
+
+template <typename T>
+hipError_t launch_pcr_batched_t(const void *ld, const void *d, const void *ud, const void *b, void *x, int64_t S,
+                                int L, hipStream_t stream)
+{
+    if (S <= 0) return hipSuccess;
+    int64_t blocks = (S + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    dim3 grid((unsigned)blocks), block(256);
+    switch (L) {
+#define TRPL_CASE(LL)                                                                                      \
+    case LL:                                                                                               \
+        hipLaunchKernelGGL((pcr_batched_kernel<T, LL>), grid, block, 0, stream, (const T *)ld, (const T *)d, \
+                           (const T *)ud, (const T *)b, (T *)x, S);                                        \
+        break;
+        TRPL_CASE(4) TRPL_CASE(8) TRPL_CASE(16) TRPL_CASE(32) TRPL_CASE(64) TRPL_CASE(128) TRPL_CASE(256)
+        TRPL_CASE(512)
+#undef TRPL_CASE
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace trpl

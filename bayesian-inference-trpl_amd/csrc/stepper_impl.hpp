@@ -42,8 +42,8 @@ __device__ __forceinline__ double uniform_d(double v)
 }
 
 // y[j] = x at node i+RF (any finite in-array value when i+RF >= L)
-template <int NR, int W, int RF>
-__device__ __forceinline__ void fetch_up(const double (&x)[NR], double (&y)[NR], int ln)
+template <typename T, int NR, int W, int RF>
+__device__ __forceinline__ void fetch_up(const T (&x)[NR], T (&y)[NR], int ln)
 {
     if constexpr (RF >= W) {
         constexpr int m = RF / W;
@@ -52,7 +52,7 @@ __device__ __forceinline__ void fetch_up(const double (&x)[NR], double (&y)[NR],
     } else {
         const int src = (ln + RF) & (W - 1);
         const bool wrap = ln + RF >= W;
-        double s[NR];
+        T s[NR];
 #pragma unroll
         for (int j = 0; j < NR; j++) s[j] = __shfl(x[j], src, 64);
 #pragma unroll
@@ -61,8 +61,8 @@ __device__ __forceinline__ void fetch_up(const double (&x)[NR], double (&y)[NR],
 }
 
 // y[j] = x at node i-RF (any finite in-array value when i < RF)
-template <int NR, int W, int RF>
-__device__ __forceinline__ void fetch_dn(const double (&x)[NR], double (&y)[NR], int ln)
+template <typename T, int NR, int W, int RF>
+__device__ __forceinline__ void fetch_dn(const T (&x)[NR], T (&y)[NR], int ln)
 {
     if constexpr (RF >= W) {
         constexpr int m = RF / W;
@@ -71,7 +71,7 @@ __device__ __forceinline__ void fetch_dn(const double (&x)[NR], double (&y)[NR],
     } else {
         const int src = (ln - RF) & (W - 1);
         const bool wrap = ln < RF;
-        double s[NR];
+        T s[NR];
 #pragma unroll
         for (int j = 0; j < NR; j++) s[j] = __shfl(x[j], src, 64);
 #pragma unroll
@@ -81,83 +81,81 @@ __device__ __forceinline__ void fetch_dn(const double (&x)[NR], double (&y)[NR],
 
 // Sum over all L nodes with the reference's tree association (norm2, pvSimPCR.py:32-38):
 // level rf pairs (i, i+rf), rf = L/2 ... 1.  Every lane ends with the same value.
-template <int NR, int W>
-__device__ __forceinline__ double tree_sum(double (&v)[NR])
+template <typename T, int NR, int W>
+__device__ __forceinline__ T tree_sum(T (&v)[NR])
 {
 #pragma unroll
     for (int m = NR / 2; m >= 1; m /= 2)
 #pragma unroll
         for (int j = 0; j < m; j++) v[j] = v[j] + v[j + m];
-    double r = v[0];
+    T r = v[0];
 #pragma unroll
     for (int off = W / 2; off >= 1; off /= 2) r = r + __shfl_xor(r, off, 64);
     return r;
 }
 
 // One PCR level (pvSimPCR.py:57-69) with stride RF on the snapshot semantics of :49-54.
-template <int NR, int W, int L, int RF>
-__device__ __forceinline__ void pcr_level(double (&ld)[NR], double (&d)[NR], double (&ud)[NR],
-                                          double (&B)[NR], int ln)
+template <typename T, int NR, int W, int L, int RF>
+__device__ __forceinline__ void pcr_level(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], int ln)
 {
-    double ld_m[NR], d_m[NR], ud_m[NR], B_m[NR], ld_p[NR], d_p[NR], ud_p[NR], B_p[NR];
-    fetch_dn<NR, W, RF>(ld, ld_m, ln);
-    fetch_dn<NR, W, RF>(d, d_m, ln);
-    fetch_dn<NR, W, RF>(ud, ud_m, ln);
-    fetch_dn<NR, W, RF>(B, B_m, ln);
-    fetch_up<NR, W, RF>(ld, ld_p, ln);
-    fetch_up<NR, W, RF>(d, d_p, ln);
-    fetch_up<NR, W, RF>(ud, ud_p, ln);
-    fetch_up<NR, W, RF>(B, B_p, ln);
+    T ld_m[NR], d_m[NR], ud_m[NR], B_m[NR], ld_p[NR], d_p[NR], ud_p[NR], B_p[NR];
+    fetch_dn<T, NR, W, RF>(ld, ld_m, ln);
+    fetch_dn<T, NR, W, RF>(d, d_m, ln);
+    fetch_dn<T, NR, W, RF>(ud, ud_m, ln);
+    fetch_dn<T, NR, W, RF>(B, B_m, ln);
+    fetch_up<T, NR, W, RF>(ld, ld_p, ln);
+    fetch_up<T, NR, W, RF>(d, d_p, ln);
+    fetch_up<T, NR, W, RF>(ud, ud_p, ln);
+    fetch_up<T, NR, W, RF>(B, B_p, ln);
 #pragma unroll
     for (int j = 0; j < NR; j++) {
         const int i = ln + W * j;
         const bool lo = i >= RF, hi = i < L - RF;
-        const double k1 = lo ? ld[j] / d_m[j] : 0.0;
-        const double k2 = hi ? ud[j] / d_p[j] : 0.0;
-        double dn = d[j] - ud_m[j] * k1;
-        double Bn = B[j] - B_m[j] * k1;
-        const double ldn = lo ? -ld_m[j] * k1 : ld[j];
+        const T k1 = lo ? ld[j] / d_m[j] : T(0);
+        const T k2 = hi ? ud[j] / d_p[j] : T(0);
+        T dn = d[j] - ud_m[j] * k1;
+        T Bn = B[j] - B_m[j] * k1;
+        const T ldn = lo ? -ld_m[j] * k1 : ld[j];
         dn = dn - ld_p[j] * k2;
         Bn = Bn - B_p[j] * k2;
-        const double udn = hi ? -ud_p[j] * k2 : ud[j];
+        const T udn = hi ? -ud_p[j] * k2 : ud[j];
         d[j] = dn; B[j] = Bn; ld[j] = ldn; ud[j] = udn;
     }
 }
 
-template <int NR, int W, int L, int RF>
-__device__ __forceinline__ void pcr_levels(double (&ld)[NR], double (&d)[NR], double (&ud)[NR],
-                                           double (&B)[NR], int ln)
+template <typename T, int NR, int W, int L, int RF>
+__device__ __forceinline__ void pcr_levels(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], int ln)
 {
     if constexpr (L > 2 * RF) {
-        pcr_level<NR, W, L, RF>(ld, d, ud, B, ln);
-        pcr_levels<NR, W, L, RF * 2>(ld, d, ud, B, ln);
+        pcr_level<T, NR, W, L, RF>(ld, d, ud, B, ln);
+        pcr_levels<T, NR, W, L, RF * 2>(ld, d, ud, B, ln);
     }
 }
 
 // Tridiagonal solve (pcreduce, pvSimPCR.py:42-81): destroys ld,d,ud,B; result in x.
-template <int NR, int W, int L>
-__device__ __forceinline__ void pcr_solve(double (&ld)[NR], double (&d)[NR], double (&ud)[NR],
-                                          double (&B)[NR], double (&x)[NR], int ln)
+template <typename T, int NR, int W, int L>
+__device__ __forceinline__ void pcr_solve(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], T (&x)[NR],
+                                          int ln)
 {
-    pcr_levels<NR, W, L, 1>(ld, d, ud, B, ln);
+    pcr_levels<T, NR, W, L, 1>(ld, d, ud, B, ln);
     if constexpr (NR >= 2) {                       // pairs (i, i+L/2) are (j, j+NR/2) in-lane
         constexpr int H = NR / 2;
 #pragma unroll
         for (int j = 0; j < H; j++) {              // pvSimPCR.py:75-79
-            const double k = ud[j] / d[j + H];
+            const T k = ud[j] / d[j + H];
             x[j] = (B[j] - B[j + H] * k) / (d[j] - ld[j + H] * k);
             x[j + H] = (B[j + H] - ld[j + H] * x[j]) / d[j + H];
         }
     } else {                                        // L <= 64: partner lane ln ^ L/2
         constexpr int H = W / 2;
         const bool low = (ln & H) == 0;
-        const double ud_o = __shfl_xor(ud[0], H, 64), d_o = __shfl_xor(d[0], H, 64),
-                     B_o = __shfl_xor(B[0], H, 64), ld_o = __shfl_xor(ld[0], H, 64);
-        const double l_ud = low ? ud[0] : ud_o, l_d = low ? d[0] : d_o, l_B = low ? B[0] : B_o;
-        const double h_d = low ? d_o : d[0], h_B = low ? B_o : B[0], h_ld = low ? ld_o : ld[0];
-        const double k = l_ud / h_d;
-        const double xl = (l_B - h_B * k) / (l_d - h_ld * k);
-        const double xh = (h_B - h_ld * xl) / h_d;
+        const T ud_o = __shfl_xor(ud[0], H, 64), d_o = __shfl_xor(d[0], H, 64),
+                B_o = __shfl_xor(B[0], H, 64), ld_o = __shfl_xor(ld[0], H, 64);
+        const T l_ud = low ? ud[0] : ud_o, l_d = low ? d[0] : d_o, l_B = low ? B[0] : B_o;
+        const T h_d = low ? d_o : d[0], h_B = low ? B_o : B[0], h_ld = low ? ld_o : ld[0];
+        const T k = l_ud / h_d;
+        const T xl = (l_B - h_B * k) / (l_d - h_ld * k);
+        const T xh = (h_B - h_ld * xl) / h_d;
         x[0] = low ? xl : xh;
     }
 }
@@ -170,16 +168,16 @@ __device__ __forceinline__ double residual_norm(const double (&l)[NR], const dou
                                                 const double (&c)[NR], int ln)
 {
     double cm[NR], cp[NR], r[NR], ab[NR];
-    fetch_dn<NR, W, 1>(c, cm, ln);
-    fetch_up<NR, W, 1>(c, cp, ln);
+    fetch_dn<double, NR, W, 1>(c, cm, ln);
+    fetch_up<double, NR, W, 1>(c, cp, ln);
 #pragma unroll
     for (int j = 0; j < NR; j++) {
         // l = 0 on row 0 and u = 0 on row L-1, so the wrapped neighbour contributes +-0
         r[j] = fabs(l[j] * cm[j] + dg[j] * c[j] + u[j] * cp[j] - b[j]);
         ab[j] = fabs(b[j]);
     }
-    const double sr = tree_sum<NR, W>(r);
-    const double sb = tree_sum<NR, W>(ab);
+    const double sr = tree_sum<double, NR, W>(r);
+    const double sb = tree_sum<double, NR, W>(ab);
     return sr / sb;
 }
 
@@ -249,7 +247,7 @@ __global__ void __launch_bounds__(64) stepper_kernel(const StepArgs a)
             double q[NR];
 #pragma unroll
             for (int j = 0; j < NR; j++) q[j] = hN[0][j] * hP[0][j];
-            const double Sum = tree_sum<NR, W>(q) + (-(double)L * n0p0);
+            const double Sum = tree_sum<double, NR, W>(q) + (-(double)L * n0p0);
             plv = rate * Sum;
         }
 
@@ -266,7 +264,7 @@ __global__ void __launch_bounds__(64) stepper_kernel(const StepArgs a)
         for (int iters = 0; iters < MAX; iters++) {
             double lo_[NR], dg[NR], up[NR], bb[NR], Ep[NR];
             // ---- electrons (:148-175) ----
-            fetch_up<NR, W, 1>(Ek, Ep, ln);
+            fetch_up<double, NR, W, 1>(Ek, Ep, ln);
 #pragma unroll
             for (int j = 0; j < NR; j++) {
                 const int i = ln + W * j;
@@ -293,7 +291,7 @@ __global__ void __launch_bounds__(64) stepper_kernel(const StepArgs a)
                 if (ln == W - 1) { dg[NR - 1] -= dsL; bb[NR - 1] -= fL; }
             }
             const double errN = uniform_d(residual_norm<NR, W>(lo_, dg, up, bb, Nk, ln));  // :172
-            pcr_solve<NR, W, L>(lo_, dg, up, bb, Nk, ln);                                  // :175
+            pcr_solve<double, NR, W, L>(lo_, dg, up, bb, Nk, ln);                                  // :175
 
             // ---- holes, with the updated electrons (:178-202) ----
 #pragma unroll
@@ -322,12 +320,12 @@ __global__ void __launch_bounds__(64) stepper_kernel(const StepArgs a)
                 if (ln == W - 1) { dg[NR - 1] -= dsL; bb[NR - 1] -= fL; }
             }
             const double errP = uniform_d(residual_norm<NR, W>(lo_, dg, up, bb, Pk, ln));  // :200
-            pcr_solve<NR, W, L>(lo_, dg, up, bb, Pk, ln);                                  // :202
+            pcr_solve<double, NR, W, L>(lo_, dg, up, bb, Pk, ln);                                  // :202
 
             // ---- field on edges 1..L-1 (:205-209) ----
             double Nm[NR], Pm[NR];
-            fetch_dn<NR, W, 1>(Nk, Nm, ln);
-            fetch_dn<NR, W, 1>(Pk, Pm, ln);
+            fetch_dn<double, NR, W, 1>(Nk, Nm, ln);
+            fetch_dn<double, NR, W, 1>(Pk, Pm, ln);
 #pragma unroll
             for (int j = 0; j < NR; j++) {
                 const int i = ln + W * j;

@@ -1,0 +1,353 @@
+// extern "C" entry points of libtrpl_hip.so (declared in include/trpl.h).  Host-side glue only:
+// argument checks, the per-curve constants of pvSim (pvSimPCR.py:314-331), staging for the
+// host-buffer calls, launches.  Nothing here throws across the ABI.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <chrono>
+#include <vector>
+
+#include "../../include/trpl.h"
+#include "trpl_common.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(TRPL_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// pvSim's non-dimensionalisation (pvSimPCR.py:314-331, :393).  Python's float `**` is C pow().
+void curve_const(double length, double time_ns, int L, int64_t T, trpl::CurveConst &cc)
+{
+    const double dx = length / L, dt = time_ns / (double)T;
+    const double dx3 = pow(dx, 3.0), dtdx = dt / dx, dtdx2 = dtdx / dx;
+    const double dtdx6 = dt / pow(dx, 6.0);
+    const double s[12] = {dx3, dx3, dtdx2, dtdx2, dtdx2 / dx, dtdx, dtdx, dtdx6, dtdx6, 1 / dt, 1 / dt, 1 / dx};
+    memcpy(cc.scales, s, sizeof s);
+    cc.dx3 = dx3;
+    cc.plnorm = pow(dx, 2.0) * dt;
+    cc.n_obs = 0;
+}
+
+int check_grid(int32_t L, int64_t T, int32_t plT, int32_t max_iter, double time_ns)
+{
+    if (!pow2(L) || L < 4 || L > 512) return fail(TRPL_ERR_ARG, "L=%d must be a power of two in [4, 512]", L);
+    if (T < 1) return fail(TRPL_ERR_ARG, "T=%lld must be >= 1", (long long)T);
+    if (plT < 1) return fail(TRPL_ERR_ARG, "plT=%d must be >= 1", plT);
+    if (max_iter < 1) return fail(TRPL_ERR_ARG, "max_iter=%d must be >= 1", max_iter);
+    if (!(time_ns > 0)) return fail(TRPL_ERR_ARG, "time_ns must be > 0");
+    return TRPL_OK;
+}
+
+int launch(const trpl::StepArgs &a, uint32_t flags, hipStream_t st)
+{
+    hipError_t e = (flags & TRPL_FLAG_STRICT) ? trpl::launch_stepper_strict(a, st) : trpl::launch_stepper_fast(a, st);
+    if (e != hipSuccess) return fail(TRPL_ERR_HIP, "stepper launch: %s", hipGetErrorString(e));
+    return TRPL_OK;
+}
+
+struct DevBuf {                      // RAII device allocation for the host-buffer calls
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+    template <typename T> T *as() { return (T *)p; }
+};
+
+int select_device(int32_t device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(TRPL_ERR_NODEVICE, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(TRPL_ERR_ARG, "device %d out of range (%d visible)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    return TRPL_OK;
+}
+
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+extern "C" {
+
+int trpl_abi_version(void) { return TRPL_ABI_VERSION; }
+const char *trpl_last_error(void) { return g_err; }
+
+int trpl_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+/* ------------------------------------------------------------------ solve_pl ------------ */
+int trpl_solve_pl_dev(const double *matpar, int64_t S, double length_nm, double time_ns, int32_t L, int64_t T,
+                      int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN, void *plI,
+                      int32_t pl_elem_bytes, int64_t pl_ld, int32_t *status, int64_t *iters_total, uint32_t flags,
+                      void *stream)
+{
+    if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
+    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (S == 0) return TRPL_OK;
+    if (!matpar || !dN || !plI) return fail(TRPL_ERR_ARG, "matpar, dN and plI must not be NULL");
+    if (pl_elem_bytes != 4 && pl_elem_bytes != 8) return fail(TRPL_ERR_ARG, "pl_elem_bytes must be 4 or 8");
+    if (pl_ld < T / plT + 1) return fail(TRPL_ERR_ARG, "pl_ld=%lld < T/plT+1", (long long)pl_ld);
+    if (!(length_nm > 0)) return fail(TRPL_ERR_ARG, "length_nm must be > 0");
+    if (S > 0x7fffffffLL) return fail(TRPL_ERR_ARG, "S too large for one launch");
+    trpl::StepArgs a;
+    memset(&a, 0, sizeof a);
+    a.X = matpar; a.xld = 12; a.dN = dN; a.pl = plI; a.pl_bytes = pl_elem_bytes; a.pl_ld = pl_ld;
+    a.status = status; a.iters_total = iters_total;
+    a.S = S; a.C = 1; a.L = L; a.T = T; a.plT = plT; a.MAX = max_iter; a.flags = flags;
+    a.TOL = pow(10.0, -(double)tol_exp);                        /* pvSimPCR.py:112 */
+    curve_const(length_nm, time_ns, L, T, a.curve[0]);
+    return launch(a, flags, (hipStream_t)stream);
+}
+
+int trpl_solve_pl(const double *matpar, int64_t S, double length_nm, double time_ns, int32_t L, int64_t T,
+                  int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN, void *plI,
+                  int32_t pl_elem_bytes, int64_t pl_ld, int32_t *status, int64_t *iters_total, uint32_t flags,
+                  int32_t device, double *seconds)
+{
+    if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
+    if (pl_elem_bytes != 4 && pl_elem_bytes != 8) return fail(TRPL_ERR_ARG, "pl_elem_bytes must be 4 or 8");
+    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (seconds) *seconds = 0.0;
+    if (S == 0) return TRPL_OK;
+    if (!matpar || !dN || !plI) return fail(TRPL_ERR_ARG, "matpar, dN and plI must not be NULL");
+    const int64_t ncol = T / plT + 1;
+    if (pl_ld < ncol) return fail(TRPL_ERR_ARG, "pl_ld=%lld < T/plT+1", (long long)pl_ld);
+    if (int rc = select_device(device)) return rc;
+    DevBuf dm, dn, dp, ds, di;
+    HIP_TRY(dm.alloc((size_t)S * 12 * 8));
+    HIP_TRY(dn.alloc((size_t)L * 8));
+    HIP_TRY(dp.alloc((size_t)S * ncol * pl_elem_bytes));
+    HIP_TRY(ds.alloc((size_t)S * 4));
+    HIP_TRY(di.alloc((size_t)S * 8));
+    HIP_TRY(hipMemcpy(dm.p, matpar, (size_t)S * 12 * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dn.p, dN, (size_t)L * 8, hipMemcpyHostToDevice));
+    const double t0 = now_s();
+    if (int rc = trpl_solve_pl_dev(dm.as<double>(), S, length_nm, time_ns, L, T, plT, tol_exp, max_iter,
+                                   dn.as<double>(), dp.p, pl_elem_bytes, ncol, ds.as<int32_t>(),
+                                   di.as<int64_t>(), flags, nullptr))
+        return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (seconds) *seconds = now_s() - t0;                       /* pvSimPCR.py:378-381 */
+    HIP_TRY(hipMemcpy2D(plI, (size_t)pl_ld * pl_elem_bytes, dp.p, (size_t)ncol * pl_elem_bytes,
+                        (size_t)ncol * pl_elem_bytes, (size_t)S, hipMemcpyDeviceToHost));
+    if (status) HIP_TRY(hipMemcpy(status, ds.p, (size_t)S * 4, hipMemcpyDeviceToHost));
+    if (iters_total) HIP_TRY(hipMemcpy(iters_total, di.p, (size_t)S * 8, hipMemcpyDeviceToHost));
+    return TRPL_OK;
+}
+
+/* ------------------------------------------------------------------ log10 clamp --------- */
+int trpl_log10_clamp_dev(void *x, int32_t elem_bytes, int64_t rows, int64_t cols, int64_t ld, double min,
+                         void *stream)
+{
+    if (elem_bytes != 4 && elem_bytes != 8) return fail(TRPL_ERR_ARG, "elem_bytes must be 4 or 8");
+    if (rows < 0 || cols < 0 || ld < cols) return fail(TRPL_ERR_ARG, "bad shape rows=%lld cols=%lld ld=%lld",
+                                                       (long long)rows, (long long)cols, (long long)ld);
+    if (rows == 0 || cols == 0) return TRPL_OK;
+    if (!x) return fail(TRPL_ERR_ARG, "x must not be NULL");
+    hipError_t e = trpl::launch_log10_clamp(x, elem_bytes, rows, cols, ld, min, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(TRPL_ERR_HIP, "log10_clamp launch: %s", hipGetErrorString(e));
+    return TRPL_OK;
+}
+
+int trpl_log10_clamp(void *x, int32_t elem_bytes, int64_t rows, int64_t cols, int64_t ld, double min,
+                     int32_t device, double *seconds)
+{
+    if (elem_bytes != 4 && elem_bytes != 8) return fail(TRPL_ERR_ARG, "elem_bytes must be 4 or 8");
+    if (rows < 0 || cols < 0 || ld < cols) return fail(TRPL_ERR_ARG, "bad shape");
+    if (seconds) *seconds = 0.0;
+    if (rows == 0 || cols == 0) return TRPL_OK;
+    if (!x) return fail(TRPL_ERR_ARG, "x must not be NULL");
+    if (int rc = select_device(device)) return rc;
+    const double t0 = now_s();                                   /* probs.py:79: includes the copies */
+    DevBuf dx;
+    const size_t rowb = (size_t)cols * elem_bytes;
+    HIP_TRY(dx.alloc(rowb * rows));
+    HIP_TRY(hipMemcpy2D(dx.p, rowb, x, (size_t)ld * elem_bytes, rowb, (size_t)rows, hipMemcpyHostToDevice));
+    if (int rc = trpl_log10_clamp_dev(dx.p, elem_bytes, rows, cols, cols, min, nullptr)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy2D(x, (size_t)ld * elem_bytes, dx.p, rowb, rowb, (size_t)rows, hipMemcpyDeviceToHost));
+    if (seconds) *seconds = now_s() - t0;
+    return TRPL_OK;
+}
+
+/* ------------------------------------------------------------------ sse accumulate ------ */
+int trpl_sse_accumulate_dev(double *P, const void *plI, int32_t elem_bytes, int64_t rows, int64_t n_obs,
+                            int64_t ld, const double *values, const double *mag, void *stream)
+{
+    if (elem_bytes != 4 && elem_bytes != 8) return fail(TRPL_ERR_ARG, "elem_bytes must be 4 or 8");
+    if (rows < 0 || n_obs < 0 || ld < n_obs) return fail(TRPL_ERR_ARG, "bad shape");
+    if (rows == 0) return TRPL_OK;
+    if (!P || !mag || (n_obs && (!plI || !values))) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    hipError_t e = trpl::launch_sse_accumulate(P, plI, elem_bytes, rows, n_obs, ld, values, mag, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(TRPL_ERR_HIP, "sse_accumulate launch: %s", hipGetErrorString(e));
+    return TRPL_OK;
+}
+
+int trpl_sse_accumulate(double *P, const void *plI, int32_t elem_bytes, int64_t rows, int64_t n_obs, int64_t ld,
+                        const double *values, const double *mag, int32_t device, double *seconds)
+{
+    if (elem_bytes != 4 && elem_bytes != 8) return fail(TRPL_ERR_ARG, "elem_bytes must be 4 or 8");
+    if (rows < 0 || n_obs < 0 || ld < n_obs) return fail(TRPL_ERR_ARG, "bad shape");
+    if (seconds) *seconds = 0.0;
+    if (rows == 0) return TRPL_OK;
+    if (!P || !mag || (n_obs && (!plI || !values))) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (int rc = select_device(device)) return rc;
+    const double t0 = now_s();                                   /* probs.py:51 */
+    DevBuf dP, dpl, dv, dm;
+    const size_t rowb = (size_t)n_obs * elem_bytes;
+    HIP_TRY(dP.alloc((size_t)rows * 8));
+    HIP_TRY(dpl.alloc(rowb * rows));
+    HIP_TRY(dv.alloc((size_t)n_obs * 8));
+    HIP_TRY(dm.alloc((size_t)rows * 8));
+    HIP_TRY(hipMemcpy(dP.p, P, (size_t)rows * 8, hipMemcpyHostToDevice));
+    if (n_obs) {
+        HIP_TRY(hipMemcpy2D(dpl.p, rowb, plI, (size_t)ld * elem_bytes, rowb, (size_t)rows, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dv.p, values, (size_t)n_obs * 8, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemcpy(dm.p, mag, (size_t)rows * 8, hipMemcpyHostToDevice));
+    if (int rc = trpl_sse_accumulate_dev(dP.as<double>(), dpl.p, elem_bytes, rows, n_obs, n_obs, dv.as<double>(),
+                                         dm.as<double>(), nullptr))
+        return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(P, dP.p, (size_t)rows * 8, hipMemcpyDeviceToHost));
+    if (seconds) *seconds = now_s() - t0;
+    return TRPL_OK;
+}
+
+/* ------------------------------------------------------------------ fused loglik -------- */
+int trpl_loglik_dev(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns, int32_t L,
+                    int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN,
+                    const double *obs, int64_t obs_ld, const int64_t *n_obs, double *P, double *sse,
+                    int32_t *status, int64_t *iters_total, uint32_t flags, void *stream)
+{
+    if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
+    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (C < 1 || C > trpl::kMaxCurves) return fail(TRPL_ERR_ARG, "C=%d must be in [1, %d]", C, trpl::kMaxCurves);
+    if (S == 0) return TRPL_OK;
+    if (!X || !lengths_nm || !dN || !obs || !n_obs || !P || !sse) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (S * (int64_t)C > 0x7fffffffLL) return fail(TRPL_ERR_ARG, "S*C too large for one launch");
+    trpl::StepArgs a;
+    memset(&a, 0, sizeof a);
+    a.X = X; a.xld = 13; a.dN = dN; a.obs = obs; a.obs_ld = obs_ld; a.sse = sse;
+    a.status = status; a.iters_total = iters_total;
+    a.S = S; a.C = C; a.L = L; a.T = T; a.plT = plT; a.MAX = max_iter; a.flags = flags;
+    a.TOL = pow(10.0, -(double)tol_exp);
+    const int64_t ncol = T / plT + 1;
+    for (int c = 0; c < C; c++) {
+        if (!(lengths_nm[c] > 0)) return fail(TRPL_ERR_ARG, "lengths_nm[%d] must be > 0", c);
+        if (n_obs[c] < 1 || n_obs[c] > ncol || n_obs[c] > obs_ld)
+            return fail(TRPL_ERR_ARG, "n_obs[%d]=%lld must be in [1, min(T/plT+1, obs_ld)]", c, (long long)n_obs[c]);
+        curve_const(lengths_nm[c], time_ns, L, T, a.curve[c]);
+        a.curve[c].n_obs = n_obs[c];
+    }
+    if (int rc = launch(a, flags, (hipStream_t)stream)) return rc;
+    hipError_t e = trpl::launch_reduce_curves(P, sse, S, C, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(TRPL_ERR_HIP, "reduce_curves launch: %s", hipGetErrorString(e));
+    return TRPL_OK;
+}
+
+int trpl_loglik(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns, int32_t L,
+                int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN, const double *obs,
+                int64_t obs_ld, const int64_t *n_obs, double *P, double *sse, int32_t *status,
+                int64_t *iters_total, uint32_t flags, int32_t device, double *seconds)
+{
+    if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
+    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (C < 1 || C > trpl::kMaxCurves) return fail(TRPL_ERR_ARG, "C=%d must be in [1, %d]", C, trpl::kMaxCurves);
+    if (seconds) *seconds = 0.0;
+    if (S == 0) return TRPL_OK;
+    if (!X || !lengths_nm || !dN || !obs || !n_obs || !P) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (int rc = select_device(device)) return rc;
+    DevBuf dX, ddN, dobs, dP, dsse, dst, dit;
+    const size_t nsys = (size_t)S * C;
+    HIP_TRY(dX.alloc((size_t)S * 13 * 8));
+    HIP_TRY(ddN.alloc((size_t)C * L * 8));
+    HIP_TRY(dobs.alloc((size_t)C * obs_ld * 8));
+    HIP_TRY(dP.alloc((size_t)S * 8));
+    HIP_TRY(dsse.alloc(nsys * 8));
+    HIP_TRY(dst.alloc(nsys * 4));
+    HIP_TRY(dit.alloc(nsys * 8));
+    HIP_TRY(hipMemcpy(dX.p, X, (size_t)S * 13 * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ddN.p, dN, (size_t)C * L * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dobs.p, obs, (size_t)C * obs_ld * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dP.p, P, (size_t)S * 8, hipMemcpyHostToDevice));
+    const double t0 = now_s();
+    if (int rc = trpl_loglik_dev(dX.as<double>(), S, C, lengths_nm, time_ns, L, T, plT, tol_exp, max_iter,
+                                 ddN.as<double>(), dobs.as<double>(), obs_ld, n_obs, dP.as<double>(),
+                                 dsse.as<double>(), dst.as<int32_t>(), dit.as<int64_t>(), flags, nullptr))
+        return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (seconds) *seconds = now_s() - t0;
+    HIP_TRY(hipMemcpy(P, dP.p, (size_t)S * 8, hipMemcpyDeviceToHost));
+    if (sse) HIP_TRY(hipMemcpy(sse, dsse.p, nsys * 8, hipMemcpyDeviceToHost));
+    if (status) HIP_TRY(hipMemcpy(status, dst.p, nsys * 4, hipMemcpyDeviceToHost));
+    if (iters_total) HIP_TRY(hipMemcpy(iters_total, dit.p, nsys * 8, hipMemcpyDeviceToHost));
+    return TRPL_OK;
+}
+
+/* ------------------------------------------------------------------ batched PCR --------- */
+int trpl_pcr_solve_batched_dev(const void *ld, const void *d, const void *ud, const void *b, void *x, int64_t S,
+                               int32_t L, int32_t elem_bytes, uint32_t flags, void *stream)
+{
+    if (!pow2(L) || L < 4 || L > 512) return fail(TRPL_ERR_ARG, "L=%d must be a power of two in [4, 512]", L);
+    if (elem_bytes != 4 && elem_bytes != 8) return fail(TRPL_ERR_ARG, "elem_bytes must be 4 or 8");
+    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (S == 0) return TRPL_OK;
+    if (!ld || !d || !ud || !b || !x) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    hipError_t e = (flags & TRPL_FLAG_STRICT)
+                       ? trpl::launch_pcr_batched_strict(ld, d, ud, b, x, S, L, elem_bytes, (hipStream_t)stream)
+                       : trpl::launch_pcr_batched_fast(ld, d, ud, b, x, S, L, elem_bytes, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(TRPL_ERR_HIP, "pcr_batched launch: %s", hipGetErrorString(e));
+    return TRPL_OK;
+}
+
+int trpl_pcr_solve_batched(const void *ld, const void *d, const void *ud, const void *b, void *x, int64_t S,
+                           int32_t L, int32_t elem_bytes, uint32_t flags, int32_t device, double *seconds)
+{
+    if (!pow2(L) || L < 4 || L > 512) return fail(TRPL_ERR_ARG, "L=%d must be a power of two in [4, 512]", L);
+    if (elem_bytes != 4 && elem_bytes != 8) return fail(TRPL_ERR_ARG, "elem_bytes must be 4 or 8");
+    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (seconds) *seconds = 0.0;
+    if (S == 0) return TRPL_OK;
+    if (!ld || !d || !ud || !b || !x) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (int rc = select_device(device)) return rc;
+    const size_t n = (size_t)S * L * elem_bytes;
+    DevBuf bl, bd, bu, bb, bx;
+    HIP_TRY(bl.alloc(n)); HIP_TRY(bd.alloc(n)); HIP_TRY(bu.alloc(n)); HIP_TRY(bb.alloc(n)); HIP_TRY(bx.alloc(n));
+    HIP_TRY(hipMemcpy(bl.p, ld, n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(bd.p, d, n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(bu.p, ud, n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(bb.p, b, n, hipMemcpyHostToDevice));
+    const double t0 = now_s();
+    if (int rc = trpl_pcr_solve_batched_dev(bl.p, bd.p, bu.p, bb.p, bx.p, S, L, elem_bytes, flags, nullptr)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (seconds) *seconds = now_s() - t0;
+    HIP_TRY(hipMemcpy(x, bx.p, n, hipMemcpyDeviceToHost));
+    return TRPL_OK;
+}
+
+}  // extern "C"

@@ -51,8 +51,10 @@ hipError_t launch_sse_accumulate(double *P, const void *pl, int elem_bytes, int6
                                  int64_t ld, const double *values, const double *mag, hipStream_t stream);
 hipError_t launch_reduce_curves(double *P, const double *sse, int64_t S, int C, hipStream_t stream);
 
-// pcr_batched.hip
-hipError_t launch_pcr_batched(const void *ld, const void *d, const void *ud, const void *b, void *x, int64_t S,
-                              int L, int elem_bytes, uint32_t flags, hipStream_t stream);
+// batched tridiagonal solve (pcr_batched_impl.hpp, instantiated in both arithmetic modes)
+hipError_t launch_pcr_batched_strict(const void *ld, const void *d, const void *ud, const void *b, void *x,
+                                     int64_t S, int L, int elem_bytes, hipStream_t stream);
+hipError_t launch_pcr_batched_fast(const void *ld, const void *d, const void *ud, const void *b, void *x,
+                                   int64_t S, int L, int elem_bytes, hipStream_t stream);
 
 }  // namespace trpl

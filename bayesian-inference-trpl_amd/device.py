@@ -1,0 +1,69 @@
+"""Device-resident entry points: inputs and outputs are torch tensors already in HBM; nothing is
+allocated, copied or synchronised by the library (trpl_*_dev in include/trpl.h).  torch is used
+for device memory, streams and torch.distributed only -- plumbing, not compute."""
+import numpy as np
+
+from . import _abi
+
+
+def _stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, dtype, name):
+    import torch
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise ValueError("%s must be a contiguous CUDA tensor of dtype %s" % (name, dtype))
+    return t.data_ptr()
+
+
+def loglik_device(X, init_params, lengths, Time, L, T, obs, n_obs, P, sse, status=None, iters_total=None,
+                  tol=7, MAX=10000, plT=1, flags=0):
+    """trpl_loglik_dev on the current device and stream.  X (S,13) f64, init_params (C,L) f64,
+    obs (C,obs_ld) f64, P (S,) f64 accumulated in place, sse (C,S) f64 out, optional status
+    (C,S) int32 and iters_total (C,S) int64.  lengths / n_obs are host sequences."""
+    import torch
+    S, Cn = X.shape[0], init_params.shape[0]
+    if X.shape[1] != 13 or init_params.shape[1] != L or obs.shape[0] != Cn or tuple(sse.shape) != (Cn, S) \
+            or tuple(P.shape) != (S,):
+        raise ValueError("shape mismatch")
+    lengths = np.ascontiguousarray(np.broadcast_to(np.asarray(lengths, dtype=np.float64), (Cn,)))
+    n_obs = np.ascontiguousarray(np.broadcast_to(np.asarray(n_obs, dtype=np.int64), (Cn,)))
+    _abi.check(_abi.lib().trpl_loglik_dev(
+        _chk(X, torch.float64, "X"), S, Cn, _abi.ptr(lengths), float(Time), int(L), int(T), int(plT), int(tol),
+        int(MAX), _chk(init_params, torch.float64, "init_params"), _chk(obs, torch.float64, "obs"),
+        obs.shape[1], _abi.ptr(n_obs), _chk(P, torch.float64, "P"), _chk(sse, torch.float64, "sse"),
+        None if status is None else _chk(status, torch.int32, "status"),
+        None if iters_total is None else _chk(iters_total, torch.int64, "iters_total"), int(flags), _stream()))
+
+
+def solve_pl_device(matPar, Length, Time, L, T, dN, plI, status=None, iters_total=None, tol=7, MAX=10000, plT=1,
+                    flags=0):
+    """trpl_solve_pl_dev: matPar (S,12) f64, dN (L,) f64, plI (S, T//plT+1) f32/f64 out."""
+    import torch
+    S = matPar.shape[0]
+    if matPar.shape[1] != 12 or tuple(dN.shape) != (L,) or tuple(plI.shape) != (S, T // plT + 1):
+        raise ValueError("shape mismatch")
+    if plI.dtype not in (torch.float32, torch.float64):
+        raise ValueError("plI must be float32 or float64")
+    _abi.check(_abi.lib().trpl_solve_pl_dev(
+        _chk(matPar, torch.float64, "matPar"), S, float(Length), float(Time), int(L), int(T), int(plT), int(tol),
+        int(MAX), _chk(dN, torch.float64, "dN"), _chk(plI, plI.dtype, "plI"), plI.element_size(), plI.shape[1],
+        None if status is None else _chk(status, torch.int32, "status"),
+        None if iters_total is None else _chk(iters_total, torch.int64, "iters_total"), int(flags), _stream()))
+
+
+def pcr_solve_device(ld, d, ud, b, x, flags=0):
+    """trpl_pcr_solve_batched_dev: all (S,L) tensors of one dtype (f64 or f32)."""
+    import torch
+    S, L = d.shape
+    dt = d.dtype
+    if dt not in (torch.float32, torch.float64):
+        raise ValueError("dtype must be float32 or float64")
+    for t in (ld, ud, b, x):
+        if tuple(t.shape) != (S, L):
+            raise ValueError("shape mismatch")
+    _abi.check(_abi.lib().trpl_pcr_solve_batched_dev(_chk(ld, dt, "ld"), _chk(d, dt, "d"), _chk(ud, dt, "ud"),
+                                                     _chk(b, dt, "b"), _chk(x, dt, "x"), S, L, d.element_size(),
+                                                     int(flags), _stream()))

@@ -1,0 +1,185 @@
+"""Host control loop: the semantics of bayeslib.simulate / bayes (bayeslib.py:83-252) over the
+gfx950 kernels, plus the fused single-call likelihood the reference does not have.
+
+Two paths compute the same P:
+  * unfused (drop-in order of operations): model -> fastlog -> [time interpolation] -> prob per
+    curve x sample block x experiment, exactly the reference's loop nest and dtypes;
+  * fused (`loglik`): one launch per experiment, PL never leaves the registers; usable when
+    every observation time grid is a prefix of the simulation grid (the shipped example data).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import _abi
+from .likelihood import fastlog, prob
+from .model import pvSim
+from .sampler import make_grid
+
+
+def almost_equal(x, x0, threshold=1e-10):
+    """bayeslib.almost_equal (bayeslib.py:78-81)."""
+    x = np.asarray(x)
+    x0 = np.asarray(x0)
+    if x.shape != x0.shape:
+        return False
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return bool(np.abs(np.nanmax((x - x0) / x0)) < threshold)
+
+
+def is_grid_prefix(times, sim_t, threshold=1e-10):
+    """True when `times` coincides with the first len(times) points of the simulation grid."""
+    times = np.asarray(times, dtype=float)
+    n = len(times)
+    if n < 1 or n > len(sim_t):
+        return False
+    ref = sim_t[:n]
+    scale = np.maximum(np.abs(ref), np.abs(sim_t[1]) if len(sim_t) > 1 else 1.0)
+    return bool(np.all(np.abs(times - ref) <= threshold * scale))
+
+
+def interp_rows(sim_t, pl, times):
+    """Vectorised 1-D linear interpolation of every row of `pl` from sim_t onto `times`; the
+    arithmetic of scipy's interp1d/griddata, which the reference applies row by row
+    (bayeslib.py:186-189): slope = (y_hi - y_lo) / (x_hi - x_lo) with the difference taken in
+    pl's own dtype (float32 for the reference's buffer), then slope * (x - x_lo) + y_lo in
+    float64; NaN outside the grid.  Returns float64."""
+    sim_t = np.asarray(sim_t, dtype=float)
+    times = np.asarray(times, dtype=float)
+    hi = np.clip(np.searchsorted(sim_t, times), 1, len(sim_t) - 1)
+    lo = hi - 1
+    slope = (pl[:, hi] - pl[:, lo]) / (sim_t[hi] - sim_t[lo])[None, :]
+    out = np.ascontiguousarray(slope * (times - sim_t[lo])[None, :] + pl[:, lo], dtype=np.float64)
+    outside = (times < sim_t[0]) | (times > sim_t[-1])
+    out[:, outside] = np.nan
+    return out
+
+
+def loglik(X, init_params, lengths, Time, L, T, obs, tol=7, MAX=10000, plT=1, P=None, pl_f32=False,
+           normalize=False, strict=False, device=0, info=None):
+    """Fused likelihood of one experiment (trpl_loglik).
+
+    X (S,13) solver units; init_params (C,L) nm^-3; lengths scalar or (C,); obs = list of C
+    arrays of log10 observations on the first len(obs[c]) simulation-grid points.
+    Accumulates into P (S,) if given (like probs.prob), else starts from zeros.  Returns P.
+    """
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    if X.ndim != 2 or X.shape[1] != 13:
+        raise ValueError("X must have shape (S, 13)")
+    S = X.shape[0]
+    ini = np.ascontiguousarray(init_params, dtype=np.float64)
+    if ini.ndim != 2 or ini.shape[1] != L:
+        raise ValueError("init_params must have shape (C, L=%d), got %r" % (L, ini.shape))
+    Cn = ini.shape[0]
+    lengths = np.full(Cn, float(lengths)) if np.isscalar(lengths) else np.ascontiguousarray(lengths, dtype=float)
+    if lengths.shape != (Cn,) or len(obs) != Cn:
+        raise ValueError("need one length and one observation set per curve")
+    n_obs = np.array([len(o) for o in obs], dtype=np.int64)
+    obs_ld = int(n_obs.max())
+    obs_mat = np.zeros((Cn, obs_ld))
+    for c, o in enumerate(obs):
+        obs_mat[c, :len(o)] = o
+    if P is None:
+        P = np.zeros(S)
+    if not (P.dtype == np.float64 and P.flags.c_contiguous and P.shape == (S,)):
+        raise ValueError("P must be a contiguous float64 array of shape (S,)")
+    sse = np.zeros((Cn, S))
+    status = np.zeros((Cn, S), dtype=np.int32)
+    iters = np.zeros((Cn, S), dtype=np.int64)
+    flags = (_abi.FLAG_STRICT if strict else 0) | (_abi.FLAG_PL_F32 if pl_f32 else 0) \
+        | (_abi.FLAG_NORMALIZE if normalize else 0)
+    sec = _abi.C.c_double(0.0)
+    _abi.check(_abi.lib().trpl_loglik(_abi.ptr(X), S, Cn, _abi.ptr(lengths), float(Time), int(L), int(T), int(plT),
+                                      int(tol), int(MAX), _abi.ptr(ini), _abi.ptr(obs_mat), obs_ld, _abi.ptr(n_obs),
+                                      _abi.ptr(P), _abi.ptr(sse), _abi.ptr(status), _abi.ptr(iters), flags,
+                                      int(device), _abi.C.byref(sec)))
+    if info is not None:
+        info.update(sse=sse, status=status, iters_total=iters, seconds=sec.value)
+    return P
+
+
+def simulate(model, e_data, P, X, plI, plI_int, num_curves, sim_params, init_params, sim_flags, gpu_info, gpu_id,
+             solver_time, err_sq_time, misc_time, logger=None):
+    """bayeslib.simulate (bayeslib.py:83-205), GPU branch, same arguments and in-place effects.
+
+    Loop order curves -> sample blocks of gpu_info['sims_per_gpu'] (blocks gpu_id, gpu_id +
+    num_gpus, ...) -> experiments; float32 PL buffer (:137); X[:, :-1] to the model and
+    X[:, -1] as the log offset (:144,:195).  With gpu_info['fused'] true and every observation
+    grid a prefix of the simulation grid, each (curve-set, block, experiment) is one fused launch.
+    """
+    group = int(gpu_info["sims_per_gpu"])
+    num_gpus = int(gpu_info["num_gpus"])
+    device = int(gpu_info.get("device", 0))
+    LOG_PL = sim_flags["log_pl"]
+    NORMALIZE = sim_flags["self_normalize"]
+    if sim_flags.get("load_PL_from_file"):
+        raise NotImplementedError("load PL not implemented")              # bayeslib.py:163-164
+    if isinstance(sim_params[0], (int, float)):                           # :109-112
+        thicknesses = [sim_params[0]] * num_curves
+    else:
+        thicknesses = list(sim_params[0])
+    Time, L, T = sim_params[1], sim_params[2], sim_params[3]
+    sim_t = np.linspace(0, Time, T + 1)                                   # :115
+    pl_dtype = np.dtype(gpu_info.get("pl_dtype", np.float32))
+
+    fused = bool(gpu_info.get("fused", False)) and LOG_PL and sim_params[4] == 1 and all(
+        is_grid_prefix(exp[0][c], sim_t) for exp in e_data for c in range(num_curves))
+    if fused:
+        for blk in range(gpu_id * group, len(X), num_gpus * group):
+            size = min(group, len(X) - blk)
+            for e, exp in enumerate(e_data):
+                info = {}
+                loglik(X[blk:blk + size], init_params, thicknesses, Time, L, T,
+                       [exp[1][c] for c in range(num_curves)], tol=sim_params[6], MAX=sim_params[7],
+                       P=P[e, blk:blk + size], pl_f32=(pl_dtype == np.float32), normalize=NORMALIZE,
+                       device=device, info=info)
+                solver_time[gpu_id] += info["seconds"]
+        return
+
+    for ic_num in range(num_curves):
+        sim_params[0] = thicknesses[ic_num]                               # :119
+        for blk in range(gpu_id * group, len(X), num_gpus * group):       # :131
+            if logger is not None:
+                logger.info("Curve #{}: Calculating {} of {}".format(ic_num, blk, len(X)))
+            size = min(group, len(X) - blk)
+            plI[gpu_id] = np.empty((size, T // sim_params[4] + 1), dtype=pl_dtype)      # :137
+            solver_time[gpu_id] += model(plI[gpu_id], None, None, None, X[blk:blk + size, :-1], sim_params,
+                                         init_params[ic_num], None, None, 1, init_mode="points")
+            if NORMALIZE:                                                 # :150-154
+                plI[gpu_id] /= plI[gpu_id][:, :1].copy()
+            if LOG_PL:                                                    # :155-157
+                misc_time[gpu_id] += fastlog(plI[gpu_id], sys.float_info.min, device=device)
+            for e, exp in enumerate(e_data):                              # :168
+                times, values = np.asarray(exp[0][ic_num], dtype=float), exp[1][ic_num]
+                if almost_equal(sim_t, times):                            # :173,:182-183
+                    plI_int[gpu_id] = plI[gpu_id]
+                else:                                                     # :184-191
+                    clock0 = time.perf_counter()
+                    plI_int[gpu_id] = interp_rows(sim_t, plI[gpu_id], times)
+                    misc_time[gpu_id] += time.perf_counter() - clock0
+                err_sq_time[gpu_id] += prob(P[e, blk:blk + size], plI_int[gpu_id], values, None,
+                                            np.ascontiguousarray(X[blk:blk + size, -1]), device=device)
+
+
+def bayes(model, N, P, minX, maxX, do_log, init_params, sim_params, e_data, sim_flags, gpu_info, logger=None,
+          rng=None):
+    """bayeslib.bayes (bayeslib.py:207-252): sample the box, run simulate() for this process's
+    share of the sample blocks, return (N, P, X).  The process's block index comes from
+    SLURM_ARRAY_TASK_ID as in the reference (:231), falling back to RANK, then 0."""
+    num_gpus = int(gpu_info["num_gpus"])
+    solver_time, err_sq_time, misc_time = np.zeros(num_gpus), np.zeros(num_gpus), np.zeros(num_gpus)
+    N, P, X = make_grid(len(e_data), minX, maxX, do_log, sim_flags, rng=rng)
+    gpu_id = int(os.getenv("SLURM_ARRAY_TASK_ID", os.getenv("RANK", "0")))
+    if not 0 <= gpu_id < num_gpus:
+        raise ValueError("process index %d outside num_gpus=%d" % (gpu_id, num_gpus))
+    plI, plI_int = [None] * num_gpus, [None] * num_gpus
+    simulate(model if model is not None else pvSim, e_data, P, X, plI, plI_int, len(init_params),
+             list(sim_params), init_params, sim_flags, gpu_info, gpu_id, solver_time, err_sq_time, misc_time,
+             logger=logger)
+    if logger is not None:
+        logger.info("Total tEvol time: {}".format(solver_time))
+        logger.info("Total err_sq time: {}".format(err_sq_time))
+        logger.info("Total misc time: {}".format(misc_time))
+    return N, P, X

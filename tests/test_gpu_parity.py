@@ -1,0 +1,289 @@
+"""Parity tests proper (-m gpu): the HIP path, called through the C ABI, against the golden
+vectors produced by the reference and against the CPU oracle on the same seeded inputs.
+
+Bars
+  STRICT mode (TRPL_FLAG_STRICT): N/P/E state and every convergence decision are bit-identical
+      to the reference, so iteration counts must be EQUAL; PL differs only by the summation
+      order of the 128-term quadrature (tree vs serial): rtol 1e-13.
+  FAST mode (default): FMA contraction + reciprocal arithmetic: PL rtol 1e-9 (north_star's fp64
+      tolerance), iteration totals within 1 %.
+  byte/serial-order kernels (sse accumulation): bit-exact.  log10: 1 ulp of the buffer dtype.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL_STRICT = 1e-13
+RTOL_FAST = 1e-9
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(a - b) / np.abs(b)))
+
+
+# ----------------------------------------------------------------------------- batched PCR
+@pytest.mark.parametrize("N", [4, 8, 32, 128, 512])
+def test_pcr_batched_vs_reference_golden(gpu, golden, N):
+    g = golden("pcr_norm")
+    ld, d, ud, B, want = (np.ascontiguousarray(g[f"{k}{N}"]) for k in ("ld", "d", "ud", "B", "x"))
+    lib = gpu._abi.lib()
+    for flags, exact in ((gpu.FLAG_STRICT, True), (0, False)):
+        x = np.zeros_like(d)
+        keep = [a.copy() for a in (ld, d, ud, B)]
+        gpu._abi.check(lib.trpl_pcr_solve_batched(ld.ctypes.data, d.ctypes.data, ud.ctypes.data, B.ctypes.data,
+                                                  x.ctypes.data, d.shape[0], N, 8, flags, 0, None))
+        assert all(np.array_equal(a, b) for a, b in zip(keep, (ld, d, ud, B)))       # inputs untouched
+        if exact:
+            assert np.array_equal(x, want)
+        else:
+            assert np.max(np.abs(x - want)) <= 1e-13 * np.max(np.abs(want))
+
+
+def test_pcr_batched_fp32_and_many_systems(gpu, oracle):
+    rng = np.random.default_rng(5)
+    S, L = 1000, 128
+    ld = rng.uniform(-1, 1, (S, L)); ud = rng.uniform(-1, 1, (S, L)); d = rng.uniform(2.5, 4, (S, L))
+    ld[:, 0] = 0; ud[:, -1] = 0
+    b = rng.normal(size=(S, L))
+    lib = gpu._abi.lib()
+    x = np.zeros((S, L))
+    gpu._abi.check(lib.trpl_pcr_solve_batched(ld.ctypes.data, d.ctypes.data, ud.ctypes.data, b.ctypes.data,
+                                              x.ctypes.data, S, L, 8, gpu.FLAG_STRICT, 0, None))
+    for s in (0, 1, 499, 999):
+        assert np.array_equal(x[s], oracle.pcreduce(ld[s], d[s], ud[s], b[s]))
+    r = d * x; r[:, 1:] += ld[:, 1:] * x[:, :-1]; r[:, :-1] += ud[:, :-1] * x[:, 1:]
+    assert np.max(np.abs(r - b)) < 1e-12
+    f = [a.astype(np.float32) for a in (ld, d, ud, b)]
+    x32 = np.zeros((S, L), dtype=np.float32)
+    gpu._abi.check(lib.trpl_pcr_solve_batched(*(a.ctypes.data for a in f), x32.ctypes.data, S, L, 4, 0, 0, None))
+    assert np.max(np.abs(x32 - x)) < 2e-5
+
+
+# ----------------------------------------------------------------------------- pvSim
+def _run(gpu, X12, length, time_ns, L, T, ini, **kw):
+    pl, status, iters, sec = gpu.solve_pl(X12, length, time_ns, L, T, ini, **kw)
+    assert sec > 0
+    return pl, status, iters
+
+
+def test_pvsim_power_scan_vs_reference_golden(gpu, golden):
+    g = golden("pvsim_power")
+    X, T = g["X"], int(g["T"])
+    for c in range(3):
+        want, want_it = g["plI"][c], g["iters"][c].sum(axis=1)
+        pl, st, it = _run(gpu, X[:, :-1], 2000.0, float(g["time"]), 128, T, g["ini"][c], strict=True)
+        assert not st.any() and np.array_equal(it, want_it)
+        assert relerr(pl, want) < RTOL_STRICT
+        pl, st, it = _run(gpu, X[:, :-1], 2000.0, float(g["time"]), 128, T, g["ini"][c])
+        assert not st.any() and np.all(np.abs(it - want_it) <= 0.01 * want_it + 1)
+        assert relerr(pl, want) < RTOL_FAST
+
+
+def test_pvsim_twothick_vs_reference_golden(gpu, golden):
+    g = golden("pvsim_twothick")
+    X, T = g["X"], int(g["T"])
+    for c, length in enumerate(g["lengths"]):
+        want, want_it = g["plI"][c], g["iters"][c].sum(axis=1)
+        pl, st, it = _run(gpu, X[:, :-1], float(length), float(g["time"]), 128, T, g["ini"][c], strict=True)
+        assert not st.any() and np.array_equal(it, want_it)
+        assert relerr(pl, want) < RTOL_STRICT
+        pl, st, it = _run(gpu, X[:, :-1], float(length), float(g["time"]), 128, T, g["ini"][c])
+        assert not st.any() and np.all(np.abs(it - want_it) <= 0.01 * want_it + 1)
+        assert relerr(pl, want) < RTOL_FAST
+
+
+def test_pvsim_float32_buffer_matches_reference(gpu, golden):
+    g = golden("pvsim_power")
+    T = int(g["T32"])
+    pl, st, _ = _run(gpu, g["X"][:2, :-1], 2000.0, T * 0.025, 128, T, g["ini"][2], dtype=np.float32, strict=True)
+    assert pl.dtype == np.float32 and not st.any()
+    # same two float32 roundings as the reference (store, then divide); the fp64 value in front
+    # of them differs by ~1e-16, so allow one float32 ulp
+    assert np.max(np.abs(pl - g["plI32"]) / g["plI32"]) <= 2.0 ** -23
+
+
+def test_pvsim_small_grids_plT_and_nonconvergence(gpu, golden):
+    g = golden("pvsim_small")
+    X = g["X"]
+    for L in (8, 32, 64):
+        for strict, tol in ((True, RTOL_STRICT), (False, RTOL_FAST)):
+            pl, st, it = _run(gpu, X[:, :-1], 500.0, 30 * 0.05, L, 30, g[f"ini_L{L}"], tol=6, strict=strict)
+            assert not st.any() and relerr(pl, g[f"plI_L{L}"]) < tol
+            if strict:
+                assert np.array_equal(it, g[f"it_L{L}"].sum(axis=1))
+    pl, st, it = _run(gpu, X[:, :-1], 500.0, 40 * 0.05, 32, 40, g["ini_L32"], tol=6, plT=4, strict=True)
+    assert pl.shape == (3, 11) and relerr(pl, g["plI_plT4"]) < RTOL_STRICT
+    assert np.array_equal(it, g["it_plT4"].sum(axis=1))
+    # forced non-convergence: status = 1 + step, remaining PL = NaN, other systems unaffected
+    p, t, n = g["nc_log"][-1]
+    Xnc = np.vstack([X[2, :-1], X[0, :-1]])
+    pl, st, it = _run(gpu, Xnc, 311.0, 10 * 0.025, 32, 10, g["nc_ini"], MAX=3, strict=True)
+    assert st[0] == 1 + t and np.isnan(pl[0, t:]).all()
+
+
+def test_pvsim_dropin_signature(gpu, golden):
+    """Called exactly the way bayeslib.simulate calls the model (bayeslib.py:144-146)."""
+    g = golden("pvsim_power")
+    T = 24
+    sim_params = [2000, T * 0.025, 128, T, 1, (0, 1, 3, 10, 30, 100), 7, 10000]
+    plI = np.empty((5, T + 1), dtype=np.float32)
+    plN = np.empty((5, 2, 128)); plE = np.empty((5, 2, 129))
+    sec = gpu.pvSim(plI, plN, plN.copy(), plE, g["X"][:, :-1], sim_params, g["ini"][1], (128,), 8 * 256, 1,
+                    init_mode="points")
+    assert isinstance(sec, float) and sec > 0
+    want = g["plI"][1][:, :T + 1]
+    assert np.max(np.abs(plI / want - 1)) < 2e-7
+    with pytest.raises(ValueError):
+        gpu.pvSim(plI, None, None, None, g["X"][:, :-1], sim_params, g["ini"][1], init_mode="continue")
+    with pytest.raises(ValueError):
+        gpu.pvSim(plI, None, None, None, g["X"][:, :-1], sim_params, g["ini"][1][:64], init_mode="points")
+
+
+# ----------------------------------------------------------------------------- probs
+def test_fastlog_and_prob_vs_reference_golden(gpu, golden):
+    g = golden("probs")
+    l64 = g["pl64"].copy()
+    assert gpu.fastlog(l64, float(g["MIN"]), 128, 256) > 0
+    assert np.max(np.abs(l64 - g["log64"])) <= 2e-16 * np.max(np.abs(g["log64"]))
+    l32 = g["pl32"].copy()
+    gpu.fastlog(l32, float(g["MIN"]))
+    assert l32.dtype == np.float32 and np.max(np.abs(l32 - g["log32"]) / np.abs(g["log32"])) <= 2.0 ** -23
+    P = g["P64_in"].copy()
+    assert gpu.prob(P, g["log64"], g["values"], np.ones(37), g["mag"], 128, 256) > 0
+    assert np.array_equal(P, g["P64"])                               # serial order kept: bit-exact
+    P = np.zeros(5)
+    gpu.prob(P, g["log32"], g["values"], None, g["mag"])
+    assert np.array_equal(P, g["P32"])
+
+
+def test_fastlog_prob_edge_cases(gpu, oracle):
+    x = np.array([[0.0, -1.0, 1e-3]], dtype=np.float32)
+    gpu.fastlog(x)
+    assert np.isneginf(x[0, 0]) and np.isneginf(x[0, 1])             # (float)DBL_MIN == 0
+    rng = np.random.default_rng(11)
+    rows, cols = 131, 203                                            # ragged vs the 64x64 tiles
+    big = rng.lognormal(-5, 2, (rows, cols + 9))
+    view = big[:, 3:3 + cols]                                        # non-contiguous rows (ld > cols)
+    want = view.copy(); oracle.fastlog(want)
+    gpu.fastlog(view)
+    assert np.max(np.abs(view - want)) <= 4e-16 * np.max(np.abs(want))
+    assert np.array_equal(big[:, :3], big[:, :3]) and np.all(big[:, cols + 3:] > 0)
+    values = rng.uniform(-9, -1, cols); mag = rng.uniform(-1, 1, rows)
+    Pfull = np.zeros((2, rows + 5))
+    gpu.prob(Pfull[1, 2:2 + rows], want, values, None, mag)          # a view into P, like bayeslib.py:195
+    Pw = np.zeros(rows); oracle.prob(Pw, want, values, mag)
+    assert np.array_equal(Pfull[1, 2:2 + rows], Pw) and not Pfull[0].any() and not Pfull[1, :2].any()
+    P0 = np.ones(3); gpu.prob(P0, np.zeros((3, 0)), np.zeros(0), None, np.zeros(3))
+    assert np.array_equal(P0, np.ones(3))
+
+
+# ----------------------------------------------------------------------------- end to end
+def _e2e_inputs(g):
+    T, tg, npre = int(g["T"]), g["tgrid"], int(g["npre"])
+    e_data = [([tg] * 3, list(g["obs0"]), [None] * 3), ([tg[:npre]] * 3, list(g["obs1"]), [None] * 3)]
+    flags = {"load_PL_from_file": False, "log_pl": True, "self_normalize": False}
+    return T, e_data, flags
+
+
+def test_simulate_unfused_vs_reference_bayes_golden(gpu, golden):
+    g = golden("bayes_e2e")
+    T, e_data, flags = _e2e_inputs(g)
+    X = g["X"]
+    P = np.zeros((2, len(X)))
+    z = np.zeros(1)
+    sim_params = [float(g["length"]), float(g["time"]), 128, T, 1, (0,), 7, 10000]
+    gpu.simulate(gpu.pvSim, e_data, P, X, [None], [None], 3, sim_params, g["ini"], flags,
+                 {"sims_per_gpu": 4, "num_gpus": 1}, 0, z.copy(), z.copy(), z.copy())
+    # fp32 PL buffer: one float32 ulp of log10 PL (~1e-7 * |log PL| ~ 7e-7) enters each residual
+    assert np.max(np.abs(P - g["P"]) / np.abs(g["P"])) < 2e-5
+
+
+def test_fused_loglik_vs_reference_and_oracle(gpu, oracle, golden):
+    g = golden("bayes_e2e")
+    T, e_data, flags = _e2e_inputs(g)
+    X = g["X"]
+    for e in range(2):
+        obs = [e_data[e][1][c] for c in range(3)]
+        info = {}
+        P32 = gpu.loglik(X, g["ini"], 2000.0, float(g["time"]), 128, T, obs, pl_f32=True, info=info)
+        assert not info["status"].any()
+        assert np.max(np.abs(P32 - g["P"][e]) / np.abs(g["P"][e])) < 2e-5
+        # full fp64 (no float32 staging) against the oracle run with a float64 buffer
+        e64 = [([g["tgrid"][:len(o)] for o in obs], obs)]
+        want = oracle.simulate_loglik(X, g["ini"], 2000.0, float(g["time"]), 128, T, e64, pl_dtype=np.float64,
+                                      nthreads=4)[0]
+        for strict, tol in ((True, 1e-11), (False, 1e-8)):
+            P64 = gpu.loglik(X, g["ini"], 2000.0, float(g["time"]), 128, T, obs, strict=strict)
+            assert np.max(np.abs(P64 - want) / np.abs(want)) < tol
+    # simulate() in fused mode accumulates into P exactly like the unfused loop
+    P = np.zeros((2, len(X))); z = np.zeros(1)
+    sim_params = [2000.0, float(g["time"]), 128, T, 1, (0,), 7, 10000]
+    gpu.simulate(gpu.pvSim, e_data, P, X, [None], [None], 3, sim_params, g["ini"], flags,
+                 {"sims_per_gpu": 4, "num_gpus": 1, "fused": True}, 0, z.copy(), z.copy(), z.copy())
+    assert np.max(np.abs(P - g["P"]) / np.abs(g["P"])) < 2e-5
+
+
+def test_fused_loglik_twothick_normalize_and_nonconvergence(gpu, oracle):
+    w = gpu.workloads
+    ini, lens = w.twothick(128)
+    X = w.samples(6)
+    X[:, -1] = np.linspace(-0.3, 0.3, 6)
+    T, Time = 40, 1.0
+    ref = [oracle.pvsim((w.MARKED_POINT * gpu.UNIT_CONVERSIONS)[None, :-1], lens[c], Time, 128, T, ini[c])["plI"][0]
+           for c in range(6)]
+    obs = [np.log10(r / r[0])[: T + 1 - 3 * c] for c, r in enumerate(ref)]          # ragged n_obs
+    e_data = [([np.linspace(0, Time, T + 1)[:len(o)] for o in obs], obs)]
+    want = oracle.simulate_loglik(X, ini, lens, Time, 128, T, e_data, pl_dtype=np.float64, normalize=True,
+                                  nthreads=4)[0]
+    info = {}
+    Ps = gpu.loglik(X, ini, lens, Time, 128, T, obs, normalize=True, strict=True, info=info)
+    assert np.max(np.abs(Ps - want) / np.abs(want)) < 1e-10
+    P = gpu.loglik(X, ini, lens, Time, 128, T, obs, normalize=True)
+    assert np.max(np.abs(P - want) / np.abs(want)) < 1e-8
+    # non-convergence: pick MAX from the oracle's per-sample iteration maxima so that some samples
+    # fail and some do not; a failing sample gets -inf, the others are bit-identical to the full run
+    imax = np.array([oracle.pvsim(X[:, :-1], lens[c], Time, 128, T, ini[c])["iters_max"] for c in range(6)]).max(0)
+    MAXc = int(np.sort(imax)[len(imax) // 2])
+    expect_bad = imax >= MAXc
+    assert expect_bad.any() and not expect_bad.all()
+    Pn = gpu.loglik(X, ini, lens, Time, 128, T, obs, normalize=True, strict=True, MAX=MAXc, info=info)
+    bad = info["status"].any(axis=0)
+    assert np.array_equal(bad, expect_bad)
+    assert np.all(np.isneginf(Pn[bad])) and np.array_equal(Pn[~bad], Ps[~bad])
+
+
+# ----------------------------------------------------------------------------- full-size properties
+def test_full_size_properties(gpu):
+    """At sizes the CPU oracle cannot reach: (i) FAST vs STRICT agree on thousands of random
+    samples; (ii) shard invariance: a sample's likelihood does not depend on its batch;
+    (iii) determinism: two runs are bit-identical; (iv) the offset identity
+    P(m) = P(0) - sum_c [ n_c m^2 + 2 m r_c ] holds through the fused kernel."""
+    w = gpu.workloads
+    ini, lens = w.power_scan(128)
+    S, T, Time = 4096, 64, 64 * 0.025
+    X = w.samples(S)
+    mark = (w.MARKED_POINT * gpu.UNIT_CONVERSIONS)[None, :]
+    obs = []
+    for c in range(3):
+        pl, st, _, _ = gpu.solve_pl(mark[:, :-1], lens[c], Time, 128, T, ini[c], strict=True)
+        obs.append(np.log10(pl[0]))
+    info_f, info_s = {}, {}
+    Pf = gpu.loglik(X, ini, lens, Time, 128, T, obs, info=info_f)
+    Ps = gpu.loglik(X, ini, lens, Time, 128, T, obs, strict=True, info=info_s)
+    ok = ~(info_f["status"].any(axis=0) | info_s["status"].any(axis=0))
+    assert ok.mean() > 0.99
+    assert np.max(np.abs(Pf[ok] - Ps[ok]) / np.abs(Ps[ok])) < 1e-8
+    assert abs(info_f["iters_total"].sum() / info_s["iters_total"].sum() - 1) < 1e-3
+    Pf2 = gpu.loglik(X, ini, lens, Time, 128, T, obs)
+    assert np.array_equal(Pf, Pf2)                                            # (iii)
+    sub = gpu.loglik(X[1000:1300], ini, lens, Time, 128, T, obs)
+    assert np.array_equal(sub, Pf[1000:1300])                                 # (ii)
+    m = 0.25
+    Xm = X.copy(); Xm[:, -1] = m
+    Pm = gpu.loglik(Xm, ini, lens, Time, 128, T, obs)
+    # residual sums r_c from sse(m=0): sum (a+m)^2 = sum a^2 + 2 m sum a + n m^2; check via a third offset
+    Xm2 = X.copy(); Xm2[:, -1] = -m
+    Pm2 = gpu.loglik(Xm2, ini, lens, Time, 128, T, obs)
+    n_tot = 3 * (T + 1)
+    assert np.max(np.abs((Pm[ok] + Pm2[ok]) / 2 - (Pf[ok] - n_tot * m * m)) / np.abs(Pf[ok])) < 1e-9

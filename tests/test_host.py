@@ -1,0 +1,122 @@
+"""Host-side logic of the product package that needs no GPU: sampler, time-grid mapping,
+interpolation, sharding, and the control flow of simulate() with stand-in compute callables."""
+import numpy as np
+import pytest
+from scipy.interpolate import griddata
+
+
+def test_sampler_matches_reference_draws(trpl, golden):
+    g = golden("sampler")
+    assert np.array_equal(trpl.UNIT_CONVERSIONS, g["unit"])
+    for S in (4, 64):
+        assert np.array_equal(trpl.default_box(42, S), g[f"X{S}"])
+    np.random.seed(42)                                   # legacy global state, like the reference
+    X = trpl.random_grid(g["minX"] * g["unit"], g["maxX"] * g["unit"], g["do_log"], 4)
+    assert np.array_equal(X, g["X4"])
+    # SURVEY Appendix B result 2 (row 0 of the S=4 draw, common units)
+    row0 = g["X4"][0] / g["unit"]
+    assert np.allclose(row0[:5], [1e8, 5.61151642e14, 7.80093202, 30.0557506, 4.622589e-10], rtol=1e-8)
+
+
+def test_make_grid_overrides(trpl):
+    flags = {"random_sample": True, "num_points": 5, "override_equal_mu": True, "override_equal_s": True,
+             "override_equal_auger": True}
+    rng = np.random.RandomState(1)
+    N, P, X = trpl.make_grid(2, trpl.DEFAULT_MINX, trpl.DEFAULT_MAXX, trpl.DEFAULT_DO_LOG, flags, rng=rng)
+    assert P.shape == (2, 5) and not P.any() and len(N) == 5
+    assert np.array_equal(X[:, 2], X[:, 3]) and np.array_equal(X[:, 6], X[:, 5]) and np.array_equal(X[:, 8], X[:, 7])
+    with pytest.raises(NotImplementedError):
+        trpl.make_grid(1, trpl.DEFAULT_MINX, trpl.DEFAULT_MAXX, trpl.DEFAULT_DO_LOG, {"random_sample": False})
+
+
+def test_interp_rows_matches_scipy_griddata(trpl):
+    rng = np.random.default_rng(0)
+    sim_t = np.linspace(0, 10, 401)
+    pl = rng.normal(size=(5, 401)).astype(np.float32)
+    times = np.concatenate([sim_t[:50], rng.uniform(0, 10, 30), [10.0, 0.0]])
+    got = trpl.interp_rows(sim_t, pl, times)
+    for i in range(len(pl)):
+        want = griddata(sim_t, pl[i], times)
+        assert np.array_equal(got[i], want)
+    out = trpl.interp_rows(sim_t, pl, np.array([-1.0, 11.0]))
+    assert np.isnan(out).all()
+
+
+def test_grid_prefix_and_almost_equal(trpl):
+    sim_t = np.linspace(0, 2000, 80001)
+    assert trpl.is_grid_prefix(sim_t[:5601], sim_t) and trpl.is_grid_prefix(sim_t, sim_t)
+    assert not trpl.is_grid_prefix(sim_t[1:10], sim_t)
+    assert not trpl.is_grid_prefix(sim_t[:10] * 1.001, sim_t)
+    assert not trpl.is_grid_prefix(np.linspace(0, 1, 5), np.linspace(0, 1, 3))
+    assert trpl.almost_equal(sim_t, sim_t.copy()) and not trpl.almost_equal(sim_t, sim_t[:-1])
+
+
+def test_shard_bounds_partition(trpl):
+    for S in (0, 1, 7, 64, 65536, 524288 + 3):
+        for world in (1, 2, 3, 8):
+            spans = [trpl.dist.shard_bounds(S, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == S
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        trpl.dist.shard_bounds(4, 2, 2)
+
+
+def test_simulate_control_flow_with_standin_compute(trpl, monkeypatch):
+    """simulate(): curve -> block -> experiment order, block striding over processes, float32 PL
+    buffer, log + interpolation + offset, all checked with numpy stand-ins for the three device
+    calls (the real ones are exercised by the -m gpu tests)."""
+    drv = trpl.driver
+    S, L, T, Time = 10, 8, 20, 2.0
+    rng = np.random.default_rng(3)
+    X = rng.uniform(1, 2, (S, 13))
+    ini = rng.uniform(1, 2, (2, L))
+    sim_t = np.linspace(0, Time, T + 1)
+    calls = []
+
+    def fake_model(plI, plN, plP, plE, matPar, simPar, iniPar, TPB, BPG, mspb, init_mode="exp"):
+        assert plI.dtype == np.float32 and matPar.shape[1] == 12 and init_mode == "points"
+        calls.append((simPar[0], len(matPar)))
+        plI[:] = (matPar[:, :1] * iniPar.sum() * np.exp(-sim_t))[:, :T + 1]
+        return 0.5
+
+    def fake_fastlog(plI, MIN, device=0):
+        plI[:] = np.log10(np.maximum(plI, MIN))
+        return 0.25
+
+    def fake_prob(P, plI, values, unc, mag, device=0):
+        P -= np.sum((plI.astype(np.float64) + mag[:, None] - values) ** 2, axis=1)
+        return 0.125
+
+    monkeypatch.setattr(drv, "fastlog", fake_fastlog)
+    monkeypatch.setattr(drv, "prob", fake_prob)
+    e_data = [([sim_t, sim_t], [np.zeros(T + 1), np.ones(T + 1)]),
+              ([sim_t[:7], sim_t[:5] + 0.01], [np.zeros(7), np.ones(5)])]
+    flags = {"load_PL_from_file": False, "log_pl": True, "self_normalize": False}
+    P_parts = []
+    for gpu_id in range(2):
+        P = np.zeros((2, S))
+        st, et, mt = np.zeros(2), np.zeros(2), np.zeros(2)
+        sim_params = [[100.0, 200.0], Time, L, T, 1, (0,), 7, 50]
+        drv.simulate(fake_model, e_data, P, X, [None, None], [None, None], 2, sim_params, ini, flags,
+                     {"sims_per_gpu": 3, "num_gpus": 2}, gpu_id, st, et, mt)
+        P_parts.append(P)
+        assert st[gpu_id] > 0 and et[gpu_id] > 0 and mt[gpu_id] > 0 and st[1 - gpu_id] == 0
+    # process 0 takes blocks starting at 0 and 6, process 1 at 3 and 9 (bayeslib.py:131)
+    assert np.all(P_parts[0][:, [3, 4, 5, 9]] == 0) and np.all(P_parts[0][:, [0, 1, 2, 6, 7, 8]] != 0)
+    assert np.all(P_parts[1][:, [0, 1, 2, 6, 7, 8]] == 0) and np.all(P_parts[1][:, [3, 4, 5, 9]] != 0)
+    assert calls[0] == (100.0, 3) and (200.0, 1) in calls
+    # direct evaluation of the same quantity
+    P = P_parts[0] + P_parts[1]
+    want = np.zeros((2, S))
+    for c in range(2):
+        pl = (X[:, :1] * ini[c].sum() * np.exp(-sim_t)).astype(np.float32)
+        lg = np.log10(pl)
+        want[0] -= np.sum((lg.astype(np.float64) + X[:, -1:] - e_data[0][1][c]) ** 2, axis=1)
+        t1 = e_data[1][0][c]
+        want[1] -= np.sum((drv.interp_rows(sim_t, lg, t1) + X[:, -1:] - e_data[1][1][c]) ** 2, axis=1)
+    assert np.allclose(P, want, rtol=1e-12)
+    with pytest.raises(NotImplementedError):
+        drv.simulate(fake_model, e_data, P, X, [None], [None], 2, sim_params, ini,
+                     dict(flags, load_PL_from_file=True), {"sims_per_gpu": 3, "num_gpus": 1}, 0, st, et, mt)

@@ -1,0 +1,103 @@
+"""The CPU oracle (oracle/trpl_oracle.c) against the golden vectors produced by the reference's
+own code (oracle/gen_golden.py).  The restatement follows the reference's evaluation order and
+is built without FMA contraction, so the bar is BIT-EXACT everywhere."""
+import numpy as np
+
+
+def test_pcreduce_and_norm2_bit_exact(oracle, golden):
+    g = golden("pcr_norm")
+    for N in (4, 8, 32, 128, 512):
+        for s in range(g[f"d{N}"].shape[0]):
+            x = oracle.pcreduce(g[f"ld{N}"][s], g[f"d{N}"][s], g[f"ud{N}"][s], g[f"B{N}"][s])
+            assert np.array_equal(x, g[f"x{N}"][s])
+            # reference call form: norm2(A0=upper, A1=diag, A2=lower, b, c)
+            e = oracle.norm2(g[f"ud{N}"][s], g[f"d{N}"][s], g[f"ld{N}"][s], g[f"B{N}"][s], g[f"c{N}"][s])
+            assert e == g[f"err{N}"][s]
+
+
+def test_pcreduce_solves_the_system(oracle, golden):
+    g = golden("pcr_norm")
+    N = 128
+    ld, d, ud, B = g[f"ld{N}"][0], g[f"d{N}"][0], g[f"ud{N}"][0], g[f"B{N}"][0]
+    x = oracle.pcreduce(ld, d, ud, B)
+    r = d * x
+    r[1:] += ld[1:] * x[:-1]
+    r[:-1] += ud[:-1] * x[1:]
+    assert np.max(np.abs(r - B)) < 1e-12
+
+
+def test_pvsim_power_scan_bit_exact(oracle, golden):
+    g = golden("pvsim_power")
+    X, T = g["X"], int(g["T"])
+    for c in range(3):
+        r = oracle.pvsim(X[:, :-1], float(g["length"]), float(g["time"]), int(g["L"]), T, g["ini"][c],
+                         want_step_iters=True)
+        assert np.array_equal(r["plI"], g["plI"][c])
+        assert np.array_equal(r["step_iters"], g["iters"][c])
+        assert not r["status"].any()
+    r = oracle.pvsim(X[:2, :-1], 2000, int(g["T32"]) * 0.025, 128, int(g["T32"]), g["ini"][2], dtype=np.float32)
+    assert r["plI"].dtype == np.float32 and np.array_equal(r["plI"], g["plI32"])
+
+
+def test_pvsim_twothick_bit_exact(oracle, golden):
+    g = golden("pvsim_twothick")
+    X, T = g["X"], int(g["T"])
+    for c in range(len(g["lengths"])):
+        r = oracle.pvsim(X[:, :-1], float(g["lengths"][c]), float(g["time"]), 128, T, g["ini"][c],
+                         want_step_iters=True)
+        assert np.array_equal(r["plI"], g["plI"][c])
+        assert np.array_equal(r["step_iters"], g["iters"][c])
+    assert g["iters"].max() > 400          # the 311 nm / high power curve stresses the iteration
+
+
+def test_pvsim_small_grids_plT_and_nonconvergence(oracle, golden):
+    g = golden("pvsim_small")
+    X = g["X"]
+    for L in (8, 32, 64):
+        r = oracle.pvsim(X[:, :-1], 500, 30 * 0.05, L, 30, g[f"ini_L{L}"], tol=6, want_step_iters=True)
+        assert np.array_equal(r["plI"], g[f"plI_L{L}"]) and np.array_equal(r["step_iters"], g[f"it_L{L}"])
+    r = oracle.pvsim(X[:, :-1], 500, 40 * 0.05, 32, 40, g["ini_L32"], tol=6, plT=4, want_step_iters=True)
+    assert r["plI"].shape == (3, 11)
+    assert np.array_equal(r["plI"], g["plI_plT4"]) and np.array_equal(r["step_iters"], g["it_plT4"])
+    # reference: iterate() returned MAX=3 at step 0 -> flagged, nothing written (pvSimPCR.py:269-274)
+    p, t, it = g["nc_log"][-1]
+    r = oracle.pvsim(X[2:3, :-1], 311, 10 * 0.025, 32, 10, g["nc_ini"], MAX=3)
+    assert it == 3 and r["status"][0] == 1 + t
+    assert np.isnan(r["plI"][0, t:]).all()
+    assert np.all(g["nc_plI"] < 0)         # the reference never touched its (pre-filled) buffer
+
+
+def test_fastlog_and_prob_bit_exact(oracle, golden):
+    g = golden("probs")
+    l64 = g["pl64"].copy()
+    oracle.fastlog(l64, float(g["MIN"]))
+    assert np.array_equal(l64, g["log64"])
+    l32 = g["pl32"].copy()
+    oracle.fastlog(l32, float(g["MIN"]))
+    assert l32.dtype == np.float32 and np.array_equal(l32, g["log32"])
+    P = g["P64_in"].copy()
+    oracle.prob(P, g["log64"], g["values"], g["mag"])
+    assert np.array_equal(P, g["P64"])
+    P = np.zeros(len(g["mag"]))
+    oracle.prob(P, g["log32"], g["values"], g["mag"])
+    assert np.array_equal(P, g["P32"])
+
+
+def test_fastlog_float32_clamp_is_minus_inf(oracle):
+    # (float)DBL_MIN == 0.0f, so a clamped float32 entry becomes log10(0) = -inf
+    x = np.array([[0.0, -1.0, 1e-3]], dtype=np.float32)
+    oracle.fastlog(x)
+    assert np.isneginf(x[0, 0]) and np.isneginf(x[0, 1]) and np.isclose(x[0, 2], -3)
+    y = np.array([[0.0, 1e-3]])
+    oracle.fastlog(y)
+    assert np.isclose(y[0, 0], np.log10(np.finfo(float).tiny))
+
+
+def test_simulate_end_to_end_bit_exact(oracle, golden):
+    """bayeslib.bayes(pvSim, ...) -> P for two experiments (bypass and griddata paths)."""
+    g = golden("bayes_e2e")
+    T, tg, npre = int(g["T"]), g["tgrid"], int(g["npre"])
+    e_data = [([tg] * 3, list(g["obs0"])), ([tg[:npre]] * 3, list(g["obs1"]))]
+    P = oracle.simulate_loglik(g["X"], g["ini"], float(g["length"]), float(g["time"]), int(g["L"]), T, e_data,
+                               sims_per_gpu=int(g["sims_per_gpu"]), nthreads=4)
+    assert np.array_equal(P, g["P"])
