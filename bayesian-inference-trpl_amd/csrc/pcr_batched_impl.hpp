@@ -7,7 +7,7 @@
 
 namespace trpl {
 
-template <typename T, int L>
+template <typename T, int L, bool STRICT>
 __global__ void __launch_bounds__(256) pcr_batched_kernel(const T *__restrict__ ld, const T *__restrict__ d,
                                                           const T *__restrict__ ud, const T *__restrict__ b,
                                                           T *__restrict__ x, int64_t S)
@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(256) pcr_batched_kernel(const T *__restrict__ 
             const int64_t o = base + ln + W * j;
             vl[j] = ld[o]; vd[j] = d[o]; vu[j] = ud[o]; vb[j] = b[o];
         }
-        pcr_solve<T, NR, W, L>(vl, vd, vu, vb, vx, ln);
+        tridiag_solve<STRICT, T, NR, W, L>(vl, vd, vu, vb, vx, ln);
         if (lane < W) {
 #pragma unroll
             for (int j = 0; j < NR; j++) x[base + ln + W * j] = vx[j];
@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(256) pcr_batched_kernel(const T *__restrict__ 
     }
 }
 
-template <typename T>
+template <typename T, bool STRICT>
 hipError_t launch_pcr_batched_t(const void *ld, const void *d, const void *ud, const void *b, void *x, int64_t S,
                                 int L, hipStream_t stream)
 {
@@ -45,7 +45,7 @@ hipError_t launch_pcr_batched_t(const void *ld, const void *d, const void *ud, c
     switch (L) {
 #define TRPL_CASE(LL)                                                                                      \
     case LL:                                                                                               \
-        hipLaunchKernelGGL((pcr_batched_kernel<T, LL>), grid, block, 0, stream, (const T *)ld, (const T *)d, \
+        hipLaunchKernelGGL((pcr_batched_kernel<T, LL, STRICT>), grid, block, 0, stream, (const T *)ld, (const T *)d, \
                            (const T *)ud, (const T *)b, (T *)x, S);                                        \
         break;
         TRPL_CASE(4) TRPL_CASE(8) TRPL_CASE(16) TRPL_CASE(32) TRPL_CASE(64) TRPL_CASE(128) TRPL_CASE(256)

@@ -56,7 +56,7 @@ __device__ __forceinline__ void fetch_up(const T (&x)[NR], T (&y)[NR], int ln)
 #pragma unroll
         for (int j = 0; j < NR; j++) s[j] = __shfl(x[j], src, 64);
 #pragma unroll
-        for (int j = 0; j < NR; j++) y[j] = wrap ? s[(j + 1) % NR] : s[j];
+        for (int j = 0; j < NR; j++) y[j] = wrap ? +s[(j + 1) % NR] : +s[j];
     }
 }
 
@@ -75,7 +75,7 @@ __device__ __forceinline__ void fetch_dn(const T (&x)[NR], T (&y)[NR], int ln)
 #pragma unroll
         for (int j = 0; j < NR; j++) s[j] = __shfl(x[j], src, 64);
 #pragma unroll
-        for (int j = 0; j < NR; j++) y[j] = wrap ? s[(j + NR - 1) % NR] : s[j];
+        for (int j = 0; j < NR; j++) y[j] = wrap ? +s[(j + NR - 1) % NR] : +s[j];
     }
 }
 
@@ -160,16 +160,219 @@ __device__ __forceinline__ void pcr_solve(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// FAST-mode building blocks (STRICT=false).  Same mathematics, cheaper arithmetic:
+//   * 1/x by v_rcp_f64 + two Newton steps (~1 ulp) instead of the IEEE divide expansion;
+//   * PCR on normalised rows: each row publishes (ld, ud, B)/d, so a neighbour fetch moves 3
+//     values instead of 4 and one reciprocal per row per level replaces two divides; boundary
+//     rows need no guards because their ld / ud are exact zeros (pvSimPCR.py:59,:65 guard the
+//     same rows);
+//   * unit shifts (i +- 1) by DPP wave rotates on the VALU instead of ds_bpermute through LDS.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rcp_nr(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ float rcp_nr(float d) { return 1.0f / d; }
+
+// Hide a value's provenance from the optimiser.  Without it LLVM packs the shuffled rows into a
+// vector and turns `wrap ? s[j+1] : s[j]` into a dynamically indexed extract, which lands in
+// scratch memory (seen at the stride-32 level, where the up and down sources coincide).
+template <typename T>
+__device__ __forceinline__ T pick(bool c, T a, T b)
+{
+    asm volatile("" : "+v"(a));
+    asm volatile("" : "+v"(b));
+    return c ? a : b;
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v)
+{
+    union { double d; int i[2]; } u, r;
+    u.d = v;
+    r.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], CTRL, 0xF, 0xF, false);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], CTRL, 0xF, 0xF, false);
+    return r.d;
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+constexpr int kDppWaveRol1 = 0x134;   // lane l <- lane (l+1) & 63
+constexpr int kDppWaveRor1 = 0x13C;   // lane l <- lane (l-1) & 63
+
+// y[j] = x at node i+1 / i-1; the out-of-range entry (last row's last lane / first row's first
+// lane) holds an arbitrary in-array value.  W == 64 uses DPP, narrower systems the generic path.
+template <typename T, int NR, int W>
+__device__ __forceinline__ void fetch_up1(const T (&x)[NR], T (&y)[NR], int ln)
+{
+    if constexpr (W == 64) {
+        T r[NR];
+#pragma unroll
+        for (int j = 0; j < NR; j++) r[j] = dpp_mov<kDppWaveRol1>(x[j]);
+#pragma unroll
+        for (int j = 0; j < NR - 1; j++) y[j] = ln == 63 ? +r[j + 1] : +r[j];
+        y[NR - 1] = r[NR - 1];
+    } else {
+        fetch_up<T, NR, W, 1>(x, y, ln);
+    }
+}
+template <typename T, int NR, int W>
+__device__ __forceinline__ void fetch_dn1(const T (&x)[NR], T (&y)[NR], int ln)
+{
+    if constexpr (W == 64) {
+        T r[NR];
+#pragma unroll
+        for (int j = 0; j < NR; j++) r[j] = dpp_mov<kDppWaveRor1>(x[j]);
+        y[0] = r[0];
+#pragma unroll
+        for (int j = 1; j < NR; j++) y[j] = ln == 0 ? +r[j - 1] : +r[j];
+    } else {
+        fetch_dn<T, NR, W, 1>(x, y, ln);
+    }
+}
+
+// neighbour fetch for the fast PCR: like fetch_up/fetch_dn but the entry that is always out of
+// range is not fixed up (saves the select), and stride 1 goes through DPP.
+template <typename T, int NR, int W, int RF>
+__device__ __forceinline__ void nb_up(const T (&x)[NR], T (&y)[NR], int ln)
+{
+    if constexpr (RF == 1) {
+        fetch_up1<T, NR, W>(x, y, ln);
+    } else if constexpr (RF >= W) {
+        constexpr int m = RF / W;
+#pragma unroll
+        for (int j = 0; j < NR; j++) y[j] = x[(j + m) % NR];
+    } else {
+        const int src = (ln + RF) & (W - 1);
+        const bool wrap = ln + RF >= W;
+        T s[NR];
+#pragma unroll
+        for (int j = 0; j < NR; j++) s[j] = __shfl(x[j], src, 64);
+#pragma unroll
+        for (int j = 0; j < NR - 1; j++) y[j] = pick(wrap, s[j + 1], s[j]);
+        y[NR - 1] = s[NR - 1];
+    }
+}
+template <typename T, int NR, int W, int RF>
+__device__ __forceinline__ void nb_dn(const T (&x)[NR], T (&y)[NR], int ln)
+{
+    if constexpr (RF == 1) {
+        fetch_dn1<T, NR, W>(x, y, ln);
+    } else if constexpr (RF >= W) {
+        constexpr int m = RF / W;
+#pragma unroll
+        for (int j = 0; j < NR; j++) y[j] = x[(j + NR - m) % NR];
+    } else {
+        const int src = (ln - RF) & (W - 1);
+        const bool wrap = ln < RF;
+        T s[NR];
+#pragma unroll
+        for (int j = 0; j < NR; j++) s[j] = __shfl(x[j], src, 64);
+        y[0] = s[0];
+#pragma unroll
+        for (int j = 1; j < NR; j++) y[j] = pick(wrap, s[j - 1], s[j]);
+    }
+}
+
+template <typename T, int NR, int W, int L, int RF>
+__device__ __forceinline__ void pcr_level_fast(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], int ln)
+{
+    T nl[NR], nu[NR], nB[NR];
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        const T r = rcp_nr(d[j]);
+        nl[j] = ld[j] * r; nu[j] = ud[j] * r; nB[j] = B[j] * r;
+    }
+    T l_m[NR], u_m[NR], B_m[NR], l_p[NR], u_p[NR], B_p[NR];
+    nb_dn<T, NR, W, RF>(nl, l_m, ln);
+    nb_dn<T, NR, W, RF>(nu, u_m, ln);
+    nb_dn<T, NR, W, RF>(nB, B_m, ln);
+    nb_up<T, NR, W, RF>(nl, l_p, ln);
+    nb_up<T, NR, W, RF>(nu, u_p, ln);
+    nb_up<T, NR, W, RF>(nB, B_p, ln);
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        // rows i < RF have ld == 0 and rows i >= L-RF have ud == 0 (exactly), so the wrapped
+        // neighbour values they fetched drop out
+        d[j] = d[j] - ld[j] * u_m[j] - ud[j] * l_p[j];
+        B[j] = B[j] - ld[j] * B_m[j] - ud[j] * B_p[j];
+        ld[j] = -ld[j] * l_m[j];
+        ud[j] = -ud[j] * u_p[j];
+    }
+}
+
+template <typename T, int NR, int W, int L, int RF>
+__device__ __forceinline__ void pcr_levels_fast(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], int ln)
+{
+    if constexpr (L > 2 * RF) {
+        pcr_level_fast<T, NR, W, L, RF>(ld, d, ud, B, ln);
+        pcr_levels_fast<T, NR, W, L, RF * 2>(ld, d, ud, B, ln);
+    }
+}
+
+template <typename T, int NR, int W, int L>
+__device__ __forceinline__ void pcr_solve_fast(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], T (&x)[NR],
+                                               int ln)
+{
+    pcr_levels_fast<T, NR, W, L, 1>(ld, d, ud, B, ln);
+    if constexpr (NR >= 2) {
+        constexpr int H = NR / 2;
+#pragma unroll
+        for (int j = 0; j < H; j++) {
+            const T r1 = rcp_nr(d[j + H]);
+            const T k = ud[j] * r1;
+            const T den = d[j] - ld[j + H] * k;
+            const T num = B[j] - B[j + H] * k;
+            x[j] = num * rcp_nr(den);
+            x[j + H] = (B[j + H] - ld[j + H] * x[j]) * r1;
+        }
+    } else {
+        constexpr int H = W / 2;
+        const bool low = (ln & H) == 0;
+        const T ud_o = __shfl_xor(ud[0], H, 64), d_o = __shfl_xor(d[0], H, 64), B_o = __shfl_xor(B[0], H, 64),
+                ld_o = __shfl_xor(ld[0], H, 64);
+        const T l_ud = low ? ud[0] : ud_o, l_d = low ? d[0] : d_o, l_B = low ? B[0] : B_o;
+        const T h_d = low ? d_o : d[0], h_B = low ? B_o : B[0], h_ld = low ? ld_o : ld[0];
+        const T r1 = rcp_nr(h_d);
+        const T k = l_ud * r1;
+        const T xl = (l_B - h_B * k) * rcp_nr(l_d - h_ld * k);
+        const T xh = (h_B - h_ld * xl) * r1;
+        x[0] = low ? xl : xh;
+    }
+}
+
+// mode dispatch
+template <bool STRICT, typename T, int NR, int W, int L>
+__device__ __forceinline__ void tridiag_solve(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], T (&x)[NR], int ln)
+{
+    if constexpr (STRICT) pcr_solve<T, NR, W, L>(ld, d, ud, B, x, ln);
+    else                  pcr_solve_fast<T, NR, W, L>(ld, d, ud, B, x, ln);
+}
+
 // Relative L1 residual of iterate c in the system (lower l, diagonal dg, upper u | b):
-// norm2, pvSimPCR.py:14-40.
-template <int NR, int W>
-__device__ __forceinline__ double residual_norm(const double (&l)[NR], const double (&dg)[NR],
-                                                const double (&u)[NR], const double (&b)[NR],
-                                                const double (&c)[NR], int ln)
+// norm2, pvSimPCR.py:14-40.  Returns true when sum|A c - b| / sum|b| < TOL.  STRICT forms the
+// quotient like the reference; FAST compares sum|r| < TOL * sum|b| (no divide) and uses DPP shifts.
+template <bool STRICT, int NR, int W>
+__device__ __forceinline__ bool residual_below(const double (&l)[NR], const double (&dg)[NR],
+                                               const double (&u)[NR], const double (&b)[NR],
+                                               const double (&c)[NR], double TOL, int ln)
 {
     double cm[NR], cp[NR], r[NR], ab[NR];
-    fetch_dn<double, NR, W, 1>(c, cm, ln);
-    fetch_up<double, NR, W, 1>(c, cp, ln);
+    if constexpr (STRICT) {
+        fetch_dn<double, NR, W, 1>(c, cm, ln);
+        fetch_up<double, NR, W, 1>(c, cp, ln);
+    } else {
+        fetch_dn1<double, NR, W>(c, cm, ln);
+        fetch_up1<double, NR, W>(c, cp, ln);
+    }
 #pragma unroll
     for (int j = 0; j < NR; j++) {
         // l = 0 on row 0 and u = 0 on row L-1, so the wrapped neighbour contributes +-0
@@ -178,11 +381,122 @@ __device__ __forceinline__ double residual_norm(const double (&l)[NR], const dou
     }
     const double sr = tree_sum<double, NR, W>(r);
     const double sb = tree_sum<double, NR, W>(ab);
-    return sr / sb;
+    if constexpr (STRICT) return uniform_d(sr / sb) < TOL;
+    else                  return uniform_d(sr) < TOL * uniform_d(sb);
+}
+
+
+// the 12 non-dimensional material parameters of one system (wave-uniform) + N0*P0
+struct MatPar {
+    double N0, P0, DN, DP, rate, sr0, srL, CN, CP, tauN, tauP, Lambda, n0p0;
+};
+
+// Assemble the electron (IS_N) or hole tridiagonal system of one Newton/Picard iteration:
+// pvSimPCR.py:148-170 (electrons) / :178-198 (holes).  lo = A2 (sub-diagonal), dg = A1,
+// up = A0 (super-diagonal), bb = right-hand side.  Ep[j] = E at node i+1.
+template <bool STRICT, bool IS_N, int NR, int W, int L>
+__device__ __forceinline__ void assemble(const MatPar &m, double a0, const double (&Nk)[NR], const double (&Pk)[NR],
+                                         const double (&Ek)[NR], const double (&Ep)[NR], const double (&bU)[NR],
+                                         double (&lo)[NR], double (&dg)[NR], double (&up)[NR], double (&bb)[NR],
+                                         int ln)
+{
+    const double D = IS_N ? m.DN : m.DP;
+    const double Co = IS_N ? m.CN : m.CP;        // Auger coefficient of the equation's own carrier
+    const double Cx = IS_N ? m.CP : m.CN;
+    const double tauV = IS_N ? m.tauP : m.tauN;
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        const int i = ln + W * j;
+        const bool first = i == 0, last = i == L - 1;
+        const double U = IS_N ? Nk[j] : Pk[j];   // the unknown of this equation
+        const double V = IS_N ? Pk[j] : Nk[j];   // the other carrier
+        if constexpr (STRICT) {
+            const double sE = IS_N ? Ek[j] : -Ek[j], sEp = IS_N ? Ep[j] : -Ep[j];
+            const double u_i = last ? 0.0 : D * (-sEp / 2 - 1);    // A0[i]
+            const double l_i = first ? 0.0 : D * (sE / 2 - 1);     // A2[i]
+            const double u_m = first ? 0.0 : D * (-sE / 2 - 1);    // A0[i-1]
+            const double l_p = last ? 0.0 : D * (sEp / 2 - 1);     // A2[i+1]
+            const double tp = Nk[j] * m.tauP + Pk[j] * m.tauN;
+            const double np_ = Nk[j] * Pk[j] - m.n0p0;
+            const double ds = -m.rate * V - (V * tp - tauV * np_) / (tp * tp)
+                            - (Co * Nk[j] * Pk[j] + Cx * (V * V) + Co * np_);
+            up[j] = u_i; lo[j] = l_i;
+            dg[j] = a0 - u_m - l_p - ds;
+            bb[j] = -(m.CN * Nk[j] + m.CP * Pk[j] + m.rate + 1 / tp) * np_ - ds * U - bU[j];
+        } else {
+            const double hD = IS_N ? 0.5 * D : -0.5 * D;
+            const double u_i = last ? 0.0 : __builtin_fma(-hD, Ep[j], -D);
+            const double l_i = first ? 0.0 : __builtin_fma(hD, Ek[j], -D);
+            const double u_m = first ? 0.0 : __builtin_fma(-hD, Ek[j], -D);
+            const double l_p = last ? 0.0 : __builtin_fma(hD, Ep[j], -D);
+            const double tp = Nk[j] * m.tauP + Pk[j] * m.tauN;
+            const double np_ = Nk[j] * Pk[j] - m.n0p0;
+            const double inv = rcp_nr(tp);
+            const double ds = -m.rate * V - (V * tp - tauV * np_) * (inv * inv)
+                            - (Co * Nk[j] * Pk[j] + Cx * (V * V) + Co * np_);
+            up[j] = u_i; lo[j] = l_i;
+            dg[j] = a0 - u_m - l_p - ds;
+            bb[j] = -(m.CN * Nk[j] + m.CP * Pk[j] + m.rate + inv) * np_ - ds * U - bU[j];
+        }
+    }
+    // surfaces (:164-170 / :192-198): node 0 is (lane 0, row 0), node L-1 is (lane W-1, row NR-1)
+    if constexpr (STRICT) {
+        const double N0_ = Nk[0], P0_ = Pk[0], NL = Nk[NR - 1], PL = Pk[NR - 1];
+        const double V0 = IS_N ? P0_ : N0_, VL = IS_N ? PL : NL, U0 = IS_N ? N0_ : P0_, UL = IS_N ? NL : PL;
+        const double s0 = N0_ + P0_, sL = NL + PL;
+        const double ds0 = -m.sr0 * (V0 * V0 + m.n0p0) / (s0 * s0);
+        const double dsL = -m.srL * (VL * VL + m.n0p0) / (sL * sL);
+        const double f0 = m.sr0 * (N0_ * P0_ - m.n0p0) / s0 + ds0 * U0;
+        const double fL = m.srL * (NL * PL - m.n0p0) / sL + dsL * UL;
+        if (ln == 0) { dg[0] -= ds0; bb[0] -= f0; }
+        if (ln == W - 1) { dg[NR - 1] -= dsL; bb[NR - 1] -= fL; }
+    } else {
+        // one evaluation serves both surfaces: the upper half of the wave works on node L-1
+        const bool hiHalf = ln >= W / 2;
+        const double Ns = hiHalf ? +Nk[NR - 1] : +Nk[0], Ps = hiHalf ? +Pk[NR - 1] : +Pk[0];
+        const double sr = hiHalf ? +m.srL : +m.sr0;
+        const double Vs = IS_N ? Ps : Ns, Us = IS_N ? Ns : Ps;
+        const double inv = rcp_nr(Ns + Ps);
+        const double dss = -sr * (Vs * Vs + m.n0p0) * (inv * inv);
+        const double fs = sr * (Ns * Ps - m.n0p0) * inv + dss * Us;
+        if (ln == 0) { dg[0] -= dss; bb[0] -= fs; }
+        if (ln == W - 1) { dg[NR - 1] -= dss; bb[NR - 1] -= fs; }
+    }
+}
+
+// Pointwise field update on edges 1..L-1 (pvSimPCR.py:205-209); edge 0 keeps its value (0).
+template <bool STRICT, int NR, int W>
+__device__ __forceinline__ void update_field(const MatPar &m, double a0, const double (&Nk)[NR],
+                                             const double (&Pk)[NR], const double (&bE)[NR], double (&Ek)[NR],
+                                             int ln)
+{
+    double Nm[NR], Pm[NR];
+    if constexpr (STRICT) {
+        fetch_dn<double, NR, W, 1>(Nk, Nm, ln);
+        fetch_dn<double, NR, W, 1>(Pk, Pm, ln);
+    } else {
+        fetch_dn1<double, NR, W>(Nk, Nm, ln);
+        fetch_dn1<double, NR, W>(Pk, Pm, ln);
+    }
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        const int i = ln + W * j;
+        double e;
+        if constexpr (STRICT) {
+            const double A = m.Lambda * (m.DP * (Pk[j] + Pm[j]) + m.DN * (Nk[j] + Nm[j])) / 2 + a0;
+            const double b = m.Lambda * (m.DP * (Pk[j] - Pm[j]) - m.DN * (Nk[j] - Nm[j])) - bE[j];
+            e = b / A;
+        } else {
+            const double A = (0.5 * m.Lambda) * (m.DP * (Pk[j] + Pm[j]) + m.DN * (Nk[j] + Nm[j])) + a0;
+            const double b = m.Lambda * (m.DP * (Pk[j] - Pm[j]) - m.DN * (Nk[j] - Nm[j])) - bE[j];
+            e = b * rcp_nr(A);
+        }
+        Ek[j] = i >= 1 ? e : Ek[j];
+    }
 }
 
 template <int L, bool STRICT>
-__global__ void __launch_bounds__(64) stepper_kernel(const StepArgs a)
+__global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
 {
     constexpr int W = L < 64 ? L : 64;
     constexpr int NR = L / W;
@@ -201,6 +515,7 @@ __global__ void __launch_bounds__(64) stepper_kernel(const StepArgs a)
                  tauN = xs[9] * cc.scales[9], tauP = xs[10] * cc.scales[10],
                  Lambda = xs[11] * cc.scales[11];
     const double n0p0 = N0 * P0;
+    const MatPar mp = {N0, P0, DN, DP, rate, sr0, srL, CN, CP, tauN, tauP, Lambda, n0p0};
     const double mag = a.xld > 12 ? xs[12] : 0.0;
     const double TOL = a.TOL;
     const int MAX = a.MAX;
@@ -263,78 +578,19 @@ __global__ void __launch_bounds__(64) stepper_kernel(const StepArgs a)
         int it = MAX;                              // value if the loop runs to exhaustion (:225)
         for (int iters = 0; iters < MAX; iters++) {
             double lo_[NR], dg[NR], up[NR], bb[NR], Ep[NR];
+            if constexpr (STRICT) fetch_up<double, NR, W, 1>(Ek, Ep, ln);
+            else                  fetch_up1<double, NR, W>(Ek, Ep, ln);
             // ---- electrons (:148-175) ----
-            fetch_up<double, NR, W, 1>(Ek, Ep, ln);
-#pragma unroll
-            for (int j = 0; j < NR; j++) {
-                const int i = ln + W * j;
-                const bool first = i == 0, last = i == L - 1;
-                const double u_i = last ? 0.0 : DN * (-Ep[j] / 2 - 1);    // A0[i]
-                const double l_i = first ? 0.0 : DN * (+Ek[j] / 2 - 1);   // A2[i]
-                const double u_m = first ? 0.0 : DN * (-Ek[j] / 2 - 1);   // A0[i-1]
-                const double l_p = last ? 0.0 : DN * (+Ep[j] / 2 - 1);    // A2[i+1]
-                const double tp = Nk[j] * tauP + Pk[j] * tauN;
-                const double np_ = Nk[j] * Pk[j] - n0p0;
-                const double ds = -rate * Pk[j] - (Pk[j] * tp - tauP * np_) / (tp * tp)
-                                - (CN * Nk[j] * Pk[j] + CP * (Pk[j] * Pk[j]) + CN * np_);
-                up[j] = u_i; lo_[j] = l_i;
-                dg[j] = a0 - u_m - l_p - ds;
-                bb[j] = -(CN * Nk[j] + CP * Pk[j] + rate + 1 / tp) * np_ - ds * Nk[j] - bN[j];
-            }
-            {   // surfaces (:164-170): node 0 is (lane 0, row 0), node L-1 is (lane W-1, row NR-1)
-                const double s0 = Nk[0] + Pk[0], sL = Nk[NR - 1] + Pk[NR - 1];
-                const double ds0 = -sr0 * (Pk[0] * Pk[0] + n0p0) / (s0 * s0);
-                const double dsL = -srL * (Pk[NR - 1] * Pk[NR - 1] + n0p0) / (sL * sL);
-                const double f0 = sr0 * (Nk[0] * Pk[0] - n0p0) / s0 + ds0 * Nk[0];
-                const double fL = srL * (Nk[NR - 1] * Pk[NR - 1] - n0p0) / sL + dsL * Nk[NR - 1];
-                if (ln == 0) { dg[0] -= ds0; bb[0] -= f0; }
-                if (ln == W - 1) { dg[NR - 1] -= dsL; bb[NR - 1] -= fL; }
-            }
-            const double errN = uniform_d(residual_norm<NR, W>(lo_, dg, up, bb, Nk, ln));  // :172
-            pcr_solve<double, NR, W, L>(lo_, dg, up, bb, Nk, ln);                                  // :175
-
+            assemble<STRICT, true, NR, W, L>(mp, a0, Nk, Pk, Ek, Ep, bN, lo_, dg, up, bb, ln);
+            const bool okN = residual_below<STRICT, NR, W>(lo_, dg, up, bb, Nk, TOL, ln);          // :172
+            tridiag_solve<STRICT, double, NR, W, L>(lo_, dg, up, bb, Nk, ln);                      // :175
             // ---- holes, with the updated electrons (:178-202) ----
-#pragma unroll
-            for (int j = 0; j < NR; j++) {
-                const int i = ln + W * j;
-                const bool first = i == 0, last = i == L - 1;
-                const double u_i = last ? 0.0 : DP * (+Ep[j] / 2 - 1);
-                const double l_i = first ? 0.0 : DP * (-Ek[j] / 2 - 1);
-                const double u_m = first ? 0.0 : DP * (+Ek[j] / 2 - 1);
-                const double l_p = last ? 0.0 : DP * (-Ep[j] / 2 - 1);
-                const double np_ = Nk[j] * Pk[j] - n0p0;
-                const double tp = Nk[j] * tauP + Pk[j] * tauN;
-                const double ds = -rate * Nk[j] - (Nk[j] * tp - tauN * np_) / (tp * tp)
-                                - (CP * Nk[j] * Pk[j] + CN * (Nk[j] * Nk[j]) + CP * np_);
-                up[j] = u_i; lo_[j] = l_i;
-                dg[j] = a0 - u_m - l_p - ds;
-                bb[j] = -(CN * Nk[j] + CP * Pk[j] + rate + 1 / tp) * np_ - ds * Pk[j] - bP[j];
-            }
-            {   // :192-198
-                const double s0 = Nk[0] + Pk[0], sL = Nk[NR - 1] + Pk[NR - 1];
-                const double ds0 = -sr0 * (Nk[0] * Nk[0] + n0p0) / (s0 * s0);
-                const double dsL = -srL * (Nk[NR - 1] * Nk[NR - 1] + n0p0) / (sL * sL);
-                const double f0 = sr0 * (Nk[0] * Pk[0] - n0p0) / s0 + ds0 * Pk[0];
-                const double fL = srL * (Nk[NR - 1] * Pk[NR - 1] - n0p0) / sL + dsL * Pk[NR - 1];
-                if (ln == 0) { dg[0] -= ds0; bb[0] -= f0; }
-                if (ln == W - 1) { dg[NR - 1] -= dsL; bb[NR - 1] -= fL; }
-            }
-            const double errP = uniform_d(residual_norm<NR, W>(lo_, dg, up, bb, Pk, ln));  // :200
-            pcr_solve<double, NR, W, L>(lo_, dg, up, bb, Pk, ln);                                  // :202
-
+            assemble<STRICT, false, NR, W, L>(mp, a0, Nk, Pk, Ek, Ep, bP, lo_, dg, up, bb, ln);
+            const bool okP = residual_below<STRICT, NR, W>(lo_, dg, up, bb, Pk, TOL, ln);          // :200
+            tridiag_solve<STRICT, double, NR, W, L>(lo_, dg, up, bb, Pk, ln);                      // :202
             // ---- field on edges 1..L-1 (:205-209) ----
-            double Nm[NR], Pm[NR];
-            fetch_dn<double, NR, W, 1>(Nk, Nm, ln);
-            fetch_dn<double, NR, W, 1>(Pk, Pm, ln);
-#pragma unroll
-            for (int j = 0; j < NR; j++) {
-                const int i = ln + W * j;
-                const double A = Lambda * (DP * (Pk[j] + Pm[j]) + DN * (Nk[j] + Nm[j])) / 2 + a0;
-                const double b = Lambda * (DP * (Pk[j] - Pm[j]) - DN * (Nk[j] - Nm[j])) - bE[j];
-                const double e = b / A;
-                Ek[j] = i >= 1 ? e : Ek[j];
-            }
-            if (errN < TOL && errP < TOL) { it = iters + 1; break; }                       // :213-216
+            update_field<STRICT, NR, W>(mp, a0, Nk, Pk, bE, Ek, ln);
+            if (okN && okP) { it = iters + 1; break; }                                             // :213-216
         }
         itot += it;
         if (it >= MAX) { status = 1 + (int)t; break; }                                     // :269-274

@@ -11,7 +11,7 @@ hipError_t launch_stepper_strict(const StepArgs &a, hipStream_t stream) { return
 hipError_t launch_pcr_batched_strict(const void *ld, const void *d, const void *ud, const void *b, void *x,
                                      int64_t S, int L, int elem_bytes, hipStream_t stream)
 {
-    return elem_bytes == 8 ? launch_pcr_batched_t<double>(ld, d, ud, b, x, S, L, stream)
-                           : launch_pcr_batched_t<float>(ld, d, ud, b, x, S, L, stream);
+    return elem_bytes == 8 ? launch_pcr_batched_t<double, true>(ld, d, ud, b, x, S, L, stream)
+                           : launch_pcr_batched_t<float, true>(ld, d, ud, b, x, S, L, stream);
 }
 }  // namespace trpl
