@@ -21,15 +21,28 @@ __global__ void __launch_bounds__(256) pcr_batched_kernel(const T *__restrict__ 
     for (int64_t s = wave; s < S; s += nwaves) {
         const int64_t base = s * L;
         T vl[NR], vd[NR], vu[NR], vb[NR], vx[NR];
+        if constexpr (!STRICT && L >= 128 && sizeof(T) == 8) {
+            // interleaved layout: lane owns nodes NR*lane .. NR*lane+NR-1 -> 16-byte loads, fully
+            // coalesced 1 KiB per wave-instruction
 #pragma unroll
-        for (int j = 0; j < NR; j++) {
-            const int64_t o = base + ln + W * j;
-            vl[j] = ld[o]; vd[j] = d[o]; vu[j] = ud[o]; vb[j] = b[o];
-        }
-        tridiag_solve<STRICT, T, NR, W, L>(vl, vd, vu, vb, vx, ln);
-        if (lane < W) {
+            for (int j = 0; j < NR; j++) {
+                const int64_t o = base + NR * lane + j;
+                vl[j] = ld[o]; vd[j] = d[o]; vu[j] = ud[o]; vb[j] = b[o];
+            }
+            pcr_solve_B<NR, L>(vl, vd, vu, vb, vx, lane);
 #pragma unroll
-            for (int j = 0; j < NR; j++) x[base + ln + W * j] = vx[j];
+            for (int j = 0; j < NR; j++) x[base + NR * lane + j] = vx[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                const int64_t o = base + ln + W * j;
+                vl[j] = ld[o]; vd[j] = d[o]; vu[j] = ud[o]; vb[j] = b[o];
+            }
+            tridiag_solve<STRICT, T, NR, W, L>(vl, vd, vu, vb, vx, ln);
+            if (lane < W) {
+#pragma unroll
+                for (int j = 0; j < NR; j++) x[base + ln + W * j] = vx[j];
+            }
         }
     }
 }

@@ -24,6 +24,9 @@
 #include <math.h>
 #include <float.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "trpl_common.hpp"
 
 namespace trpl {
@@ -357,34 +360,214 @@ __device__ __forceinline__ void tridiag_solve(T (&ld)[NR], T (&d)[NR], T (&ud)[N
     else                  pcr_solve_fast<T, NR, W, L>(ld, d, ud, B, x, ln);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// FAST mode, L >= 128: INTERLEAVED layout  node i = NR*lane + j  (NR = L/64 consecutive nodes per
+// lane).  Every neighbour i +- RF is then (lane +- K, row j') with K and j' known at compile
+// time, so a fetch is a pure lane shift -- no per-lane selects at all:
+//      K = 0 : in-lane register move          K = 1 : DPP wave rotate (VALU, no LDS)
+//      K >= 2: ds_bpermute                    final pairing (lane ^ 32): v_permlane32_swap
+// Wave-wide sums (residual norms, PL) are DPP row reductions ending in lane 63 + v_readlane.
+// The reduction order differs from the reference's tree, which is why STRICT mode keeps the
+// blocked layout above.
+// ------------------------------------------------------------------------------------------
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+__device__ __forceinline__ double rcp_nr1(double d)      // one Newton step: 2e-15 relative (measured)
+{
+    const double r = __builtin_amdgcn_rcp(d);
+    return __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+}
+__device__ __forceinline__ float rcp_nr1(float d) { return 1.0f / d; }
+
+template <int K, typename T>
+__device__ __forceinline__ T lane_up(T v, int lane)       // value held by lane + K (mod 64)
+{
+    if constexpr (K == 0) return v;
+    else if constexpr (K == 1) return dpp_mov<kDppWaveRol1>(v);
+    else return __shfl(v, (lane + K) & 63, 64);
+}
+template <int K, typename T>
+__device__ __forceinline__ T lane_dn(T v, int lane)       // value held by lane - K (mod 64)
+{
+    if constexpr (K == 0) return v;
+    else if constexpr (K == 1) return dpp_mov<kDppWaveRor1>(v);
+    else return __shfl(v, (lane - K) & 63, 64);
+}
+
+// y[j] = x at node i+RF / i-RF in the interleaved layout (wrapped lanes give in-array values)
+template <typename T, int NR, int RF>
+__device__ __forceinline__ void nbrB_up(const T (&x)[NR], T (&y)[NR], int lane)
+{
+    static_for<NR>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        y[j] = lane_up<(j + RF) / NR>(x[(j + RF) % NR], lane);
+    });
+}
+template <typename T, int NR, int RF>
+__device__ __forceinline__ void nbrB_dn(const T (&x)[NR], T (&y)[NR], int lane)
+{
+    static_for<NR>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int K = RF > j ? (RF - j + NR - 1) / NR : 0;
+        y[j] = lane_dn<K>(x[((j - RF) % NR + NR) % NR], lane);
+    });
+}
+
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_add(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xF, true);
+    return v + __hiloint2double(hi, lo);
+}
+// Sum of v over the 64 lanes, returned wave-uniform (SGPRs).
+__device__ __forceinline__ double wave_sum(double v)
+{
+    v = dpp_add<0x111, 0xF>(v);          // row_shr:1
+    v = dpp_add<0x112, 0xF>(v);          // row_shr:2
+    v = dpp_add<0x114, 0xF>(v);          // row_shr:4
+    v = dpp_add<0x118, 0xF>(v);          // row_shr:8   -> lane 15 of each row holds the row sum
+    v = dpp_add<0x142, 0xA>(v);          // row_bcast:15 into rows 1,3
+    v = dpp_add<0x143, 0xC>(v);          // row_bcast:31 into rows 2,3 -> lane 63 holds the total
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+// (value of the lower-half lane, value of the upper-half lane) of each lane pair (l, l^32), in
+// every lane: v_permlane32_swap on two copies of v.
+__device__ __forceinline__ void pair32(double v, double &lo_half, double &hi_half)
+{
+    const unsigned a = (unsigned)__double2loint(v), b = (unsigned)__double2hiint(v);
+    const auto r0 = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+    lo_half = __hiloint2double((int)r1[0], (int)r0[0]);
+    hi_half = __hiloint2double((int)r1[1], (int)r0[1]);
+}
+
+template <typename T, int NR, int L, int RF>
+__device__ __forceinline__ void pcr_levels_B(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], int lane)
+{
+    if constexpr (L > 2 * RF) {
+        T nl[NR], nu[NR], nB[NR];
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            const T r = rcp_nr1(d[j]);
+            nl[j] = ld[j] * r; nu[j] = ud[j] * r; nB[j] = B[j] * r;
+        }
+        T l_m[NR], u_m[NR], B_m[NR], l_p[NR], u_p[NR], B_p[NR];
+        nbrB_dn<T, NR, RF>(nl, l_m, lane);
+        nbrB_dn<T, NR, RF>(nu, u_m, lane);
+        nbrB_dn<T, NR, RF>(nB, B_m, lane);
+        nbrB_up<T, NR, RF>(nl, l_p, lane);
+        nbrB_up<T, NR, RF>(nu, u_p, lane);
+        nbrB_up<T, NR, RF>(nB, B_p, lane);
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            // rows i < RF have ld == 0 and rows i >= L-RF have ud == 0 exactly: wrapped values drop out
+            d[j] = d[j] - ld[j] * u_m[j] - ud[j] * l_p[j];
+            B[j] = B[j] - ld[j] * B_m[j] - ud[j] * B_p[j];
+            ld[j] = -ld[j] * l_m[j];
+            ud[j] = -ud[j] * u_p[j];
+        }
+        pcr_levels_B<T, NR, L, RF * 2>(ld, d, ud, B, lane);
+    }
+}
+
+// PCR solve in the interleaved layout (double only; L >= 128 so the final pairs are lanes l, l^32)
+template <int NR, int L>
+__device__ __forceinline__ void pcr_solve_B(double (&ld)[NR], double (&d)[NR], double (&ud)[NR], double (&B)[NR],
+                                            double (&x)[NR], int lane)
+{
+    pcr_levels_B<double, NR, L, 1>(ld, d, ud, B, lane);
+    const bool low = lane < 32;
+#pragma unroll
+    for (int j = 0; j < NR; j++) {                 // pvSimPCR.py:75-79 with i = lower node of the pair
+        double d_lo, d_hi, B_lo, B_hi, ud_lo, ud_hi, ld_lo, ld_hi;
+        pair32(d[j], d_lo, d_hi);
+        pair32(B[j], B_lo, B_hi);
+        pair32(ud[j], ud_lo, ud_hi);
+        pair32(ld[j], ld_lo, ld_hi);
+        const double r1 = rcp_nr1(d_hi);
+        const double k = ud_lo * r1;
+        const double xl = (B_lo - B_hi * k) * rcp_nr1(d_lo - ld_hi * k);
+        const double xh = (B_hi - ld_hi * xl) * r1;
+        x[j] = low ? xl : xh;
+    }
+}
+
+// ---- layout dispatch: LAY 0 = blocked/strict, 1 = blocked/fast (L < 128), 2 = interleaved/fast ----
+template <int LAY, int NR, int W>
+__device__ __forceinline__ constexpr int node_of(int ln, int j) { return LAY == 2 ? NR * ln + j : ln + W * j; }
+
+template <int LAY, int NR, int W>
+__device__ __forceinline__ void shift_up1(const double (&x)[NR], double (&y)[NR], int ln)
+{
+    if constexpr (LAY == 0) fetch_up<double, NR, W, 1>(x, y, ln);
+    else if constexpr (LAY == 1) fetch_up1<double, NR, W>(x, y, ln);
+    else nbrB_up<double, NR, 1>(x, y, ln);
+}
+template <int LAY, int NR, int W>
+__device__ __forceinline__ void shift_dn1(const double (&x)[NR], double (&y)[NR], int ln)
+{
+    if constexpr (LAY == 0) fetch_dn<double, NR, W, 1>(x, y, ln);
+    else if constexpr (LAY == 1) fetch_dn1<double, NR, W>(x, y, ln);
+    else nbrB_dn<double, NR, 1>(x, y, ln);
+}
+// sum over all nodes, wave-uniform
+template <int LAY, int NR, int W>
+__device__ __forceinline__ double sum_nodes(double (&v)[NR])
+{
+    if constexpr (LAY == 2) {
+        double s = v[0];
+#pragma unroll
+        for (int j = 1; j < NR; j++) s += v[j];
+        return wave_sum(s);
+    } else {
+        return uniform_d(tree_sum<double, NR, W>(v));
+    }
+}
+template <int LAY, int NR, int W, int L>
+__device__ __forceinline__ void solve_lay(double (&ld)[NR], double (&d)[NR], double (&ud)[NR], double (&B)[NR],
+                                          double (&x)[NR], int ln)
+{
+    if constexpr (LAY == 0) pcr_solve<double, NR, W, L>(ld, d, ud, B, x, ln);
+    else if constexpr (LAY == 1) pcr_solve_fast<double, NR, W, L>(ld, d, ud, B, x, ln);
+    else pcr_solve_B<NR, L>(ld, d, ud, B, x, ln);
+}
+
 // Relative L1 residual of iterate c in the system (lower l, diagonal dg, upper u | b):
-// norm2, pvSimPCR.py:14-40.  Returns true when sum|A c - b| / sum|b| < TOL.  STRICT forms the
-// quotient like the reference; FAST compares sum|r| < TOL * sum|b| (no divide) and uses DPP shifts.
-template <bool STRICT, int NR, int W>
+// norm2, pvSimPCR.py:14-40.  Returns true when sum|A c - b| / sum|b| < TOL.  STRICT (LAY 0) forms the
+// quotient like the reference; the FAST layouts compare sum|r| < TOL * sum|b| (no divide).
+template <int LAY, int NR, int W>
 __device__ __forceinline__ bool residual_below(const double (&l)[NR], const double (&dg)[NR],
                                                const double (&u)[NR], const double (&b)[NR],
                                                const double (&c)[NR], double TOL, int ln)
 {
     double cm[NR], cp[NR], r[NR], ab[NR];
-    if constexpr (STRICT) {
-        fetch_dn<double, NR, W, 1>(c, cm, ln);
-        fetch_up<double, NR, W, 1>(c, cp, ln);
-    } else {
-        fetch_dn1<double, NR, W>(c, cm, ln);
-        fetch_up1<double, NR, W>(c, cp, ln);
-    }
+    shift_dn1<LAY, NR, W>(c, cm, ln);
+    shift_up1<LAY, NR, W>(c, cp, ln);
 #pragma unroll
     for (int j = 0; j < NR; j++) {
         // l = 0 on row 0 and u = 0 on row L-1, so the wrapped neighbour contributes +-0
         r[j] = fabs(l[j] * cm[j] + dg[j] * c[j] + u[j] * cp[j] - b[j]);
         ab[j] = fabs(b[j]);
     }
-    const double sr = tree_sum<double, NR, W>(r);
-    const double sb = tree_sum<double, NR, W>(ab);
-    if constexpr (STRICT) return uniform_d(sr / sb) < TOL;
-    else                  return uniform_d(sr) < TOL * uniform_d(sb);
+    const double sr = sum_nodes<LAY, NR, W>(r);
+    const double sb = sum_nodes<LAY, NR, W>(ab);
+    if constexpr (LAY == 0) return sr / sb < TOL;
+    else                    return sr < TOL * sb;
 }
-
 
 // the 12 non-dimensional material parameters of one system (wave-uniform) + N0*P0
 struct MatPar {
@@ -394,7 +577,7 @@ struct MatPar {
 // Assemble the electron (IS_N) or hole tridiagonal system of one Newton/Picard iteration:
 // pvSimPCR.py:148-170 (electrons) / :178-198 (holes).  lo = A2 (sub-diagonal), dg = A1,
 // up = A0 (super-diagonal), bb = right-hand side.  Ep[j] = E at node i+1.
-template <bool STRICT, bool IS_N, int NR, int W, int L>
+template <int LAY, bool IS_N, int NR, int W, int L>
 __device__ __forceinline__ void assemble(const MatPar &m, double a0, const double (&Nk)[NR], const double (&Pk)[NR],
                                          const double (&Ek)[NR], const double (&Ep)[NR], const double (&bU)[NR],
                                          double (&lo)[NR], double (&dg)[NR], double (&up)[NR], double (&bb)[NR],
@@ -404,9 +587,10 @@ __device__ __forceinline__ void assemble(const MatPar &m, double a0, const doubl
     const double Co = IS_N ? m.CN : m.CP;        // Auger coefficient of the equation's own carrier
     const double Cx = IS_N ? m.CP : m.CN;
     const double tauV = IS_N ? m.tauP : m.tauN;
+    constexpr bool STRICT = LAY == 0;
 #pragma unroll
     for (int j = 0; j < NR; j++) {
-        const int i = ln + W * j;
+        const int i = node_of<LAY, NR, W>(ln, j);
         const bool first = i == 0, last = i == L - 1;
         const double U = IS_N ? Nk[j] : Pk[j];   // the unknown of this equation
         const double V = IS_N ? Pk[j] : Nk[j];   // the other carrier
@@ -465,22 +649,18 @@ __device__ __forceinline__ void assemble(const MatPar &m, double a0, const doubl
 }
 
 // Pointwise field update on edges 1..L-1 (pvSimPCR.py:205-209); edge 0 keeps its value (0).
-template <bool STRICT, int NR, int W>
+template <int LAY, int NR, int W>
 __device__ __forceinline__ void update_field(const MatPar &m, double a0, const double (&Nk)[NR],
                                              const double (&Pk)[NR], const double (&bE)[NR], double (&Ek)[NR],
                                              int ln)
 {
+    constexpr bool STRICT = LAY == 0;
     double Nm[NR], Pm[NR];
-    if constexpr (STRICT) {
-        fetch_dn<double, NR, W, 1>(Nk, Nm, ln);
-        fetch_dn<double, NR, W, 1>(Pk, Pm, ln);
-    } else {
-        fetch_dn1<double, NR, W>(Nk, Nm, ln);
-        fetch_dn1<double, NR, W>(Pk, Pm, ln);
-    }
+    shift_dn1<LAY, NR, W>(Nk, Nm, ln);
+    shift_dn1<LAY, NR, W>(Pk, Pm, ln);
 #pragma unroll
     for (int j = 0; j < NR; j++) {
-        const int i = ln + W * j;
+        const int i = node_of<LAY, NR, W>(ln, j);
         double e;
         if constexpr (STRICT) {
             const double A = m.Lambda * (m.DP * (Pk[j] + Pm[j]) + m.DN * (Nk[j] + Nm[j])) / 2 + a0;
@@ -500,6 +680,7 @@ __global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
 {
     constexpr int W = L < 64 ? L : 64;
     constexpr int NR = L / W;
+    constexpr int LAY = STRICT ? 0 : (L >= 128 ? 2 : 1);   // node layout / arithmetic flavour
     const int ln = threadIdx.x & (W - 1);          // lanes >= W replicate lane (lane mod W)
     const int64_t sys = blockIdx.x;
     const int c = (int)(sys % a.C);
@@ -528,7 +709,7 @@ __global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
         for (int j = 0; j < NR; j++) { hN[m][j] = 0.0; hP[m][j] = 0.0; hE[m][j] = 0.0; }
 #pragma unroll
     for (int j = 0; j < NR; j++) {                 // pvSimPCR.py:356-362
-        const double dn = a.dN[(int64_t)c * L + ln + W * j] * cc.dx3;
+        const double dn = a.dN[(int64_t)c * L + node_of<LAY, NR, W>(ln, j)] * cc.dx3;
         hN[0][j] = N0 + dn;
         hP[0][j] = P0 + dn;
     }
@@ -562,7 +743,7 @@ __global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
             double q[NR];
 #pragma unroll
             for (int j = 0; j < NR; j++) q[j] = hN[0][j] * hP[0][j];
-            const double Sum = tree_sum<double, NR, W>(q) + (-(double)L * n0p0);
+            const double Sum = sum_nodes<LAY, NR, W>(q) + (-(double)L * n0p0);
             plv = rate * Sum;
         }
 
@@ -578,18 +759,17 @@ __global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
         int it = MAX;                              // value if the loop runs to exhaustion (:225)
         for (int iters = 0; iters < MAX; iters++) {
             double lo_[NR], dg[NR], up[NR], bb[NR], Ep[NR];
-            if constexpr (STRICT) fetch_up<double, NR, W, 1>(Ek, Ep, ln);
-            else                  fetch_up1<double, NR, W>(Ek, Ep, ln);
+            shift_up1<LAY, NR, W>(Ek, Ep, ln);
             // ---- electrons (:148-175) ----
-            assemble<STRICT, true, NR, W, L>(mp, a0, Nk, Pk, Ek, Ep, bN, lo_, dg, up, bb, ln);
-            const bool okN = residual_below<STRICT, NR, W>(lo_, dg, up, bb, Nk, TOL, ln);          // :172
-            tridiag_solve<STRICT, double, NR, W, L>(lo_, dg, up, bb, Nk, ln);                      // :175
+            assemble<LAY, true, NR, W, L>(mp, a0, Nk, Pk, Ek, Ep, bN, lo_, dg, up, bb, ln);
+            const bool okN = residual_below<LAY, NR, W>(lo_, dg, up, bb, Nk, TOL, ln);             // :172
+            solve_lay<LAY, NR, W, L>(lo_, dg, up, bb, Nk, ln);                                     // :175
             // ---- holes, with the updated electrons (:178-202) ----
-            assemble<STRICT, false, NR, W, L>(mp, a0, Nk, Pk, Ek, Ep, bP, lo_, dg, up, bb, ln);
-            const bool okP = residual_below<STRICT, NR, W>(lo_, dg, up, bb, Pk, TOL, ln);          // :200
-            tridiag_solve<STRICT, double, NR, W, L>(lo_, dg, up, bb, Pk, ln);                      // :202
+            assemble<LAY, false, NR, W, L>(mp, a0, Nk, Pk, Ek, Ep, bP, lo_, dg, up, bb, ln);
+            const bool okP = residual_below<LAY, NR, W>(lo_, dg, up, bb, Pk, TOL, ln);             // :200
+            solve_lay<LAY, NR, W, L>(lo_, dg, up, bb, Pk, ln);                                     // :202
             // ---- field on edges 1..L-1 (:205-209) ----
-            update_field<STRICT, NR, W>(mp, a0, Nk, Pk, bE, Ek, ln);
+            update_field<LAY, NR, W>(mp, a0, Nk, Pk, bE, Ek, ln);
             if (okN && okP) { it = iters + 1; break; }                                             // :213-216
         }
         itot += it;
