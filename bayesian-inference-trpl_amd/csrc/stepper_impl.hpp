@@ -199,14 +199,14 @@ __device__ __forceinline__ double dpp_mov(double v)
 {
     union { double d; int i[2]; } u, r;
     u.d = v;
-    r.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], CTRL, 0xF, 0xF, false);
-    r.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], CTRL, 0xF, 0xF, false);
+    r.i[0] = __builtin_amdgcn_mov_dpp(u.i[0], CTRL, 0xF, 0xF, false);   // every lane is written:
+    r.i[1] = __builtin_amdgcn_mov_dpp(u.i[1], CTRL, 0xF, 0xF, false);   // no destination init needed
     return r.d;
 }
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
 }
 constexpr int kDppWaveRol1 = 0x134;   // lane l <- lane (l+1) & 63
 constexpr int kDppWaveRor1 = 0x13C;   // lane l <- lane (l-1) & 63
@@ -426,8 +426,14 @@ __device__ __forceinline__ void nbrB_dn(const T (&x)[NR], T (&y)[NR], int lane)
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ double dpp_add(double v)
 {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xF, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xF, true);
+    int lo, hi;
+    if constexpr (ROWMASK == 0xF) {      // all rows written (out-of-row sources read 0): no init
+        lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+        hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+    } else {                             // masked rows keep the 0 they are initialised with
+        lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xF, true);
+        hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xF, true);
+    }
     return v + __hiloint2double(hi, lo);
 }
 // Sum of v over the 64 lanes, returned wave-uniform (SGPRs).
@@ -676,7 +682,7 @@ __device__ __forceinline__ void update_field(const MatPar &m, double a0, const d
 }
 
 template <int L, bool STRICT>
-__global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
+__global__ void __launch_bounds__(64, STRICT ? 2 : 3) stepper_kernel(const StepArgs a)
 {
     constexpr int W = L < 64 ? L : 64;
     constexpr int NR = L / W;
@@ -701,17 +707,27 @@ __global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
     const double TOL = a.TOL;
     const int MAX = a.MAX;
 
-    // ---- state + history: h?[0] = level k (time t), h?[m] = level k-m ----
-    double hN[5][NR], hP[5][NR], hE[5][NR];
-#pragma unroll
-    for (int m = 0; m < 5; m++)
-#pragma unroll
-        for (int j = 0; j < NR; j++) { hN[m][j] = 0.0; hP[m][j] = 0.0; hE[m][j] = 0.0; }
+    // ---- state U^t (registers) and the four older BDF levels U^{t-1..t-4} ----
+    // STRICT keeps the older levels in registers.  FAST keeps them in LDS as a 4-slot ring,
+    // slot (t' mod 4) holding U^{t'}: nothing is ever moved, a step reads the four slots and then
+    // overwrites the oldest with U^t.  12 KB per wave buys ~50 VGPRs, i.e. 3 waves per SIMD.
+    constexpr int HSLOT = 3 * NR * 64;
+    __shared__ double hist[STRICT ? 1 : 4 * HSLOT];
+    const int hl = threadIdx.x;                     // this lane's column of the ring
+    double Nk[NR], Pk[NR], Ek[NR];
+    double hN[4][NR], hP[4][NR], hE[4][NR];         // STRICT only: levels t-1 .. t-4
 #pragma unroll
     for (int j = 0; j < NR; j++) {                 // pvSimPCR.py:356-362
         const double dn = a.dN[(int64_t)c * L + node_of<LAY, NR, W>(ln, j)] * cc.dx3;
-        hN[0][j] = N0 + dn;
-        hP[0][j] = P0 + dn;
+        Nk[j] = N0 + dn;
+        Pk[j] = P0 + dn;
+        Ek[j] = 0.0;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            if constexpr (STRICT) { hN[m][j] = 0.0; hP[m][j] = 0.0; hE[m][j] = 0.0; }
+            else { hist[m * HSLOT + (0 * NR + j) * 64 + hl] = 0.0; hist[m * HSLOT + (1 * NR + j) * 64 + hl] = 0.0;
+                   hist[m * HSLOT + (2 * NR + j) * 64 + hl] = 0.0; }
+        }
     }
 
     const bool want_pl = a.pl != nullptr;
@@ -742,19 +758,35 @@ __global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
         if (pl_step) {
             double q[NR];
 #pragma unroll
-            for (int j = 0; j < NR; j++) q[j] = hN[0][j] * hP[0][j];
+            for (int j = 0; j < NR; j++) q[j] = Nk[j] * Pk[j];
             const double Sum = sum_nodes<LAY, NR, W>(q) + (-(double)L * n0p0);
             plv = rate * Sum;
         }
 
         // ---------------- iterate, pvSimPCR.py:93-225 ----------------
-        double Nk[NR], Pk[NR], Ek[NR], bN[NR], bP[NR], bE[NR];
+        double bN[NR], bP[NR], bE[NR];
+        double cN[NR], cP[NR], cE[NR];             // STRICT only: U^t, to enter the history after the step
+        if constexpr (STRICT) {
 #pragma unroll
-        for (int j = 0; j < NR; j++) {             // :128-135
-            Nk[j] = hN[0][j]; Pk[j] = hP[0][j]; Ek[j] = hE[0][j];
-            bN[j] = a1 * Nk[j] + a2 * hN[1][j] + a3 * hN[2][j] + a4 * hN[3][j] + a5 * hN[4][j];
-            bP[j] = a1 * Pk[j] + a2 * hP[1][j] + a3 * hP[2][j] + a4 * hP[3][j] + a5 * hP[4][j];
-            bE[j] = a1 * Ek[j] + a2 * hE[1][j] + a3 * hE[2][j] + a4 * hE[3][j] + a5 * hE[4][j];
+            for (int j = 0; j < NR; j++) {         // :128-135
+                cN[j] = Nk[j]; cP[j] = Pk[j]; cE[j] = Ek[j];
+                bN[j] = a1 * Nk[j] + a2 * hN[0][j] + a3 * hN[1][j] + a4 * hN[2][j] + a5 * hN[3][j];
+                bP[j] = a1 * Pk[j] + a2 * hP[0][j] + a3 * hP[1][j] + a4 * hP[2][j] + a5 * hP[3][j];
+                bE[j] = a1 * Ek[j] + a2 * hE[0][j] + a3 * hE[1][j] + a4 * hE[2][j] + a5 * hE[3][j];
+            }
+        } else {
+            const int s1 = (int)((t + 3) & 3) * HSLOT, s2 = (int)((t + 2) & 3) * HSLOT,
+                      s3 = (int)((t + 1) & 3) * HSLOT, s4 = (int)(t & 3) * HSLOT;   // slots of t-1 .. t-4
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                const int oN = (0 * NR + j) * 64 + hl, oP = (1 * NR + j) * 64 + hl, oE = (2 * NR + j) * 64 + hl;
+                bN[j] = a1 * Nk[j] + a2 * hist[s1 + oN] + a3 * hist[s2 + oN] + a4 * hist[s3 + oN] + a5 * hist[s4 + oN];
+                bP[j] = a1 * Pk[j] + a2 * hist[s1 + oP] + a3 * hist[s2 + oP] + a4 * hist[s3 + oP] + a5 * hist[s4 + oP];
+                bE[j] = a1 * Ek[j] + a2 * hist[s1 + oE] + a3 * hist[s2 + oE] + a4 * hist[s3 + oE] + a5 * hist[s4 + oE];
+                hist[s4 + oN] = Nk[j];             // U^t replaces U^{t-4} (same slot, t mod 4)
+                hist[s4 + oP] = Pk[j];
+                hist[s4 + oE] = Ek[j];
+            }
         }
         int it = MAX;                              // value if the loop runs to exhaustion (:225)
         for (int iters = 0; iters < MAX; iters++) {
@@ -801,12 +833,13 @@ __global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
             }
         }
 
-        // ---- rotate history: level kp becomes level k ----
+        if constexpr (STRICT) {                    // shift the register history by one level
 #pragma unroll
-        for (int j = 0; j < NR; j++) {
+            for (int j = 0; j < NR; j++) {
 #pragma unroll
-            for (int m = 4; m >= 1; m--) { hN[m][j] = hN[m - 1][j]; hP[m][j] = hP[m - 1][j]; hE[m][j] = hE[m - 1][j]; }
-            hN[0][j] = Nk[j]; hP[0][j] = Pk[j]; hE[0][j] = Ek[j];
+                for (int m = 3; m >= 1; m--) { hN[m][j] = hN[m - 1][j]; hP[m][j] = hP[m - 1][j]; hE[m][j] = hE[m - 1][j]; }
+                hN[0][j] = cN[j]; hP[0][j] = cP[j]; hE[0][j] = cE[j];
+            }
         }
     }
 
