@@ -569,10 +569,18 @@ __device__ __forceinline__ bool residual_below(const double (&l)[NR], const doub
         r[j] = fabs(l[j] * cm[j] + dg[j] * c[j] + u[j] * cp[j] - b[j]);
         ab[j] = fabs(b[j]);
     }
-    const double sr = sum_nodes<LAY, NR, W>(r);
-    const double sb = sum_nodes<LAY, NR, W>(ab);
-    if constexpr (LAY == 0) return sr / sb < TOL;
-    else                    return sr < TOL * sb;
+    if constexpr (LAY == 2) {
+        // one reduction instead of two: sum|r| < TOL*sum|b|  <=>  sum(|r| - TOL*|b|) < 0
+        double q[NR];
+#pragma unroll
+        for (int j = 0; j < NR; j++) q[j] = __builtin_fma(-TOL, ab[j], r[j]);
+        return sum_nodes<LAY, NR, W>(q) < 0.0;
+    } else {
+        const double sr = sum_nodes<LAY, NR, W>(r);
+        const double sb = sum_nodes<LAY, NR, W>(ab);
+        if constexpr (LAY == 0) return sr / sb < TOL;
+        else                    return sr < TOL * sb;
+    }
 }
 
 // the 12 non-dimensional material parameters of one system (wave-uniform) + N0*P0
@@ -621,7 +629,7 @@ __device__ __forceinline__ void assemble(const MatPar &m, double a0, const doubl
             const double l_p = last ? 0.0 : __builtin_fma(hD, Ep[j], -D);
             const double tp = Nk[j] * m.tauP + Pk[j] * m.tauN;
             const double np_ = Nk[j] * Pk[j] - m.n0p0;
-            const double inv = rcp_nr(tp);
+            const double inv = LAY == 2 ? rcp_nr1(tp) : rcp_nr(tp);
             const double ds = -m.rate * V - (V * tp - tauV * np_) * (inv * inv)
                             - (Co * Nk[j] * Pk[j] + Cx * (V * V) + Co * np_);
             up[j] = u_i; lo[j] = l_i;
@@ -646,7 +654,7 @@ __device__ __forceinline__ void assemble(const MatPar &m, double a0, const doubl
         const double Ns = hiHalf ? +Nk[NR - 1] : +Nk[0], Ps = hiHalf ? +Pk[NR - 1] : +Pk[0];
         const double sr = hiHalf ? +m.srL : +m.sr0;
         const double Vs = IS_N ? Ps : Ns, Us = IS_N ? Ns : Ps;
-        const double inv = rcp_nr(Ns + Ps);
+        const double inv = LAY == 2 ? rcp_nr1(Ns + Ps) : rcp_nr(Ns + Ps);
         const double dss = -sr * (Vs * Vs + m.n0p0) * (inv * inv);
         const double fs = sr * (Ns * Ps - m.n0p0) * inv + dss * Us;
         if (ln == 0) { dg[0] -= dss; bb[0] -= fs; }
@@ -675,7 +683,7 @@ __device__ __forceinline__ void update_field(const MatPar &m, double a0, const d
         } else {
             const double A = (0.5 * m.Lambda) * (m.DP * (Pk[j] + Pm[j]) + m.DN * (Nk[j] + Nm[j])) + a0;
             const double b = m.Lambda * (m.DP * (Pk[j] - Pm[j]) - m.DN * (Nk[j] - Nm[j])) - bE[j];
-            e = b * rcp_nr(A);
+            e = b * (LAY == 2 ? rcp_nr1(A) : rcp_nr(A));
         }
         Ek[j] = i >= 1 ? e : Ek[j];
     }
