@@ -184,6 +184,8 @@ def main():
 
     if rank == 0 and not args.no_pcr:
         out["roofline_hbm_pcr"] = bench_pcr(torch, tdev, dev, flags)
+    if rank == 0:
+        attach_traffic(out)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, trpl_amd, ini, lens, Time, L, T, args.cpu_seconds)
     if world > 1:
@@ -191,6 +193,26 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def attach_traffic(out):
+    """`traffic` = HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in
+    separate runs, gfx950 x2 read correction) of tools/profile_round.sh, as committed under
+    profiles/<tag>_hbm_traffic.json (newest tag).  PMC counters cannot be read from inside this
+    process, so the figure comes from that profile of the same kernels; null if none is committed.
+    The stepper's figure is for the profile's T (its traffic is the observation stream, ~8 B per
+    system-step through L2), the PCR's is size-matched (65 536 x 128)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), key=os.path.getmtime)
+    if not files:
+        return
+    t = json.load(open(files[-1]))
+    src = os.path.basename(files[-1])
+    for key, obj in (("void trpl::stepper_kernel<128, false>", "roofline"),
+                     ("void trpl::pcr_batched_kernel<double, 128, false>", "roofline_hbm_pcr")):
+        if key in t and obj in out:
+            out[obj]["traffic"] = t[key]["hbm_bytes_per_launch"]
+            out[obj]["traffic_source"] = "profiles/" + src
 
 
 def bench_pcr(torch, tdev, dev, flags, S=65536, L=128, reps=50):
@@ -252,7 +274,7 @@ def cpu_baseline(wl, trpl_amd, ini, lens, Time, L, T, budget_s):
     t2 = run(n2)
     rate = n2 * len(lens) * (T + 1) / t2
     return {"value": rate, "unit": "system-timesteps/s", "cores": cores, "kind": "port",
-            "sample": "first %d of the seeded samples x %d curves x T=%d steps (%.1f s on %d OpenMP threads)"
+            "sample": "%d seeded samples of the same box x %d curves x T=%d steps (%.1f s on %d OpenMP threads)"
                       % (n2, len(lens), T, t2, cores),
             "likelihoods_per_s_at_T": n2 / t2}
 

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/<tag>/ (written by tools/profile_round.sh) into profiles/<tag>_*:
+the bench line, the rocprofv3 kernel stats of our kernels, and per-launch HBM traffic from the
+FETCH_SIZE / WRITE_SIZE passes with the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE
+counts 64 B per 128-B request for wide coalesced reads: x2; both counters are in KiB)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", tag)
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+OURS = ("trpl::",)
+
+bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
+json.dump(bench, open(os.path.join(dst, tag + "_bench.json"), "w"), indent=1)
+
+rows = []
+for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
+    for r in csv.DictReader(open(f)):
+        if any(k in r["Name"] for k in OURS):
+            rows.append(r)
+with open(os.path.join(dst, tag + "_rocprof_kernel_stats.csv"), "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+    for r in rows:
+        w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+
+traffic = {}
+for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(os.path.join(src, "pmc_" + cname, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != cname or not any(k in r["Kernel_Name"] for k in OURS):
+                continue
+            k = r["Kernel_Name"].split("(")[0]
+            d = traffic.setdefault(k, {"FETCH_SIZE": [], "WRITE_SIZE": []})
+            d[cname].append(float(r["Counter_Value"]))
+out = {}
+for k, d in traffic.items():
+    fetch = sum(d["FETCH_SIZE"]) / max(len(d["FETCH_SIZE"]), 1)
+    write = sum(d["WRITE_SIZE"]) / max(len(d["WRITE_SIZE"]), 1)
+    out[k] = {"launches_fetch": len(d["FETCH_SIZE"]), "launches_write": len(d["WRITE_SIZE"]),
+              "FETCH_SIZE_KiB_per_launch_raw": fetch, "WRITE_SIZE_KiB_per_launch": write,
+              "hbm_read_bytes_per_launch_corrected": fetch * 1024 * 2,
+              "hbm_write_bytes_per_launch": write * 1024,
+              "hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024}
+json.dump(out, open(os.path.join(dst, tag + "_hbm_traffic.json"), "w"), indent=1)
+print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in out.items()}, indent=1))
+print("value", bench["value"], "pcr frac", bench.get("roofline_hbm_pcr", {}).get("frac"))
