@@ -461,23 +461,64 @@ __device__ __forceinline__ void pair32(double v, double &lo_half, double &hi_hal
     hi_half = __hiloint2double((int)r1[1], (int)r0[1]);
 }
 
-template <typename T, int NR, int L, int RF>
-__device__ __forceinline__ void pcr_levels_B(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], int lane)
+// PCR in the interleaved layout with the neighbour exchange STAGED THROUGH LDS: each level the
+// wave stores its normalised rows (ld, ud, B)/d as three node-indexed arrays (one 16-byte store
+// per array: a lane's NR rows are adjacent nodes) and loads the rows at i-RF and i+RF with one
+// 16-byte load per array and direction.  9 DS instructions per level instead of 24
+// ds_bpermute_b32 (whose issue queue was the bottleneck: SQ_WAIT_INST_LDS 29 %).  A wavefront
+// executes its DS instructions in order, so no barrier is needed and the 3*L-double buffer is
+// reused by every level.  Stride 1 (odd: rows straddle lanes) stays on DPP.  Out-of-range
+// neighbours wrap to in-array values that are multiplied by exact zeros.
+template <int NR>
+struct vecN { double v[NR]; };
+
+template <int NR, int L>
+__device__ __forceinline__ void xch_store(double *xch, int arr, int lane, const double (&x)[NR])
+{
+    vecN<NR> t;
+#pragma unroll
+    for (int j = 0; j < NR; j++) t.v[j] = x[j];
+    *reinterpret_cast<vecN<NR> *>(xch + arr * L + NR * lane) = t;
+}
+template <int NR, int L>
+__device__ __forceinline__ void xch_load(const double *xch, int arr, int node0, double (&y)[NR])
+{
+    const vecN<NR> t = *reinterpret_cast<const vecN<NR> *>(xch + arr * L + node0);
+#pragma unroll
+    for (int j = 0; j < NR; j++) y[j] = t.v[j];
+}
+
+template <int NR, int L, int RF>
+__device__ __forceinline__ void pcr_levels_L(double (&ld)[NR], double (&d)[NR], double (&ud)[NR], double (&B)[NR],
+                                             int lane, double *xch)
 {
     if constexpr (L > 2 * RF) {
-        T nl[NR], nu[NR], nB[NR];
+        double nl[NR], nu[NR], nB[NR];
 #pragma unroll
         for (int j = 0; j < NR; j++) {
-            const T r = rcp_nr1(d[j]);
+            const double r = rcp_nr1(d[j]);
             nl[j] = ld[j] * r; nu[j] = ud[j] * r; nB[j] = B[j] * r;
         }
-        T l_m[NR], u_m[NR], B_m[NR], l_p[NR], u_p[NR], B_p[NR];
-        nbrB_dn<T, NR, RF>(nl, l_m, lane);
-        nbrB_dn<T, NR, RF>(nu, u_m, lane);
-        nbrB_dn<T, NR, RF>(nB, B_m, lane);
-        nbrB_up<T, NR, RF>(nl, l_p, lane);
-        nbrB_up<T, NR, RF>(nu, u_p, lane);
-        nbrB_up<T, NR, RF>(nB, B_p, lane);
+        double l_m[NR], u_m[NR], B_m[NR], l_p[NR], u_p[NR], B_p[NR];
+        if constexpr (RF % NR != 0) {              // rows straddle lanes: DPP / in-lane moves
+            nbrB_dn<double, NR, RF>(nl, l_m, lane);
+            nbrB_dn<double, NR, RF>(nu, u_m, lane);
+            nbrB_dn<double, NR, RF>(nB, B_m, lane);
+            nbrB_up<double, NR, RF>(nl, l_p, lane);
+            nbrB_up<double, NR, RF>(nu, u_p, lane);
+            nbrB_up<double, NR, RF>(nB, B_p, lane);
+        } else {
+            xch_store<NR, L>(xch, 0, lane, nl);
+            xch_store<NR, L>(xch, 1, lane, nu);
+            xch_store<NR, L>(xch, 2, lane, nB);
+            const int dn = (NR * lane - RF) & (L - 1), up = (NR * lane + RF) & (L - 1);
+            xch_load<NR, L>(xch, 0, dn, l_m);
+            xch_load<NR, L>(xch, 1, dn, u_m);
+            xch_load<NR, L>(xch, 2, dn, B_m);
+            xch_load<NR, L>(xch, 0, up, l_p);
+            xch_load<NR, L>(xch, 1, up, u_p);
+            xch_load<NR, L>(xch, 2, up, B_p);
+        }
 #pragma unroll
         for (int j = 0; j < NR; j++) {
             // rows i < RF have ld == 0 and rows i >= L-RF have ud == 0 exactly: wrapped values drop out
@@ -486,24 +527,34 @@ __device__ __forceinline__ void pcr_levels_B(T (&ld)[NR], T (&d)[NR], T (&ud)[NR
             ld[j] = -ld[j] * l_m[j];
             ud[j] = -ud[j] * u_p[j];
         }
-        pcr_levels_B<T, NR, L, RF * 2>(ld, d, ud, B, lane);
+        pcr_levels_L<NR, L, RF * 2>(ld, d, ud, B, lane, xch);
     }
 }
 
-// PCR solve in the interleaved layout (double only; L >= 128 so the final pairs are lanes l, l^32)
+// PCR solve, interleaved layout, L >= 128 (the final pairs i, i+L/2 sit in lanes l, l^32).
 template <int NR, int L>
-__device__ __forceinline__ void pcr_solve_B(double (&ld)[NR], double (&d)[NR], double (&ud)[NR], double (&B)[NR],
-                                            double (&x)[NR], int lane)
+__device__ __forceinline__ void pcr_solve_L(double (&ld)[NR], double (&d)[NR], double (&ud)[NR], double (&B)[NR],
+                                            double (&x)[NR], int lane, double *xch)
 {
-    pcr_levels_B<double, NR, L, 1>(ld, d, ud, B, lane);
+    pcr_levels_L<NR, L, 1>(ld, d, ud, B, lane, xch);
+    // final 2x2 solves (pvSimPCR.py:75-79): the lower node of a pair needs (d, ld, B) of the upper,
+    // the upper needs (d, ud, B) of the lower: publish d, B and q = (lower ? ud : ld)
     const bool low = lane < 32;
+    double q[NR], d_o[NR], q_o[NR], B_o[NR];
 #pragma unroll
-    for (int j = 0; j < NR; j++) {                 // pvSimPCR.py:75-79 with i = lower node of the pair
-        double d_lo, d_hi, B_lo, B_hi, ud_lo, ud_hi, ld_lo, ld_hi;
-        pair32(d[j], d_lo, d_hi);
-        pair32(B[j], B_lo, B_hi);
-        pair32(ud[j], ud_lo, ud_hi);
-        pair32(ld[j], ld_lo, ld_hi);
+    for (int j = 0; j < NR; j++) q[j] = low ? +ud[j] : +ld[j];
+    xch_store<NR, L>(xch, 0, lane, d);
+    xch_store<NR, L>(xch, 1, lane, q);
+    xch_store<NR, L>(xch, 2, lane, B);
+    const int partner = (NR * lane + L / 2) & (L - 1);
+    xch_load<NR, L>(xch, 0, partner, d_o);
+    xch_load<NR, L>(xch, 1, partner, q_o);
+    xch_load<NR, L>(xch, 2, partner, B_o);
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        const double d_lo = low ? d[j] : d_o[j], d_hi = low ? d_o[j] : d[j];
+        const double B_lo = low ? B[j] : B_o[j], B_hi = low ? B_o[j] : B[j];
+        const double ud_lo = low ? ud[j] : q_o[j], ld_hi = low ? q_o[j] : ld[j];
         const double r1 = rcp_nr1(d_hi);
         const double k = ud_lo * r1;
         const double xl = (B_lo - B_hi * k) * rcp_nr1(d_lo - ld_hi * k);
@@ -545,11 +596,11 @@ __device__ __forceinline__ double sum_nodes(double (&v)[NR])
 }
 template <int LAY, int NR, int W, int L>
 __device__ __forceinline__ void solve_lay(double (&ld)[NR], double (&d)[NR], double (&ud)[NR], double (&B)[NR],
-                                          double (&x)[NR], int ln)
+                                          double (&x)[NR], int ln, double *xch)
 {
     if constexpr (LAY == 0) pcr_solve<double, NR, W, L>(ld, d, ud, B, x, ln);
     else if constexpr (LAY == 1) pcr_solve_fast<double, NR, W, L>(ld, d, ud, B, x, ln);
-    else pcr_solve_B<NR, L>(ld, d, ud, B, x, ln);
+    else pcr_solve_L<NR, L>(ld, d, ud, B, x, ln, xch);
 }
 
 // Relative L1 residual of iterate c in the system (lower l, diagonal dg, upper u | b):
@@ -716,14 +767,18 @@ __global__ void __launch_bounds__(64, STRICT ? 2 : 3) stepper_kernel(const StepA
     const int MAX = a.MAX;
 
     // ---- state U^t (registers) and the four older BDF levels U^{t-1..t-4} ----
-    // STRICT keeps the older levels in registers.  FAST keeps them in LDS as a 4-slot ring,
-    // slot (t' mod 4) holding U^{t'}: nothing is ever moved, a step reads the four slots and then
-    // overwrites the oldest with U^t.  12 KB per wave buys ~50 VGPRs, i.e. 3 waves per SIMD.
-    constexpr int HSLOT = 3 * NR * 64;
-    __shared__ double hist[STRICT ? 1 : 4 * HSLOT];
+    // STRICT keeps the older levels in registers.  FAST keeps those of N and P in LDS as a 4-slot
+    // ring, slot (t' mod 4) holding U^{t'}: nothing is ever moved, a step reads the four slots and
+    // then overwrites the oldest with U^t (8 KB per wave for L = 128); E's stay in registers so
+    // that ring + 3 KB PCR exchange buffer leave room for 3 waves per SIMD (12 x 11 KB <= 160 KB).
+    constexpr int HSLOT = 2 * NR * 64;              // N and P; the E history stays in registers
+    __shared__ __attribute__((aligned(16))) double lds[STRICT ? 2 : 4 * HSLOT + (LAY == 2 ? 3 * L : 2)];
+    double *hist = lds;
+    double *xch = lds + (STRICT ? 0 : 4 * HSLOT);   // PCR exchange buffer (LAY 2)
     const int hl = threadIdx.x;                     // this lane's column of the ring
     double Nk[NR], Pk[NR], Ek[NR];
-    double hN[4][NR], hP[4][NR], hE[4][NR];         // STRICT only: levels t-1 .. t-4
+    double hN[4][NR], hP[4][NR];                    // STRICT only: levels t-1 .. t-4
+    double hE[4][NR];                               // field history, registers in both modes
 #pragma unroll
     for (int j = 0; j < NR; j++) {                 // pvSimPCR.py:356-362
         const double dn = a.dN[(int64_t)c * L + node_of<LAY, NR, W>(ln, j)] * cc.dx3;
@@ -732,9 +787,9 @@ __global__ void __launch_bounds__(64, STRICT ? 2 : 3) stepper_kernel(const StepA
         Ek[j] = 0.0;
 #pragma unroll
         for (int m = 0; m < 4; m++) {
-            if constexpr (STRICT) { hN[m][j] = 0.0; hP[m][j] = 0.0; hE[m][j] = 0.0; }
-            else { hist[m * HSLOT + (0 * NR + j) * 64 + hl] = 0.0; hist[m * HSLOT + (1 * NR + j) * 64 + hl] = 0.0;
-                   hist[m * HSLOT + (2 * NR + j) * 64 + hl] = 0.0; }
+            hE[m][j] = 0.0;
+            if constexpr (STRICT) { hN[m][j] = 0.0; hP[m][j] = 0.0; }
+            else { hist[m * HSLOT + (0 * NR + j) * 64 + hl] = 0.0; hist[m * HSLOT + (1 * NR + j) * 64 + hl] = 0.0; }
         }
     }
 
@@ -787,13 +842,13 @@ __global__ void __launch_bounds__(64, STRICT ? 2 : 3) stepper_kernel(const StepA
                       s3 = (int)((t + 1) & 3) * HSLOT, s4 = (int)(t & 3) * HSLOT;   // slots of t-1 .. t-4
 #pragma unroll
             for (int j = 0; j < NR; j++) {
-                const int oN = (0 * NR + j) * 64 + hl, oP = (1 * NR + j) * 64 + hl, oE = (2 * NR + j) * 64 + hl;
+                const int oN = (0 * NR + j) * 64 + hl, oP = (1 * NR + j) * 64 + hl;
+                cE[j] = Ek[j];
                 bN[j] = a1 * Nk[j] + a2 * hist[s1 + oN] + a3 * hist[s2 + oN] + a4 * hist[s3 + oN] + a5 * hist[s4 + oN];
                 bP[j] = a1 * Pk[j] + a2 * hist[s1 + oP] + a3 * hist[s2 + oP] + a4 * hist[s3 + oP] + a5 * hist[s4 + oP];
-                bE[j] = a1 * Ek[j] + a2 * hist[s1 + oE] + a3 * hist[s2 + oE] + a4 * hist[s3 + oE] + a5 * hist[s4 + oE];
+                bE[j] = a1 * Ek[j] + a2 * hE[0][j] + a3 * hE[1][j] + a4 * hE[2][j] + a5 * hE[3][j];
                 hist[s4 + oN] = Nk[j];             // U^t replaces U^{t-4} (same slot, t mod 4)
                 hist[s4 + oP] = Pk[j];
-                hist[s4 + oE] = Ek[j];
             }
         }
         int it = MAX;                              // value if the loop runs to exhaustion (:225)
@@ -803,11 +858,11 @@ __global__ void __launch_bounds__(64, STRICT ? 2 : 3) stepper_kernel(const StepA
             // ---- electrons (:148-175) ----
             assemble<LAY, true, NR, W, L>(mp, a0, Nk, Pk, Ek, Ep, bN, lo_, dg, up, bb, ln);
             const bool okN = residual_below<LAY, NR, W>(lo_, dg, up, bb, Nk, TOL, ln);             // :172
-            solve_lay<LAY, NR, W, L>(lo_, dg, up, bb, Nk, ln);                                     // :175
+            solve_lay<LAY, NR, W, L>(lo_, dg, up, bb, Nk, ln, xch);                                     // :175
             // ---- holes, with the updated electrons (:178-202) ----
             assemble<LAY, false, NR, W, L>(mp, a0, Nk, Pk, Ek, Ep, bP, lo_, dg, up, bb, ln);
             const bool okP = residual_below<LAY, NR, W>(lo_, dg, up, bb, Pk, TOL, ln);             // :200
-            solve_lay<LAY, NR, W, L>(lo_, dg, up, bb, Pk, ln);                                     // :202
+            solve_lay<LAY, NR, W, L>(lo_, dg, up, bb, Pk, ln, xch);                                     // :202
             // ---- field on edges 1..L-1 (:205-209) ----
             update_field<LAY, NR, W>(mp, a0, Nk, Pk, bE, Ek, ln);
             if (okN && okP) { it = iters + 1; break; }                                             // :213-216
@@ -841,13 +896,15 @@ __global__ void __launch_bounds__(64, STRICT ? 2 : 3) stepper_kernel(const StepA
             }
         }
 
-        if constexpr (STRICT) {                    // shift the register history by one level
 #pragma unroll
-            for (int j = 0; j < NR; j++) {
+        for (int j = 0; j < NR; j++) {             // shift the register histories by one level
 #pragma unroll
-                for (int m = 3; m >= 1; m--) { hN[m][j] = hN[m - 1][j]; hP[m][j] = hP[m - 1][j]; hE[m][j] = hE[m - 1][j]; }
-                hN[0][j] = cN[j]; hP[0][j] = cP[j]; hE[0][j] = cE[j];
+            for (int m = 3; m >= 1; m--) {
+                hE[m][j] = hE[m - 1][j];
+                if constexpr (STRICT) { hN[m][j] = hN[m - 1][j]; hP[m][j] = hP[m - 1][j]; }
             }
+            hE[0][j] = cE[j];
+            if constexpr (STRICT) { hN[0][j] = cN[j]; hP[0][j] = cP[j]; }
         }
     }
 

@@ -28,6 +28,12 @@ __global__ void k(double* out, long long* cyc, int iters)
             if constexpr (OP == 6) { auto q = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2hiint(x), false, false); x = __hiloint2double((int)q[1], (int)q[0]); }
             if constexpr (OP == 7) { float f = (float)x; f = __builtin_amdgcn_rcpf(f); x = (double)f; }
             if constexpr (OP == 8) { int lo = __double2loint(x); lo = (lane & 1) ? lo : __double2hiint(x); x = __hiloint2double(__double2hiint(x), lo); }
+            if constexpr (OP == 13) a[0] = __builtin_fma(a[0], c, e);                         // ONE dependent chain
+            if constexpr (OP == 14) a[r & 1] = __builtin_fma(a[r & 1], c, e);                 // two chains
+            if constexpr (OP == 15) { a[0] = __builtin_amdgcn_rcp(a[0]); a[1] = __builtin_fma(a[1], c, e); a[2] = __builtin_fma(a[2], c, e); a[3] = __builtin_fma(a[3], c, e); }
+            if constexpr (OP == 10) x = __builtin_fma(a[(r + 3) & 7], a[(r + 5) & 7], x);      // 3 VGPR-pair operands
+            if constexpr (OP == 11) x = a[(r + 3) & 7] * a[(r + 5) & 7];                     // mul, 2 VGPR-pair operands, no RAW on x
+            if constexpr (OP == 12) x = __builtin_fma(a[(r + 3) & 7], c, x);                 // 2 VGPR pairs + uniform
             if constexpr (OP == 9) { float f = __builtin_bit_cast(float, __double2loint(x)); f = __builtin_fmaf(f, 1.0001f, 0.5f); x = __hiloint2double(__double2hiint(x), __builtin_bit_cast(int, f)); }
         }
     }
@@ -44,7 +50,7 @@ void run(const char* name)
     const int iters = 2000;
     double* out; long long* cyc;
     hipMalloc(&out, 256 * 1024 * 8); hipMalloc(&cyc, 256 * 16 * 8);
-    for (int wps : {1, 2, 3, 4}) {
+    for (int wps : {1, 2, 3}) {
         int threads = 64 * 4 * wps;              // wps waves on each of the CU's 4 SIMDs
         hipLaunchKernelGGL(k<OP>, dim3(256 * (wps > 4 ? 2 : 1)), dim3(threads > 1024 ? 1024 : threads), 0, 0, out, cyc, iters);
         hipDeviceSynchronize();
@@ -58,8 +64,7 @@ void run(const char* name)
 }
 int main()
 {
-    run<0>("v_fma_f64"); run<1>("v_mul_f64"); run<2>("v_add_f64"); run<3>("v_rcp_f64");
-    run<4>("v_mov_b32_dpp wave_rol"); run<5>("ds_bpermute_b32"); run<6>("v_permlane32_swap");
-    run<7>("cvt+v_rcp_f32+cvt"); run<8>("v_cndmask_b32"); run<9>("v_fma_f32");
+    run<0>("v_fma_f64 x*c+e"); run<13>("fma_f64 1 dependent chain"); run<14>("fma_f64 2 chains"); run<15>("rcp + 3 fma (per 4 instr)");
+    run<10>("v_fma_f64 3xVGPR"); run<11>("v_mul_f64 2xVGPR"); run<12>("v_fma_f64 2xVGPR+uniform");
     return 0;
 }
