@@ -798,8 +798,15 @@ __global__ void __launch_bounds__(64, STRICT ? 2 : 3) stepper_kernel(const StepA
     const int64_t ncol_ll = want_ll ? cc.n_obs : 0;
     // last step that can influence an output: all T+1 of them when PL is stored (the reference
     // runs them all), otherwise up to the last compared column
-    const int64_t t_last = want_pl ? a.T : (ncol_ll - 1) * a.plT;
     const double *obs = want_ll ? a.obs + (int64_t)c * a.obs_ld : nullptr;
+    // off-grid observation times (trpl_loglik_obs): bracketing data per observation, sorted by time
+    const bool interp = want_ll && a.obs_hi != nullptr;
+    const int32_t *obs_hi = interp ? a.obs_hi + (int64_t)c * a.obs_ld : nullptr;
+    const double *obs_dx = interp ? a.obs_dx + (int64_t)c * a.obs_ld : nullptr;
+    const double *obs_h = interp ? a.obs_h + (int64_t)c * a.obs_ld : nullptr;
+    const int64_t t_last = want_pl ? a.T : (interp ? (int64_t)obs_hi[ncol_ll - 1] : (ncol_ll - 1) * a.plT);
+    int64_t next_obs = 0;
+    double lg_prev = 0.0;
     double sse = 0.0;
     double pl0_d = 1.0;
     float pl0_f = 1.0f;
@@ -877,7 +884,7 @@ __global__ void __launch_bounds__(64, STRICT ? 2 : 3) stepper_kernel(const StepA
                 if (a.pl_bytes == 4) ((float *)a.pl)[orow * a.pl_ld + col] = (float)plv / (float)cc.plnorm;
                 else                 ((double *)a.pl)[orow * a.pl_ld + col] = plv / cc.plnorm;
             }
-            if (col < ncol_ll) {                   // bayeslib.py:150-157, probs.py:29-44
+            if (interp || col < ncol_ll) {         // bayeslib.py:150-157, probs.py:29-44
                 double lg;
                 if (a.flags & kFlagPlF32) {
                     float f = (float)plv / (float)cc.plnorm;
@@ -890,9 +897,23 @@ __global__ void __launch_bounds__(64, STRICT ? 2 : 3) stepper_kernel(const StepA
                     if (v < DBL_MIN) v = DBL_MIN;
                     lg = log10(v);
                 }
-                double err = lg + mag;
-                err -= obs[col];
-                sse += err * err;
+                if (!interp) {
+                    double err = lg + mag;
+                    err -= obs[col];
+                    sse += err * err;
+                } else {
+                    // every observation bracketed by grid points (col-1, col): scipy interp1d's
+                    // slope * (x - x_lo) + y_lo (bayeslib.py:189)
+                    while (next_obs < ncol_ll && obs_hi[next_obs] == (int32_t)col) {
+                        const double dy = (a.flags & kFlagPlF32) ? (double)((float)lg - (float)lg_prev) : lg - lg_prev;
+                        const double y = (dy / obs_h[next_obs]) * obs_dx[next_obs] + lg_prev;
+                        double err = y + mag;
+                        err -= obs[next_obs];
+                        sse += err * err;
+                        next_obs++;
+                    }
+                    lg_prev = lg;
+                }
             }
         }
 

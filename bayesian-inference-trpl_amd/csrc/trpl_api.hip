@@ -239,28 +239,34 @@ int trpl_sse_accumulate(double *P, const void *plI, int32_t elem_bytes, int64_t 
 }
 
 /* ------------------------------------------------------------------ fused loglik -------- */
-int trpl_loglik_dev(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns, int32_t L,
-                    int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN,
-                    const double *obs, int64_t obs_ld, const int64_t *n_obs, double *P, double *sse,
-                    int32_t *status, int64_t *iters_total, uint32_t flags, void *stream)
+static int loglik_dev_impl(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns, int32_t L,
+                           int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN,
+                           const double *obs, const int32_t *obs_hi, const double *obs_dx, const double *obs_h,
+                           int64_t obs_ld, const int64_t *n_obs, double *P, double *sse, int32_t *status,
+                           int64_t *iters_total, uint32_t flags, void *stream)
 {
     if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
     if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
     if (C < 1 || C > trpl::kMaxCurves) return fail(TRPL_ERR_ARG, "C=%d must be in [1, %d]", C, trpl::kMaxCurves);
     if (S == 0) return TRPL_OK;
     if (!X || !lengths_nm || !dN || !obs || !n_obs || !P || !sse) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    const bool interp = obs_hi || obs_dx || obs_h;
+    if (interp && !(obs_hi && obs_dx && obs_h)) return fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h go together");
+    if (interp && plT != 1) return fail(TRPL_ERR_ARG, "off-grid observations need plT = 1");
     if (S * (int64_t)C > 0x7fffffffLL) return fail(TRPL_ERR_ARG, "S*C too large for one launch");
     trpl::StepArgs a;
     memset(&a, 0, sizeof a);
-    a.X = X; a.xld = 13; a.dN = dN; a.obs = obs; a.obs_ld = obs_ld; a.sse = sse;
+    a.X = X; a.xld = 13; a.dN = dN; a.obs = obs; a.obs_hi = obs_hi; a.obs_dx = obs_dx; a.obs_h = obs_h;
+    a.obs_ld = obs_ld; a.sse = sse;
     a.status = status; a.iters_total = iters_total;
     a.S = S; a.C = C; a.L = L; a.T = T; a.plT = plT; a.MAX = max_iter; a.flags = flags;
     a.TOL = pow(10.0, -(double)tol_exp);
     const int64_t ncol = T / plT + 1;
     for (int c = 0; c < C; c++) {
         if (!(lengths_nm[c] > 0)) return fail(TRPL_ERR_ARG, "lengths_nm[%d] must be > 0", c);
-        if (n_obs[c] < 1 || n_obs[c] > ncol || n_obs[c] > obs_ld)
-            return fail(TRPL_ERR_ARG, "n_obs[%d]=%lld must be in [1, min(T/plT+1, obs_ld)]", c, (long long)n_obs[c]);
+        if (n_obs[c] < 1 || n_obs[c] > obs_ld || (!interp && n_obs[c] > ncol))
+            return fail(TRPL_ERR_ARG, "n_obs[%d]=%lld out of range (obs_ld %lld, grid columns %lld)", c,
+                        (long long)n_obs[c], (long long)obs_ld, (long long)ncol);
         curve_const(lengths_nm[c], time_ns, L, T, a.curve[c]);
         a.curve[c].n_obs = n_obs[c];
     }
@@ -270,10 +276,31 @@ int trpl_loglik_dev(const double *X, int64_t S, int32_t C, const double *lengths
     return TRPL_OK;
 }
 
-int trpl_loglik(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns, int32_t L,
-                int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN, const double *obs,
-                int64_t obs_ld, const int64_t *n_obs, double *P, double *sse, int32_t *status,
-                int64_t *iters_total, uint32_t flags, int32_t device, double *seconds)
+int trpl_loglik_dev(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns, int32_t L,
+                    int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN,
+                    const double *obs, int64_t obs_ld, const int64_t *n_obs, double *P, double *sse,
+                    int32_t *status, int64_t *iters_total, uint32_t flags, void *stream)
+{
+    return loglik_dev_impl(X, S, C, lengths_nm, time_ns, L, T, plT, tol_exp, max_iter, dN, obs, nullptr, nullptr,
+                           nullptr, obs_ld, n_obs, P, sse, status, iters_total, flags, stream);
+}
+
+int trpl_loglik_obs_dev(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns, int32_t L,
+                        int64_t T, int32_t tol_exp, int32_t max_iter, const double *dN, const double *obs,
+                        const int32_t *obs_hi, const double *obs_dx, const double *obs_h, int64_t obs_ld,
+                        const int64_t *n_obs, double *P, double *sse, int32_t *status, int64_t *iters_total,
+                        uint32_t flags, void *stream)
+{
+    if (!obs_hi || !obs_dx || !obs_h) return fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h must not be NULL");
+    return loglik_dev_impl(X, S, C, lengths_nm, time_ns, L, T, 1, tol_exp, max_iter, dN, obs, obs_hi, obs_dx, obs_h,
+                           obs_ld, n_obs, P, sse, status, iters_total, flags, stream);
+}
+
+static int loglik_host_impl(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns, int32_t L,
+                            int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN,
+                            const double *obs, const int32_t *obs_hi, const double *obs_dx, const double *obs_h,
+                            int64_t obs_ld, const int64_t *n_obs, double *P, double *sse, int32_t *status,
+                            int64_t *iters_total, uint32_t flags, int32_t device, double *seconds)
 {
     if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
     if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
@@ -281,24 +308,42 @@ int trpl_loglik(const double *X, int64_t S, int32_t C, const double *lengths_nm,
     if (seconds) *seconds = 0.0;
     if (S == 0) return TRPL_OK;
     if (!X || !lengths_nm || !dN || !obs || !n_obs || !P) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (obs_ld < 1) return fail(TRPL_ERR_ARG, "obs_ld must be >= 1");
     if (int rc = select_device(device)) return rc;
-    DevBuf dX, ddN, dobs, dP, dsse, dst, dit;
-    const size_t nsys = (size_t)S * C;
+    const bool interp = obs_hi != nullptr;
+    if (interp) {                                    // the brackets are host data here: validate them
+        for (int c = 0; c < C; c++)
+            for (int64_t i = 0; i < n_obs[c] && i < obs_ld; i++) {
+                const int32_t h = obs_hi[c * obs_ld + i];
+                if (h < 1 || h > T || (i && h < obs_hi[c * obs_ld + i - 1]))
+                    return fail(TRPL_ERR_ARG, "obs_hi[%d][%lld]=%d must be sorted and in [1, T]", c, (long long)i, h);
+            }
+    }
+    DevBuf dX, ddN, dobs, dhi, ddx, dh, dP, dsse, dst, dit;
+    const size_t nsys = (size_t)S * C, nobs = (size_t)C * obs_ld;
     HIP_TRY(dX.alloc((size_t)S * 13 * 8));
     HIP_TRY(ddN.alloc((size_t)C * L * 8));
-    HIP_TRY(dobs.alloc((size_t)C * obs_ld * 8));
+    HIP_TRY(dobs.alloc(nobs * 8));
     HIP_TRY(dP.alloc((size_t)S * 8));
     HIP_TRY(dsse.alloc(nsys * 8));
     HIP_TRY(dst.alloc(nsys * 4));
     HIP_TRY(dit.alloc(nsys * 8));
     HIP_TRY(hipMemcpy(dX.p, X, (size_t)S * 13 * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ddN.p, dN, (size_t)C * L * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dobs.p, obs, (size_t)C * obs_ld * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dobs.p, obs, nobs * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dP.p, P, (size_t)S * 8, hipMemcpyHostToDevice));
+    if (interp) {
+        HIP_TRY(dhi.alloc(nobs * 4)); HIP_TRY(ddx.alloc(nobs * 8)); HIP_TRY(dh.alloc(nobs * 8));
+        HIP_TRY(hipMemcpy(dhi.p, obs_hi, nobs * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ddx.p, obs_dx, nobs * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dh.p, obs_h, nobs * 8, hipMemcpyHostToDevice));
+    }
     const double t0 = now_s();
-    if (int rc = trpl_loglik_dev(dX.as<double>(), S, C, lengths_nm, time_ns, L, T, plT, tol_exp, max_iter,
-                                 ddN.as<double>(), dobs.as<double>(), obs_ld, n_obs, dP.as<double>(),
-                                 dsse.as<double>(), dst.as<int32_t>(), dit.as<int64_t>(), flags, nullptr))
+    if (int rc = loglik_dev_impl(dX.as<double>(), S, C, lengths_nm, time_ns, L, T, plT, tol_exp, max_iter,
+                                 ddN.as<double>(), dobs.as<double>(), interp ? dhi.as<int32_t>() : nullptr,
+                                 interp ? ddx.as<double>() : nullptr, interp ? dh.as<double>() : nullptr, obs_ld, n_obs,
+                                 dP.as<double>(), dsse.as<double>(), dst.as<int32_t>(), dit.as<int64_t>(), flags,
+                                 nullptr))
         return rc;
     HIP_TRY(hipDeviceSynchronize());
     if (seconds) *seconds = now_s() - t0;
@@ -307,6 +352,26 @@ int trpl_loglik(const double *X, int64_t S, int32_t C, const double *lengths_nm,
     if (status) HIP_TRY(hipMemcpy(status, dst.p, nsys * 4, hipMemcpyDeviceToHost));
     if (iters_total) HIP_TRY(hipMemcpy(iters_total, dit.p, nsys * 8, hipMemcpyDeviceToHost));
     return TRPL_OK;
+}
+
+int trpl_loglik(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns, int32_t L,
+                int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN, const double *obs,
+                int64_t obs_ld, const int64_t *n_obs, double *P, double *sse, int32_t *status,
+                int64_t *iters_total, uint32_t flags, int32_t device, double *seconds)
+{
+    return loglik_host_impl(X, S, C, lengths_nm, time_ns, L, T, plT, tol_exp, max_iter, dN, obs, nullptr, nullptr,
+                            nullptr, obs_ld, n_obs, P, sse, status, iters_total, flags, device, seconds);
+}
+
+int trpl_loglik_obs(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns, int32_t L,
+                    int64_t T, int32_t tol_exp, int32_t max_iter, const double *dN, const double *obs,
+                    const int32_t *obs_hi, const double *obs_dx, const double *obs_h, int64_t obs_ld,
+                    const int64_t *n_obs, double *P, double *sse, int32_t *status, int64_t *iters_total,
+                    uint32_t flags, int32_t device, double *seconds)
+{
+    if (!obs_hi || !obs_dx || !obs_h) return fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h must not be NULL");
+    return loglik_host_impl(X, S, C, lengths_nm, time_ns, L, T, 1, tol_exp, max_iter, dN, obs, obs_hi, obs_dx, obs_h,
+                            obs_ld, n_obs, P, sse, status, iters_total, flags, device, seconds);
 }
 
 /* ------------------------------------------------------------------ batched PCR --------- */

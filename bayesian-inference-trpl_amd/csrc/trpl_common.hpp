@@ -21,6 +21,9 @@ struct StepArgs {
     const double *X;        // [S][xld]   physical units; columns 0..11 = matPar, 12 = mag offset
     const double *dN;       // [C][L]     excitation, nm^-3
     const double *obs;      // [C][obs_ld] log10 observations (likelihood mode) or nullptr
+    const int32_t *obs_hi;  // [C][obs_ld] upper bracketing grid index of each observation, or nullptr (on-grid)
+    const double *obs_dx;   // [C][obs_ld] t_i - t_lo
+    const double *obs_h;    // [C][obs_ld] t_hi - t_lo
     void *pl;               // [C*S][pl_ld] PL out (solve mode) or nullptr
     double *sse;            // [C][S] out (likelihood mode) or nullptr
     int32_t *status;        // [C][S] out or nullptr

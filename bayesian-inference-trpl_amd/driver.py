@@ -57,12 +57,25 @@ def interp_rows(sim_t, pl, times):
     return out
 
 
+def bracket_times(sim_t, times):
+    """The bracketing scipy's interp1d uses for linear interpolation (and griddata with it,
+    bayeslib.py:189): hi = clip(searchsorted(x, x_new), 1, n-1), lo = hi - 1.  Returns
+    (hi int32, x_new - x_lo, x_hi - x_lo)."""
+    sim_t = np.asarray(sim_t, dtype=float)
+    times = np.asarray(times, dtype=float)
+    hi = np.clip(np.searchsorted(sim_t, times), 1, len(sim_t) - 1)
+    lo = hi - 1
+    return hi.astype(np.int32), times - sim_t[lo], sim_t[hi] - sim_t[lo]
+
+
 def loglik(X, init_params, lengths, Time, L, T, obs, tol=7, MAX=10000, plT=1, P=None, pl_f32=False,
-           normalize=False, strict=False, device=0, info=None):
-    """Fused likelihood of one experiment (trpl_loglik).
+           normalize=False, strict=False, device=0, info=None, times=None):
+    """Fused likelihood of one experiment (trpl_loglik / trpl_loglik_obs).
 
     X (S,13) solver units; init_params (C,L) nm^-3; lengths scalar or (C,); obs = list of C
-    arrays of log10 observations on the first len(obs[c]) simulation-grid points.
+    arrays of log10 observations.  With times=None they sit on the first len(obs[c])
+    simulation-grid points; otherwise times = list of C arrays of observation times in
+    [0, Time] (any spacing), interpolated like the reference does (bayeslib.py:184-191).
     Accumulates into P (S,) if given (like probs.prob), else starts from zeros.  Returns P.
     """
     X = np.ascontiguousarray(X, dtype=np.float64)
@@ -74,12 +87,30 @@ def loglik(X, init_params, lengths, Time, L, T, obs, tol=7, MAX=10000, plT=1, P=
         raise ValueError("init_params must have shape (C, L=%d), got %r" % (L, ini.shape))
     Cn = ini.shape[0]
     lengths = np.full(Cn, float(lengths)) if np.isscalar(lengths) else np.ascontiguousarray(lengths, dtype=float)
-    if lengths.shape != (Cn,) or len(obs) != Cn:
+    if lengths.shape != (Cn,) or len(obs) != Cn or (times is not None and len(times) != Cn):
         raise ValueError("need one length and one observation set per curve")
     n_obs = np.array([len(o) for o in obs], dtype=np.int64)
     obs_ld = int(n_obs.max())
     obs_mat = np.zeros((Cn, obs_ld))
+    hi_mat = np.ones((Cn, obs_ld), dtype=np.int32)
+    dx_mat = np.zeros((Cn, obs_ld))
+    h_mat = np.ones((Cn, obs_ld))
+    if times is not None:
+        if plT != 1:
+            raise ValueError("off-grid observation times need plT = 1")
+        sim_t = np.linspace(0, Time, T + 1)                                   # bayeslib.py:115
     for c, o in enumerate(obs):
+        o = np.asarray(o, dtype=float)
+        if times is not None:
+            tc = np.asarray(times[c], dtype=float)
+            if tc.shape != o.shape:
+                raise ValueError("curve %d: %d times for %d observations" % (c, len(tc), len(o)))
+            if len(tc) and (tc.min() < sim_t[0] or tc.max() > sim_t[-1]):
+                raise ValueError("curve %d: observation times outside [0, Time] (the reference would "
+                                 "interpolate them to NaN)" % c)
+            order = np.argsort(tc, kind="stable")
+            tc, o = tc[order], o[order]
+            hi_mat[c, :len(o)], dx_mat[c, :len(o)], h_mat[c, :len(o)] = bracket_times(sim_t, tc)
         obs_mat[c, :len(o)] = o
     if P is None:
         P = np.zeros(S)
@@ -91,10 +122,17 @@ def loglik(X, init_params, lengths, Time, L, T, obs, tol=7, MAX=10000, plT=1, P=
     flags = (_abi.FLAG_STRICT if strict else 0) | (_abi.FLAG_PL_F32 if pl_f32 else 0) \
         | (_abi.FLAG_NORMALIZE if normalize else 0)
     sec = _abi.C.c_double(0.0)
-    _abi.check(_abi.lib().trpl_loglik(_abi.ptr(X), S, Cn, _abi.ptr(lengths), float(Time), int(L), int(T), int(plT),
-                                      int(tol), int(MAX), _abi.ptr(ini), _abi.ptr(obs_mat), obs_ld, _abi.ptr(n_obs),
-                                      _abi.ptr(P), _abi.ptr(sse), _abi.ptr(status), _abi.ptr(iters), flags,
-                                      int(device), _abi.C.byref(sec)))
+    lib = _abi.lib()
+    if times is None:
+        rc = lib.trpl_loglik(_abi.ptr(X), S, Cn, _abi.ptr(lengths), float(Time), int(L), int(T), int(plT), int(tol),
+                             int(MAX), _abi.ptr(ini), _abi.ptr(obs_mat), obs_ld, _abi.ptr(n_obs), _abi.ptr(P),
+                             _abi.ptr(sse), _abi.ptr(status), _abi.ptr(iters), flags, int(device), _abi.C.byref(sec))
+    else:
+        rc = lib.trpl_loglik_obs(_abi.ptr(X), S, Cn, _abi.ptr(lengths), float(Time), int(L), int(T), int(tol), int(MAX),
+                                 _abi.ptr(ini), _abi.ptr(obs_mat), _abi.ptr(hi_mat), _abi.ptr(dx_mat), _abi.ptr(h_mat),
+                                 obs_ld, _abi.ptr(n_obs), _abi.ptr(P), _abi.ptr(sse), _abi.ptr(status),
+                                 _abi.ptr(iters), flags, int(device), _abi.C.byref(sec))
+    _abi.check(rc)
     if info is not None:
         info.update(sse=sse, status=status, iters_total=iters, seconds=sec.value)
     return P
@@ -124,17 +162,25 @@ def simulate(model, e_data, P, X, plI, plI_int, num_curves, sim_params, init_par
     sim_t = np.linspace(0, Time, T + 1)                                   # :115
     pl_dtype = np.dtype(gpu_info.get("pl_dtype", np.float32))
 
+    def in_range(t):
+        t = np.asarray(t, dtype=float)
+        return len(t) > 0 and t.min() >= sim_t[0] and t.max() <= sim_t[-1]
+
     fused = bool(gpu_info.get("fused", False)) and LOG_PL and sim_params[4] == 1 and all(
-        is_grid_prefix(exp[0][c], sim_t) for exp in e_data for c in range(num_curves))
+        in_range(exp[0][c]) for exp in e_data for c in range(num_curves))
     if fused:
+        # an experiment sampled exactly on the full simulation grid is compared point by point
+        # (the reference's bypass, bayeslib.py:182-183); anything else is interpolated (:184-191)
         for blk in range(gpu_id * group, len(X), num_gpus * group):
             size = min(group, len(X) - blk)
             for e, exp in enumerate(e_data):
+                on_grid = all(almost_equal(sim_t, np.asarray(exp[0][c], dtype=float)) for c in range(num_curves))
                 info = {}
                 loglik(X[blk:blk + size], init_params, thicknesses, Time, L, T,
                        [exp[1][c] for c in range(num_curves)], tol=sim_params[6], MAX=sim_params[7],
                        P=P[e, blk:blk + size], pl_f32=(pl_dtype == np.float32), normalize=NORMALIZE,
-                       device=device, info=info)
+                       device=device, info=info,
+                       times=None if on_grid else [exp[0][c] for c in range(num_curves)])
                 solver_time[gpu_id] += info["seconds"]
         return
 

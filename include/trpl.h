@@ -130,6 +130,28 @@ int trpl_loglik_dev(const double *X, int64_t S, int32_t C, const double *lengths
                     int64_t *iters_total, uint32_t flags, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * trpl_loglik_obs -- trpl_loglik for observation times that do NOT lie on the simulation grid:
+ * replaces the per-row time interpolation of bayeslib.simulate (scipy griddata, 1-D linear,
+ * bayeslib.py:184-191) followed by probs.prob, fused into the time-stepper.  For observation i of
+ * curve c (sorted by time, 0 <= t_i <= time_ns) the host passes the bracketing it would hand to
+ * interp1d:  obs_hi[c][i] in [1, T] = index of the upper grid point, obs_dx = t_i - t_lo,
+ * obs_h = t_hi - t_lo; the kernel forms ((y_hi - y_lo) / h) * dx + y_lo from log10 PL at the two
+ * grid points (difference in fp32 under TRPL_FLAG_PL_F32, like interp1d on the reference's
+ * float32 buffer) as soon as step hi has been taken.  plT is 1 on this path.
+ * ------------------------------------------------------------------------------------- */
+int trpl_loglik_obs(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns,
+                    int32_t L, int64_t T, int32_t tol_exp, int32_t max_iter, const double *dN,
+                    const double *obs, const int32_t *obs_hi, const double *obs_dx, const double *obs_h,
+                    int64_t obs_ld, const int64_t *n_obs, double *P, double *sse, int32_t *status,
+                    int64_t *iters_total, uint32_t flags, int32_t device, double *seconds);
+
+int trpl_loglik_obs_dev(const double *X, int64_t S, int32_t C, const double *lengths_nm /*host*/,
+                        double time_ns, int32_t L, int64_t T, int32_t tol_exp, int32_t max_iter,
+                        const double *dN, const double *obs, const int32_t *obs_hi, const double *obs_dx,
+                        const double *obs_h, int64_t obs_ld, const int64_t *n_obs /*host*/, double *P,
+                        double *sse, int32_t *status, int64_t *iters_total, uint32_t flags, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * trpl_pcr_solve_batched_dev -- the stand-alone batched tridiagonal solve (unit U1 of the
  * measurement plan): S independent systems  ld[i] x[i-1] + d[i] x[i] + ud[i] x[i+1] = b[i],
  * i < L, by parallel cyclic reduction with pcreduce's elimination order (pvSimPCR.py:42-81),

@@ -13,6 +13,7 @@ Reference entry points exercised (file:line):
   probs.fastlog :78-85, probs.prob :49-62                   -> probs.npz
   bayeslib.random_grid :18-32, bayeslib.bayes :207-252      -> bayes_e2e.npz, sampler.npz
   pvSim_fallback.pvSim_cpu_fallback :80-117 (as shipped)    -> fallback.npz
+  bayes_io.get_initpoints :106-119, get_data :15-104 + bayes -> bayes_realdata.npz
 
 Usage:  python oracle/gen_golden.py [case ...]     (default: all cases)
 """
@@ -244,7 +245,60 @@ def case_fallback():
                         length=2000.0, L=128, plI=pl, seconds=np.array(secs))
 
 
-CASES = {"pcr_norm": case_pcr_norm, "probs": case_probs, "sampler": case_sampler,
+def case_bayes_realdata():
+    """The reference's own ingestion (bayes_io.get_initpoints / get_data on the shipped example
+    files, bayes_io.py:15-119) feeding bayeslib.bayes: experiment 0 = the shipped
+    Balancedhighsurf observations cut at 5 ns (201 on-grid points -> bypass path), experiment 1 =
+    off-grid, irregular observation times (per-row griddata, bayeslib.py:184-191)."""
+    from bayes_io import get_data
+    obs_file = os.path.join(REF, "Example Data", "Balancedhighsurf_Power_scan_Observations.csv")
+    ic_flags = {"time_cutoff": 5, "select_obs_sets": None, "noise_level": None}
+    sim_flags = {"load_PL_from_file": False, "override_equal_auger": False, "override_equal_mu": False,
+                 "override_equal_s": False, "log_pl": True, "self_normalize": False,
+                 "random_sample": True, "num_points": 4}
+    ini = get_initpoints(EXC_POWER, ic_flags)
+    e_data = get_data([obs_file], ic_flags, sim_flags, scale_f=1e-23)
+    T, Time = 200, 5.0
+    rng = np.random.default_rng(5)
+    t_off, v_off = [], []
+    for c in range(3):
+        tt = np.sort(np.concatenate([[0.0, Time], rng.uniform(0, Time, 55), [0.025 * 17, 0.025 * 118]]))
+        t_off.append(tt)
+        v_off.append(np.interp(tt, e_data[0][0][c], e_data[0][1][c]) + 0.05)
+    e_data.append((t_off, v_off, [np.ones_like(t) for t in t_off]))
+    simPar = [2000, Time, 128, T, 1, PT, 7, 10000]
+    gpu_info = {"sims_per_gpu": 3, "num_gpus": 1, "has_GPU": True, "threads_per_block": (1,),
+                "max_sims_per_block": 1}
+    np.random.seed(42)
+    N, P, X = bayeslib.bayes(pvSimPCR.pvSim, np.array([0]), None, MINX * UNIT, MAXX * UNIT, DO_LOG, ini, simPar,
+                             e_data, sim_flags, gpu_info, logger=None)
+    out = {"X": X, "P": P, "ini": ini, "T": T, "time": Time, "length": 2000.0, "L": 128}
+    for e in range(2):
+        for c in range(3):
+            out[f"t_{e}_{c}"] = np.asarray(e_data[e][0][c]); out[f"v_{e}_{c}"] = np.asarray(e_data[e][1][c])
+            out[f"u_{e}_{c}"] = np.asarray(e_data[e][2][c])
+    np.savez_compressed(os.path.join(OUT, "bayes_realdata.npz"), **out)
+
+
+def case_csv_fixture():
+    """Small DATA fixtures in the reference's two file formats, cut from its shipped example files:
+    the three excitation rows, and the observation rows with t <= 6 ns of each of the three
+    Balancedhighsurf curves (the tests apply time_cutoff = 5 on top)."""
+    import csv
+    obs_file = os.path.join(REF, "Example Data", "Balancedhighsurf_Power_scan_Observations.csv")
+    with open(EXC_POWER, newline="") as fh, open(os.path.join(OUT, "exc_power_scan.csv"), "w", newline="") as out:
+        w = csv.writer(out)
+        for row in csv.reader(fh):
+            if len(row):
+                w.writerow(row)
+    with open(obs_file, newline="") as fh, open(os.path.join(OUT, "obs_balanced_6ns.csv"), "w", newline="") as out:
+        w = csv.writer(out)
+        for row in csv.reader(fh):
+            if row[0] == "END" or float(row[0]) <= 6.0:
+                w.writerow(row)
+
+
+CASES = {"csv_fixture": case_csv_fixture, "bayes_realdata": case_bayes_realdata, "pcr_norm": case_pcr_norm, "probs": case_probs, "sampler": case_sampler,
          "pvsim_small": case_pvsim_small, "pvsim_power": case_pvsim_power,
          "pvsim_twothick": case_pvsim_twothick, "bayes_e2e": case_bayes_e2e,
          "fallback": case_fallback}

@@ -253,6 +253,51 @@ def test_fused_loglik_twothick_normalize_and_nonconvergence(gpu, oracle):
     assert np.all(np.isneginf(Pn[bad])) and np.array_equal(Pn[~bad], Ps[~bad])
 
 
+def test_fused_loglik_real_data_and_offgrid_times(gpu, oracle, golden):
+    """Shipped example data through this repo's own ingestion, then the fused kernel: on-grid
+    experiment (trpl_loglik) and irregular off-grid observation times (trpl_loglik_obs, the
+    in-kernel form of the reference's per-row griddata) against the reference's bayes() output."""
+    import os
+    from conftest import GOLDEN
+    g = golden("bayes_realdata")
+    T, Time, X = int(g["T"]), float(g["time"]), g["X"]
+    ini = gpu.get_initpoints(os.path.join(GOLDEN, "exc_power_scan.csv"), {"select_obs_sets": None})
+    e0 = gpu.get_data([os.path.join(GOLDEN, "obs_balanced_6ns.csv")],
+                      {"time_cutoff": 5, "select_obs_sets": None, "noise_level": None},
+                      {"log_pl": True, "self_normalize": False})[0]
+    t1 = [g[f"t_1_{c}"] for c in range(3)]; v1 = [g[f"v_1_{c}"] for c in range(3)]
+    # float32-staged, like the reference's buffer
+    P0 = gpu.loglik(X, ini, 2000.0, Time, 128, T, e0[1], pl_f32=True)
+    P1 = gpu.loglik(X, ini, 2000.0, Time, 128, T, v1, times=t1, pl_f32=True)
+    assert np.max(np.abs(P0 - g["P"][0]) / np.abs(g["P"][0])) < 2e-5
+    assert np.max(np.abs(P1 - g["P"][1]) / np.abs(g["P"][1])) < 2e-5
+    # full fp64 against the oracle with a float64 buffer (scipy griddata on the CPU side)
+    want = oracle.simulate_loglik(X, ini, 2000.0, Time, 128, T, [(t1, v1)], pl_dtype=np.float64, nthreads=4)[0]
+    for strict, tol in ((True, 1e-11), (False, 1e-8)):
+        info = {}
+        P64 = gpu.loglik(X, ini, 2000.0, Time, 128, T, v1, times=t1, strict=strict, info=info)
+        assert not info["status"].any() and np.max(np.abs(P64 - want) / np.abs(want)) < tol
+    # unsorted input is sorted by time; observation order does not matter beyond rounding
+    perm = np.random.default_rng(0).permutation(len(t1[0]))
+    Pp = gpu.loglik(X, ini, 2000.0, Time, 128, T, [v1[0][perm], v1[1], v1[2]], times=[t1[0][perm], t1[1], t1[2]])
+    assert np.allclose(Pp, P64, rtol=1e-12)
+    with pytest.raises(ValueError):
+        gpu.loglik(X, ini, 2000.0, Time, 128, T, v1, times=[t1[0] + 1.0, t1[1], t1[2]])
+    # simulate() in fused mode picks the right entry point per experiment
+    e_data = [e0, (t1, v1, [None] * 3)]
+    P = np.zeros((2, len(X))); z = np.zeros(1)
+    gpu.simulate(gpu.pvSim, e_data, P, X, [None], [None], 3, [2000.0, Time, 128, T, 1, (0,), 7, 10000], ini,
+                 {"load_PL_from_file": False, "log_pl": True, "self_normalize": False},
+                 {"sims_per_gpu": 3, "num_gpus": 1, "fused": True}, 0, z.copy(), z.copy(), z.copy())
+    assert np.max(np.abs(P - g["P"]) / np.abs(g["P"])) < 2e-5
+    # ... and the unfused drop-in loop gives the same
+    P2 = np.zeros((2, len(X)))
+    gpu.simulate(gpu.pvSim, e_data, P2, X, [None], [None], 3, [2000.0, Time, 128, T, 1, (0,), 7, 10000], ini,
+                 {"load_PL_from_file": False, "log_pl": True, "self_normalize": False},
+                 {"sims_per_gpu": 3, "num_gpus": 1}, 0, z.copy(), z.copy(), z.copy())
+    assert np.max(np.abs(P2 - g["P"]) / np.abs(g["P"])) < 2e-5
+
+
 # ----------------------------------------------------------------------------- full-size properties
 def test_full_size_properties(gpu):
     """At sizes the CPU oracle cannot reach: (i) FAST vs STRICT agree on thousands of random

@@ -120,3 +120,47 @@ def test_simulate_control_flow_with_standin_compute(trpl, monkeypatch):
     with pytest.raises(NotImplementedError):
         drv.simulate(fake_model, e_data, P, X, [None], [None], 2, sim_params, ini,
                      dict(flags, load_PL_from_file=True), {"sims_per_gpu": 3, "num_gpus": 1}, 0, st, et, mt)
+
+
+def test_csv_ingestion_matches_reference(trpl, golden, tmp_path):
+    """dataio.get_initpoints / get_data on data files cut from the reference's shipped examples
+    against the arrays the reference's own bayes_io produced from them (bayes_io.py:15-119)."""
+    import os
+    from conftest import GOLDEN
+    g = golden("bayes_realdata")
+    ini = trpl.get_initpoints(os.path.join(GOLDEN, "exc_power_scan.csv"), {"select_obs_sets": None})
+    assert np.array_equal(ini, g["ini"])
+    assert np.allclose(ini, trpl.workloads.power_scan(128)[0], rtol=1e-8)      # analytic regeneration
+    ic = {"time_cutoff": 5, "select_obs_sets": None, "noise_level": None}
+    sf = {"log_pl": True, "self_normalize": False}
+    e = trpl.get_data([os.path.join(GOLDEN, "obs_balanced_6ns.csv")], ic, sf, scale_f=1e-23)
+    assert len(e) == 1 and len(e[0][0]) == 3
+    for c in range(3):
+        assert np.array_equal(e[0][0][c], g[f"t_0_{c}"]) and np.array_equal(e[0][1][c], g[f"v_0_{c}"])
+        assert np.array_equal(e[0][2][c], g[f"u_0_{c}"])
+    # options: curve selection, no cutoff (6 ns = 241 points), self-normalisation, linear PL
+    e2 = trpl.get_data([os.path.join(GOLDEN, "obs_balanced_6ns.csv")],
+                       {"time_cutoff": None, "select_obs_sets": [2, 0], "noise_level": None},
+                       {"log_pl": False, "self_normalize": True})
+    assert [len(t) for t in e2[0][0]] == [241, 241] and np.isclose(max(e2[0][1][0]), 1.0)
+    assert np.array_equal(e2[0][0][1][:201], g["t_0_0"])
+    P = np.arange(6.0).reshape(2, 3); X = np.ones((3, 13))
+    trpl.export(str(tmp_path / "runA"), P[0], X)
+    assert np.array_equal(np.load(tmp_path / "runA" / "runA_BAYRAN_P.npy"), P[0])
+    assert np.array_equal(np.load(tmp_path / "runA" / "runA_BAYRAN_X.npy"), X)
+
+
+def test_bracket_times_is_interp1d_bracketing(trpl):
+    sim_t = np.linspace(0, 5, 201)
+    rng = np.random.default_rng(2)
+    times = np.sort(np.concatenate([[0.0, 5.0, sim_t[17], sim_t[118]], rng.uniform(0, 5, 40)]))
+    hi, dx, h = trpl.bracket_times(sim_t, times)
+    # float32 rows, as in the reference's buffer: scipy takes its generic linear path (for float64
+    # 1-D rows it delegates to np.interp, which brackets on-grid points differently -- same value
+    # up to rounding)
+    y = rng.normal(size=201).astype(np.float32)
+    want = griddata(sim_t, y, times)
+    got = ((y[hi] - y[hi - 1]) / h) * dx + y[hi - 1]
+    assert np.array_equal(got, want) and hi.min() >= 1 and hi.max() <= 200 and hi.dtype == np.int32
+    y64 = y.astype(np.float64)
+    assert np.allclose(((y64[hi] - y64[hi - 1]) / h) * dx + y64[hi - 1], griddata(sim_t, y64, times), rtol=0, atol=1e-15)

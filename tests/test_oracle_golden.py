@@ -101,3 +101,14 @@ def test_simulate_end_to_end_bit_exact(oracle, golden):
     P = oracle.simulate_loglik(g["X"], g["ini"], float(g["length"]), float(g["time"]), int(g["L"]), T, e_data,
                                sims_per_gpu=int(g["sims_per_gpu"]), nthreads=4)
     assert np.array_equal(P, g["P"])
+
+
+def test_simulate_real_data_and_offgrid_times_bit_exact(oracle, golden):
+    """bayes() on the reference's shipped example files (ingested by its own bayes_io): exp 0 on
+    the grid, exp 1 at irregular off-grid times (per-row griddata)."""
+    g = golden("bayes_realdata")
+    T = int(g["T"])
+    e_data = [([g[f"t_{e}_{c}"] for c in range(3)], [g[f"v_{e}_{c}"] for c in range(3)]) for e in range(2)]
+    P = oracle.simulate_loglik(g["X"], g["ini"], float(g["length"]), float(g["time"]), 128, T, e_data,
+                               sims_per_gpu=3, nthreads=4)
+    assert np.array_equal(P, g["P"])
