@@ -29,6 +29,14 @@
 
 #include "trpl_common.hpp"
 
+// Development-only ablation switches for tools/iter_bench.hip (cost breakdown of one inner
+// iteration).  Always 0 in the library build; non-zero values compute WRONG results by design.
+//   1: no LDS exchange in the PCR levels   2: reciprocals replaced by a multiply
+//   4: no wave reductions                  8: no DPP shifts
+#ifndef TRPL_ABLATE
+#define TRPL_ABLATE 0
+#endif
+
 namespace trpl {
 
 constexpr uint32_t kFlagPlF32 = 0x2;       // TRPL_FLAG_PL_F32
@@ -384,6 +392,7 @@ __device__ __forceinline__ void static_for(F &&f)
 
 __device__ __forceinline__ double rcp_nr1(double d)      // one Newton step: 2e-15 relative (measured)
 {
+    if constexpr ((TRPL_ABLATE & 2) != 0) return d * 0.999;
     const double r = __builtin_amdgcn_rcp(d);
     return __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
 }
@@ -392,14 +401,14 @@ __device__ __forceinline__ float rcp_nr1(float d) { return 1.0f / d; }
 template <int K, typename T>
 __device__ __forceinline__ T lane_up(T v, int lane)       // value held by lane + K (mod 64)
 {
-    if constexpr (K == 0) return v;
+    if constexpr (K == 0 || (TRPL_ABLATE & 8) != 0) return v;
     else if constexpr (K == 1) return dpp_mov<kDppWaveRol1>(v);
     else return __shfl(v, (lane + K) & 63, 64);
 }
 template <int K, typename T>
 __device__ __forceinline__ T lane_dn(T v, int lane)       // value held by lane - K (mod 64)
 {
-    if constexpr (K == 0) return v;
+    if constexpr (K == 0 || (TRPL_ABLATE & 8) != 0) return v;
     else if constexpr (K == 1) return dpp_mov<kDppWaveRor1>(v);
     else return __shfl(v, (lane - K) & 63, 64);
 }
@@ -439,6 +448,7 @@ __device__ __forceinline__ double dpp_add(double v)
 // Sum of v over the 64 lanes, returned wave-uniform (SGPRs).
 __device__ __forceinline__ double wave_sum(double v)
 {
+    if constexpr ((TRPL_ABLATE & 4) != 0) return uniform_d(v);
     v = dpp_add<0x111, 0xF>(v);          // row_shr:1
     v = dpp_add<0x112, 0xF>(v);          // row_shr:2
     v = dpp_add<0x114, 0xF>(v);          // row_shr:4
@@ -464,11 +474,13 @@ __device__ __forceinline__ void pair32(double v, double &lo_half, double &hi_hal
 // PCR in the interleaved layout with the neighbour exchange STAGED THROUGH LDS: each level the
 // wave stores its normalised rows (ld, ud, B)/d as three node-indexed arrays (one 16-byte store
 // per array: a lane's NR rows are adjacent nodes) and loads the rows at i-RF and i+RF with one
-// 16-byte load per array and direction.  9 DS instructions per level instead of 24
-// ds_bpermute_b32 (whose issue queue was the bottleneck: SQ_WAIT_INST_LDS 29 %).  A wavefront
-// executes its DS instructions in order, so no barrier is needed and the 3*L-double buffer is
-// reused by every level.  Stride 1 (odd: rows straddle lanes) stays on DPP.  Out-of-range
-// neighbours wrap to in-array values that are multiplied by exact zeros.
+// 16-byte load per array and direction: 9 DS instructions per level instead of 24
+// ds_bpermute_b32.  A wavefront executes its DS instructions in order, so no barrier is needed
+// and the 3*L-double buffer is reused by every level.  The LDS (shared by the CU's 4 SIMDs) and
+// the VALU are the two near-saturated resources of this kernel (tools/iter_bench.hip), so the
+// strides whose lane shift is 0 or 1 stay on DPP rotates and the final pairing on
+// v_permlane32_swap; only lane shifts 2..16 go through LDS.  Out-of-range neighbours wrap to
+// in-array values that are multiplied by exact zeros.
 template <int NR>
 struct vecN { double v[NR]; };
 
@@ -500,13 +512,16 @@ __device__ __forceinline__ void pcr_levels_L(double (&ld)[NR], double (&d)[NR], 
             nl[j] = ld[j] * r; nu[j] = ud[j] * r; nB[j] = B[j] * r;
         }
         double l_m[NR], u_m[NR], B_m[NR], l_p[NR], u_p[NR], B_p[NR];
-        if constexpr (RF % NR != 0) {              // rows straddle lanes: DPP / in-lane moves
+        if constexpr (RF / NR <= 1) {              // lane shift 0 or 1: in-lane moves / DPP rotates (VALU only)
             nbrB_dn<double, NR, RF>(nl, l_m, lane);
             nbrB_dn<double, NR, RF>(nu, u_m, lane);
             nbrB_dn<double, NR, RF>(nB, B_m, lane);
             nbrB_up<double, NR, RF>(nl, l_p, lane);
             nbrB_up<double, NR, RF>(nu, u_p, lane);
             nbrB_up<double, NR, RF>(nB, B_p, lane);
+        } else if constexpr ((TRPL_ABLATE & 1) != 0) {
+#pragma unroll
+            for (int j = 0; j < NR; j++) { l_m[j] = nl[j]; u_m[j] = nu[j]; B_m[j] = nB[j]; l_p[j] = nu[j]; u_p[j] = nl[j]; B_p[j] = -nB[j]; }
         } else {
             xch_store<NR, L>(xch, 0, lane, nl);
             xch_store<NR, L>(xch, 1, lane, nu);
@@ -537,24 +552,20 @@ __device__ __forceinline__ void pcr_solve_L(double (&ld)[NR], double (&d)[NR], d
                                             double (&x)[NR], int lane, double *xch)
 {
     pcr_levels_L<NR, L, 1>(ld, d, ud, B, lane, xch);
-    // final 2x2 solves (pvSimPCR.py:75-79): the lower node of a pair needs (d, ld, B) of the upper,
-    // the upper needs (d, ud, B) of the lower: publish d, B and q = (lower ? ud : ld)
+    // final 2x2 solves (pvSimPCR.py:75-79) between lanes l and l^32: v_permlane32_swap hands every
+    // lane the lower and the upper node's value (VALU only; the LDS is the scarcer resource)
     const bool low = lane < 32;
-    double q[NR], d_o[NR], q_o[NR], B_o[NR];
-#pragma unroll
-    for (int j = 0; j < NR; j++) q[j] = low ? +ud[j] : +ld[j];
-    xch_store<NR, L>(xch, 0, lane, d);
-    xch_store<NR, L>(xch, 1, lane, q);
-    xch_store<NR, L>(xch, 2, lane, B);
-    const int partner = (NR * lane + L / 2) & (L - 1);
-    xch_load<NR, L>(xch, 0, partner, d_o);
-    xch_load<NR, L>(xch, 1, partner, q_o);
-    xch_load<NR, L>(xch, 2, partner, B_o);
 #pragma unroll
     for (int j = 0; j < NR; j++) {
-        const double d_lo = low ? d[j] : d_o[j], d_hi = low ? d_o[j] : d[j];
-        const double B_lo = low ? B[j] : B_o[j], B_hi = low ? B_o[j] : B[j];
-        const double ud_lo = low ? ud[j] : q_o[j], ld_hi = low ? q_o[j] : ld[j];
+        double d_lo, d_hi, B_lo, B_hi, ud_lo, ud_hi, ld_lo, ld_hi;
+        if constexpr ((TRPL_ABLATE & 1) != 0) {
+            d_lo = d[j]; d_hi = d[j] * 1.5; B_lo = B[j]; B_hi = -B[j]; ud_lo = ud[j]; ld_hi = ld[j];
+        } else {
+            pair32(d[j], d_lo, d_hi);
+            pair32(B[j], B_lo, B_hi);
+            pair32(ud[j], ud_lo, ud_hi);
+            pair32(ld[j], ld_lo, ld_hi);
+        }
         const double r1 = rcp_nr1(d_hi);
         const double k = ud_lo * r1;
         const double xl = (B_lo - B_hi * k) * rcp_nr1(d_lo - ld_hi * k);
