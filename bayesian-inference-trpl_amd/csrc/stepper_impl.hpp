@@ -23,6 +23,7 @@
 #pragma once
 #include <math.h>
 #include <float.h>
+#include <stdlib.h>
 
 #include <type_traits>
 #include <utility>
@@ -33,6 +34,9 @@
 // iteration).  Always 0 in the library build; non-zero values compute WRONG results by design.
 //   1: no LDS exchange in the PCR levels   2: reciprocals replaced by a multiply
 //   4: no wave reductions                  8: no DPP shifts
+#ifndef TRPL_FAST_WAVES
+#define TRPL_FAST_WAVES 3      // waves per SIMD the fast stepper is register-budgeted for
+#endif
 #ifndef TRPL_ABLATE
 #define TRPL_ABLATE 0
 #endif
@@ -552,25 +556,26 @@ __device__ __forceinline__ void pcr_solve_L(double (&ld)[NR], double (&d)[NR], d
                                             double (&x)[NR], int lane, double *xch)
 {
     pcr_levels_L<NR, L, 1>(ld, d, ud, B, lane, xch);
-    // final 2x2 solves (pvSimPCR.py:75-79) between lanes l and l^32: v_permlane32_swap hands every
-    // lane the lower and the upper node's value (VALU only; the LDS is the scarcer resource)
+    // final 2x2 solves (pvSimPCR.py:75-79) between lanes l and l^32, by Cramer's rule so that each
+    // lane computes only its own unknown with ONE reciprocal:
+    //     [ d_lo  ud_lo ] [x_lo]   [B_lo]        x_own = (B_own d_oth - c_own B_oth) / (d_own d_oth - c_own c_oth)
+    //     [ ld_hi d_hi  ] [x_hi] = [B_hi]        c = coupling to the partner row (ud for the lower, ld for the upper)
+    // v_permlane32_swap delivers the partner's values on the VALU (the LDS is the scarcer resource).
     const bool low = lane < 32;
 #pragma unroll
     for (int j = 0; j < NR; j++) {
-        double d_lo, d_hi, B_lo, B_hi, ud_lo, ud_hi, ld_lo, ld_hi;
+        const double c_own = low ? +ud[j] : +ld[j];
+        double d_oth, B_oth, c_oth;
         if constexpr ((TRPL_ABLATE & 1) != 0) {
-            d_lo = d[j]; d_hi = d[j] * 1.5; B_lo = B[j]; B_hi = -B[j]; ud_lo = ud[j]; ld_hi = ld[j];
+            d_oth = d[j] * 1.5; B_oth = -B[j]; c_oth = c_own;
         } else {
-            pair32(d[j], d_lo, d_hi);
-            pair32(B[j], B_lo, B_hi);
-            pair32(ud[j], ud_lo, ud_hi);
-            pair32(ld[j], ld_lo, ld_hi);
+            double lo_h, hi_h;
+            pair32(d[j], lo_h, hi_h);  d_oth = low ? hi_h : lo_h;
+            pair32(B[j], lo_h, hi_h);  B_oth = low ? hi_h : lo_h;
+            pair32(c_own, lo_h, hi_h); c_oth = low ? hi_h : lo_h;
         }
-        const double r1 = rcp_nr1(d_hi);
-        const double k = ud_lo * r1;
-        const double xl = (B_lo - B_hi * k) * rcp_nr1(d_lo - ld_hi * k);
-        const double xh = (B_hi - ld_hi * xl) * r1;
-        x[j] = low ? xl : xh;
+        const double det = d[j] * d_oth - c_own * c_oth;
+        x[j] = (B[j] * d_oth - c_own * B_oth) * rcp_nr1(det);
     }
 }
 
@@ -752,7 +757,7 @@ __device__ __forceinline__ void update_field(const MatPar &m, double a0, const d
 }
 
 template <int L, bool STRICT>
-__global__ void __launch_bounds__(64, STRICT ? 2 : 3) stepper_kernel(const StepArgs a)
+__global__ void __launch_bounds__(64, STRICT ? 2 : TRPL_FAST_WAVES) stepper_kernel(const StepArgs a)
 {
     constexpr int W = L < 64 ? L : 64;
     constexpr int NR = L / W;
@@ -962,9 +967,11 @@ hipError_t launch_stepper(const StepArgs &a, hipStream_t stream)
     const int64_t nsys = a.S * a.C;
     if (nsys <= 0) return hipSuccess;
     dim3 grid((unsigned)nsys), block(64);
+    // development knob: extra dynamic LDS per workgroup lowers the number of resident waves
+    static const unsigned lds_pad = getenv("TRPL_LDS_PAD") ? (unsigned)atoi(getenv("TRPL_LDS_PAD")) : 0u;
     switch (a.L) {
 #define TRPL_CASE(LL) \
-    case LL: hipLaunchKernelGGL((stepper_kernel<LL, STRICT>), grid, block, 0, stream, a); break;
+    case LL: hipLaunchKernelGGL((stepper_kernel<LL, STRICT>), grid, block, lds_pad, stream, a); break;
         TRPL_CASE(4) TRPL_CASE(8) TRPL_CASE(16) TRPL_CASE(32) TRPL_CASE(64) TRPL_CASE(128)
         TRPL_CASE(256) TRPL_CASE(512)
 #undef TRPL_CASE
