@@ -140,6 +140,23 @@ def test_pvsim_dropin_signature(gpu, golden):
         gpu.pvSim(plI, None, None, None, g["X"][:, :-1], sim_params, g["ini"][1][:64], init_mode="points")
 
 
+@pytest.mark.parametrize("L", [256, 512])
+def test_pvsim_fine_grids_vs_oracle(gpu, oracle, L):
+    """L = 256 / 512 (4 and 8 rows per lane; the reference cannot run 512: its shared arrays exceed
+    the 48 KB static limit).  No reference golden exists, so the pinned oracle is the
+    check: STRICT iteration counts equal, PL to 1e-13; FAST to 1e-9."""
+    w = gpu.workloads
+    X = w.samples(3)
+    T, Time, length = 12, 12 * 0.025, 2000.0
+    ini = w.beer_lambert(w.POWER_SCAN_A_CM3[2], length, L)
+    r = oracle.pvsim(X[:, :-1], length, Time, L, T, ini)
+    pl, st, it, _ = gpu.solve_pl(X[:, :-1], length, Time, L, T, ini, strict=True)
+    assert not st.any() and np.array_equal(it, r["iters_total"]) and relerr(pl, r["plI"]) < RTOL_STRICT
+    pl, st, it, _ = gpu.solve_pl(X[:, :-1], length, Time, L, T, ini)
+    assert not st.any() and relerr(pl, r["plI"]) < RTOL_FAST
+    assert np.all(np.abs(it - r["iters_total"]) <= 0.01 * r["iters_total"] + 1)
+
+
 # ----------------------------------------------------------------------------- probs
 def test_fastlog_and_prob_vs_reference_golden(gpu, golden):
     g = golden("probs")
