@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcr", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (one GPU per rank); gloo = rehearsal of the N>1 control flow "
+                         "with host-staged collectives (ranks may share a GPU)")
     args = ap.parse_args()
 
     import torch
@@ -70,11 +73,17 @@ def main():
                          % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")      # where collectives run
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     L, T, dt_ns = 128, args.T, 0.025
     Time = T * dt_ns
@@ -113,7 +122,7 @@ def main():
             e1.record()
             ev.append((e0, e1))
         if world > 1:
-            return trpl_amd.dist.gather_likelihoods(P[None, :], S_total)
+            return trpl_amd.dist.gather_likelihoods(P[None, :].to(cdev), S_total)
         return P[None, :]
 
     def fence():
@@ -131,7 +140,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -140,7 +149,7 @@ def main():
     it_total = int(iters.sum().item())                        # inner iterations in ONE pass on this rank
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     if world > 1:
-        agg = torch.tensor([it_total, n_fail], dtype=torch.float64, device=dev)
+        agg = torch.tensor([it_total, n_fail], dtype=torch.float64, device=cdev)
         dist.all_reduce(agg)
         it_all, fail_all = int(agg[0].item()), int(agg[1].item())
     else:
@@ -168,7 +177,8 @@ def main():
         "config": {"workload": "%s x %d samples/GPU (%d total), %d curves, L=128 nodes, T=%d steps of dt=0.025 ns, "
                                "tol=1e-7, MAX=10000, fp64, arithmetic=%s"
                                % (args.workload, args.samples_per_gpu, S_total, C, T, "strict" if args.strict else "fast"),
-                   "samples_total": S_total, "curves": C, "L": L, "T": T, "parallelism": "sample-shard x%d" % world},
+                   "samples_total": S_total, "curves": C, "L": L, "T": T, "parallelism": "sample-shard x%d" % world,
+                   "collective": "none" if world == 1 else ("RCCL all_gather" if args.backend == "nccl" else "gloo all_gather (rehearsal)")},
         "likelihoods_per_s_at_T": S_total * args.steps / elapsed,
         "likelihoods_per_s_at_T80000_equiv": value / (C * 80001),
         "inner_iterations_per_s": it_all * args.steps / elapsed,
