@@ -60,14 +60,24 @@ def main():
                          "with host-staged collectives (ranks may share a GPU)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    import trpl_amd
-    from trpl_amd import device as tdev, workloads as wl
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import trpl_amd
+    from trpl_amd import workloads as wl
+
+    # CPU baselines first: they fork worker processes, which must happen before this process
+    # initialises the GPU.  Rank 0 at N = 1 only; bounded samples of the same workload.
+    cpu_legs = {}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        ini_c, lens_c = wl.power_scan(128) if args.workload == "power_scan" else wl.twothick(128)
+        cpu_legs["cpu_baseline"] = cpu_baseline(wl, trpl_amd, ini_c, lens_c, args.T * 0.025, 128, args.T, args.cpu_seconds)
+        cpu_legs["cpu_baseline_scipy"] = cpu_baseline_scipy(wl, ini_c, lens_c, args.T * 0.025, 128, args.T)
+
+    import torch
+    import torch.distributed as dist
+    from trpl_amd import device as tdev
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)"
                          % (args.gpus, world))
@@ -196,8 +206,7 @@ def main():
         out["roofline_hbm_pcr"] = bench_pcr(torch, tdev, dev, flags)
     if rank == 0:
         attach_traffic(out)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(wl, trpl_amd, ini, lens, Time, L, T, args.cpu_seconds)
+    out.update(cpu_legs)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -287,6 +296,22 @@ def cpu_baseline(wl, trpl_amd, ini, lens, Time, L, T, budget_s):
             "sample": "%d seeded samples of the same box x %d curves x T=%d steps (%.1f s on %d OpenMP threads)"
                       % (n2, len(lens), T, t2, cores),
             "likelihoods_per_s_at_T": n2 / t2}
+
+
+def cpu_baseline_scipy(wl, ini, lens, Time, L, T):
+    """The "scipy CPU path" named by the north star: a port (oracle/scipy_mol.py, pinned to the
+    output of the reference's pvSim_fallback) of the reference's CPU model -- method of lines +
+    scipy solve_ivp(BDF) per system + Simpson PL + log10 + squared error -- on one worker process
+    per host core.  A different, adaptive-step algorithm: a timing baseline, not a parity target."""
+    from oracle import scipy_mol
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n = max(1, (2 * cores) // len(lens))
+    X = wl.samples(n)
+    sec, nsys = scipy_mol.timed_batch(X, ini, lens, Time, L, T, cores)
+    return {"value": nsys * (T + 1) / sec, "unit": "system-timesteps/s", "cores": cores, "kind": "port",
+            "sample": "%d seeded samples x %d curves, scipy solve_ivp(BDF, rtol 1e-5) sampled on T=%d output steps "
+                      "(%.1f s on %d processes)" % (n, len(lens), T, sec, cores),
+            "likelihoods_per_s_at_T": n / sec}
 
 
 if __name__ == "__main__":

@@ -112,3 +112,19 @@ def test_simulate_real_data_and_offgrid_times_bit_exact(oracle, golden):
     P = oracle.simulate_loglik(g["X"], g["ini"], float(g["length"]), float(g["time"]), 128, T, e_data,
                                sims_per_gpu=3, nthreads=4)
     assert np.array_equal(P, g["P"])
+
+
+def test_scipy_port_matches_reference_fallback(golden):
+    """oracle/scipy_mol.py (the "scipy CPU path" timing baseline) against PL(t) produced by the
+    reference's pvSim_fallback.pvSim_cpu_fallback as shipped (no stand-in involved)."""
+    from oracle import scipy_mol
+    g = golden("fallback")
+    X, T, Time = g["X"], int(g["T"]), float(g["time"])
+    for c in (0, 2):
+        pl = np.empty((2, T + 1))
+        scipy_mol.pvsim_cpu(pl, X[:2], [float(g["length"]), Time, int(g["L"]), T], g["ini"][c])
+        assert np.max(np.abs(pl / g["plI"][c][:2] - 1)) < 1e-6
+    # it is a different discretisation of PL (Simpson) than the GPU path's midpoint rule: 0.03-0.04 dex at t=0
+    import oracle
+    mid = oracle.pvsim(X[:1, :-1], float(g["length"]), Time, 128, T, g["ini"][2])["plI"][0]
+    assert 0.02 < abs(np.log10(mid[0] / g["plI"][2][0][0])) < 0.05
