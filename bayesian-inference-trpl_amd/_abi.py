@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libtrpl_hip.so")
 
 # status codes / flags (include/trpl.h)
 OK, ERR_ARG, ERR_HIP, ERR_NODEVICE, ERR_UNSUPPORTED = 0, 1, 2, 3, 4
-FLAG_STRICT, FLAG_PL_F32, FLAG_NORMALIZE = 0x1, 0x2, 0x4
+FLAG_STRICT, FLAG_PL_F32, FLAG_NORMALIZE, FLAG_FP32 = 0x1, 0x2, 0x4, 0x8
 
 
 class TrplError(RuntimeError):

@@ -1,0 +1,361 @@
+// fp32 variant of the time-stepper (TRPL_FLAG_FP32; BASELINE configs[4]: L = 512, fp32).
+//
+// Same scheme as stepper_impl.hpp (reference: pvSimPCR.py:93-306), interleaved layout
+// i = NR*lane + j, FAST arithmetic.  The N/P/E state, the BDF history, the tridiagonal systems and
+// the PCR run in fp32 (half the registers, LDS bytes and cross-lane traffic per node); everything
+// that is summed over nodes or time -- residual norms, the PL quadrature, log10 and the squared
+// error -- is formed in fp64.  fp32 cannot reach the reference's tol = 7 (residual floor ~1e-7,
+// SURVEY App. B result 5): callers pass tol 4-5.  There is no reference for this mode (the
+// reference is fp64 only and cannot run L = 512); parity is stated against the fp64 oracle at the
+// tolerance fp32 allows (tests/test_gpu_parity.py).
+#pragma once
+#include "stepper_impl.hpp"
+
+namespace trpl {
+namespace f32 {
+
+__device__ __forceinline__ float rcp1(float d)            // v_rcp_f32 (1 ulp) + one Newton step
+{
+    const float r = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(r, __builtin_fmaf(-d, r, 1.0f), r);
+}
+
+struct MatParF {
+    float N0, P0, DN, DP, rate, sr0, srL, CN, CP, tauN, tauP, Lambda, n0p0;
+};
+
+template <int NR>
+struct vecF { float v[NR]; };
+
+template <int NR, int L>
+__device__ __forceinline__ void xstore(float *xch, int arr, int lane, const float (&x)[NR])
+{
+    vecF<NR> t;
+#pragma unroll
+    for (int j = 0; j < NR; j++) t.v[j] = x[j];
+    *reinterpret_cast<vecF<NR> *>(xch + arr * L + NR * lane) = t;
+}
+template <int NR, int L>
+__device__ __forceinline__ void xload(const float *xch, int arr, int node0, float (&y)[NR])
+{
+    const vecF<NR> t = *reinterpret_cast<const vecF<NR> *>(xch + arr * L + node0);
+#pragma unroll
+    for (int j = 0; j < NR; j++) y[j] = t.v[j];
+}
+
+__device__ __forceinline__ float partner32(float v)       // value held by lane ^ 32
+{
+    const unsigned a = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+    // r[0] = (lo,lo) halves, r[1] = (hi,hi): the other half's value is r[1] in low lanes, r[0] in high lanes
+    return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
+}
+
+template <int NR, int L, int RF>
+__device__ __forceinline__ void pcr_levels(float (&ld)[NR], float (&d)[NR], float (&ud)[NR], float (&B)[NR], int lane,
+                                           float *xch)
+{
+    if constexpr (L > 2 * RF) {
+        float nl[NR], nu[NR], nB[NR];
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            const float r = rcp1(d[j]);
+            nl[j] = ld[j] * r; nu[j] = ud[j] * r; nB[j] = B[j] * r;
+        }
+        float l_m[NR], u_m[NR], B_m[NR], l_p[NR], u_p[NR], B_p[NR];
+        if constexpr (RF / NR <= 1) {              // lane shift 0 or 1: in-lane moves / DPP rotates
+            nbrB_dn<float, NR, RF>(nl, l_m, lane);
+            nbrB_dn<float, NR, RF>(nu, u_m, lane);
+            nbrB_dn<float, NR, RF>(nB, B_m, lane);
+            nbrB_up<float, NR, RF>(nl, l_p, lane);
+            nbrB_up<float, NR, RF>(nu, u_p, lane);
+            nbrB_up<float, NR, RF>(nB, B_p, lane);
+        } else {                                   // larger shifts staged through LDS
+            xstore<NR, L>(xch, 0, lane, nl);
+            xstore<NR, L>(xch, 1, lane, nu);
+            xstore<NR, L>(xch, 2, lane, nB);
+            const int dn = (NR * lane - RF) & (L - 1), up = (NR * lane + RF) & (L - 1);
+            xload<NR, L>(xch, 0, dn, l_m);
+            xload<NR, L>(xch, 1, dn, u_m);
+            xload<NR, L>(xch, 2, dn, B_m);
+            xload<NR, L>(xch, 0, up, l_p);
+            xload<NR, L>(xch, 1, up, u_p);
+            xload<NR, L>(xch, 2, up, B_p);
+        }
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            d[j] = d[j] - ld[j] * u_m[j] - ud[j] * l_p[j];
+            B[j] = B[j] - ld[j] * B_m[j] - ud[j] * B_p[j];
+            ld[j] = -ld[j] * l_m[j];
+            ud[j] = -ud[j] * u_p[j];
+        }
+        pcr_levels<NR, L, RF * 2>(ld, d, ud, B, lane, xch);
+    }
+}
+
+template <int NR, int L>
+__device__ __forceinline__ void pcr_solve(float (&ld)[NR], float (&d)[NR], float (&ud)[NR], float (&B)[NR],
+                                          float (&x)[NR], int lane, float *xch)
+{
+    pcr_levels<NR, L, 1>(ld, d, ud, B, lane, xch);
+    const bool low = lane < 32;                    // final 2x2 solves by Cramer's rule (see pcr_solve_L)
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        const float c_own = low ? +ud[j] : +ld[j];
+        const float d_oth = partner32(d[j]), B_oth = partner32(B[j]), c_oth = partner32(c_own);
+        const float det = d[j] * d_oth - c_own * c_oth;
+        x[j] = (B[j] * d_oth - c_own * B_oth) * rcp1(det);
+    }
+}
+
+template <bool IS_N, int NR, int L>
+__device__ __forceinline__ void assemble(const MatParF &m, float a0, const float (&Nk)[NR], const float (&Pk)[NR],
+                                         const float (&Ek)[NR], const float (&Ep)[NR], const float (&bU)[NR],
+                                         float (&lo)[NR], float (&dg)[NR], float (&up)[NR], float (&bb)[NR], int lane)
+{
+    const float D = IS_N ? m.DN : m.DP, Co = IS_N ? m.CN : m.CP, Cx = IS_N ? m.CP : m.CN;
+    const float tauV = IS_N ? m.tauP : m.tauN;
+    const float hD = IS_N ? 0.5f * D : -0.5f * D;
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        const int i = NR * lane + j;
+        const bool first = i == 0, last = i == L - 1;
+        const float U = IS_N ? Nk[j] : Pk[j], V = IS_N ? Pk[j] : Nk[j];
+        const float u_i = last ? 0.0f : __builtin_fmaf(-hD, Ep[j], -D);
+        const float l_i = first ? 0.0f : __builtin_fmaf(hD, Ek[j], -D);
+        const float u_m = first ? 0.0f : __builtin_fmaf(-hD, Ek[j], -D);
+        const float l_p = last ? 0.0f : __builtin_fmaf(hD, Ep[j], -D);
+        const float tp = Nk[j] * m.tauP + Pk[j] * m.tauN;
+        const float np_ = Nk[j] * Pk[j] - m.n0p0;
+        const float inv = rcp1(tp);
+        const float ds = -m.rate * V - (V * tp - tauV * np_) * (inv * inv) - (Co * Nk[j] * Pk[j] + Cx * (V * V) + Co * np_);
+        up[j] = u_i; lo[j] = l_i;
+        dg[j] = a0 - u_m - l_p - ds;
+        bb[j] = -(m.CN * Nk[j] + m.CP * Pk[j] + m.rate + inv) * np_ - ds * U - bU[j];
+    }
+    const bool hiHalf = lane >= 32;                // one evaluation serves both surfaces
+    const float Ns = hiHalf ? +Nk[NR - 1] : +Nk[0], Ps = hiHalf ? +Pk[NR - 1] : +Pk[0];
+    const float sr = hiHalf ? +m.srL : +m.sr0;
+    const float Vs = IS_N ? Ps : Ns, Us = IS_N ? Ns : Ps;
+    const float inv = rcp1(Ns + Ps);
+    const float dss = -sr * (Vs * Vs + m.n0p0) * (inv * inv);
+    const float fs = sr * (Ns * Ps - m.n0p0) * inv + dss * Us;
+    if (lane == 0) { dg[0] -= dss; bb[0] -= fs; }
+    if (lane == 63) { dg[NR - 1] -= dss; bb[NR - 1] -= fs; }
+}
+
+// sum|A c - b| < TOL * sum|b| with the node sums in fp64
+template <int NR>
+__device__ __forceinline__ bool residual_below(const float (&l)[NR], const float (&dg)[NR], const float (&u)[NR],
+                                               const float (&b)[NR], const float (&c)[NR], double TOL, int lane)
+{
+    float cm[NR], cp[NR];
+    nbrB_dn<float, NR, 1>(c, cm, lane);
+    nbrB_up<float, NR, 1>(c, cp, lane);
+    double q = 0.0;
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        // the row residual cancels terms ~D dt/dx^2 times larger than itself: accumulate it in fp64
+        // (the products of two floats are exact in a double), or its fp32 rounding noise would sit
+        // above the tolerance on fine grids
+        const double r = (double)l[j] * (double)cm[j] + (double)dg[j] * (double)c[j] + (double)u[j] * (double)cp[j]
+                       - (double)b[j];
+        q += fabs(r) - TOL * (double)fabsf(b[j]);
+    }
+    return wave_sum(q) < 0.0;
+}
+
+template <int NR>
+__device__ __forceinline__ void update_field(const MatParF &m, float a0, const float (&Nk)[NR], const float (&Pk)[NR],
+                                             const float (&bE)[NR], float (&Ek)[NR], int lane)
+{
+    float Nm[NR], Pm[NR];
+    nbrB_dn<float, NR, 1>(Nk, Nm, lane);
+    nbrB_dn<float, NR, 1>(Pk, Pm, lane);
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        const float A = (0.5f * m.Lambda) * (m.DP * (Pk[j] + Pm[j]) + m.DN * (Nk[j] + Nm[j])) + a0;
+        const float b = m.Lambda * (m.DP * (Pk[j] - Pm[j]) - m.DN * (Nk[j] - Nm[j])) - bE[j];
+        Ek[j] = (NR * lane + j) >= 1 ? b * rcp1(A) : Ek[j];
+    }
+}
+
+template <int L>
+__global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
+{
+    constexpr int NR = L / 64;
+    constexpr int HSLOT = 2 * NR * 64;
+    __shared__ __attribute__((aligned(16))) float lds[4 * HSLOT + 3 * L];
+    float *hist = lds, *xch = lds + 4 * HSLOT;
+    const int lane = threadIdx.x;
+    const int64_t sys = blockIdx.x;
+    const int c = (int)(sys % a.C);
+    const int64_t s = sys / a.C;
+    const CurveConst &cc = a.curve[c];
+    const int64_t orow = (int64_t)c * a.S + s;
+
+    const double *xs = a.X + s * a.xld;            // scaled in fp64 like the reference, then rounded once
+    const double N0d = xs[0] * cc.scales[0], P0d = xs[1] * cc.scales[1], rated = xs[4] * cc.scales[4];
+    MatParF mp;
+    mp.N0 = (float)N0d; mp.P0 = (float)P0d; mp.DN = (float)(xs[2] * cc.scales[2]); mp.DP = (float)(xs[3] * cc.scales[3]);
+    mp.rate = (float)rated; mp.sr0 = (float)(xs[5] * cc.scales[5]); mp.srL = (float)(xs[6] * cc.scales[6]);
+    mp.CN = (float)(xs[7] * cc.scales[7]); mp.CP = (float)(xs[8] * cc.scales[8]);
+    mp.tauN = (float)(xs[9] * cc.scales[9]); mp.tauP = (float)(xs[10] * cc.scales[10]);
+    mp.Lambda = (float)(xs[11] * cc.scales[11]); mp.n0p0 = (float)(N0d * P0d);
+    const double n0p0d = N0d * P0d;
+    const double mag = a.xld > 12 ? xs[12] : 0.0;
+    const double TOL = a.TOL;
+    const int MAX = a.MAX;
+
+    float Nk[NR], Pk[NR], Ek[NR], hE[4][NR];
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        const double dn = a.dN[(int64_t)c * L + NR * lane + j] * cc.dx3;
+        Nk[j] = (float)(N0d + dn);
+        Pk[j] = (float)(P0d + dn);
+        Ek[j] = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            hE[m][j] = 0.0f;
+            hist[m * HSLOT + (0 * NR + j) * 64 + lane] = 0.0f;
+            hist[m * HSLOT + (1 * NR + j) * 64 + lane] = 0.0f;
+        }
+    }
+
+    const bool want_pl = a.pl != nullptr, want_ll = a.sse != nullptr;
+    const int64_t ncol_ll = want_ll ? cc.n_obs : 0;
+    const double *obs = want_ll ? a.obs + (int64_t)c * a.obs_ld : nullptr;
+    const bool interp = want_ll && a.obs_hi != nullptr;
+    const int32_t *obs_hi = interp ? a.obs_hi + (int64_t)c * a.obs_ld : nullptr;
+    const double *obs_dx = interp ? a.obs_dx + (int64_t)c * a.obs_ld : nullptr;
+    const double *obs_h = interp ? a.obs_h + (int64_t)c * a.obs_ld : nullptr;
+    const int64_t t_last = want_pl ? a.T : (interp ? (int64_t)obs_hi[ncol_ll - 1] : (ncol_ll - 1) * a.plT);
+    int64_t next_obs = 0;
+    double lg_prev = 0.0, sse = 0.0, pl0_d = 1.0;
+    float pl0_f = 1.0f;
+    int status = 0;
+    int64_t itot = 0;
+
+    for (int64_t t = 0; t <= t_last; t++) {
+        float a0, a1, a2, a3, a4, a5;              // BDF table, pvSimPCR.py:241-250
+        if (t == 0)      { a0 = 1.0f; a1 = -1.0f; a2 = 0.0f; a3 = 0.0f; a4 = 0.0f; a5 = 0.0f; }
+        else if (t == 1) { a0 = 1.5f; a1 = -2.0f; a2 = 0.5f; a3 = 0.0f; a4 = 0.0f; a5 = 0.0f; }
+        else if (t == 2) { a0 = (float)(11.0 / 6); a1 = -3.0f; a2 = 1.5f; a3 = (float)(-1.0 / 3); a4 = 0.0f; a5 = 0.0f; }
+        else if (t == 3) { a0 = (float)(25.0 / 12); a1 = -4.0f; a2 = 3.0f; a3 = (float)(-4.0 / 3); a4 = 0.25f; a5 = 0.0f; }
+        else             { a0 = (float)(137.0 / 60); a1 = -5.0f; a2 = 5.0f; a3 = (float)(-10.0 / 3); a4 = 1.25f; a5 = -0.2f; }
+
+        double plv = 0.0;
+        const bool pl_step = (t % a.plT) == 0;
+        if (pl_step) {                             // midpoint PL in fp64 (pvSimPCR.py:276-281)
+            double q = 0.0;
+#pragma unroll
+            for (int j = 0; j < NR; j++) q += (double)Nk[j] * (double)Pk[j];
+            plv = rated * (wave_sum(q) - (double)L * n0p0d);
+        }
+
+        float bN[NR], bP[NR], bE[NR], cE[NR];
+        {
+            const int s1 = (int)((t + 3) & 3) * HSLOT, s2 = (int)((t + 2) & 3) * HSLOT,
+                      s3 = (int)((t + 1) & 3) * HSLOT, s4 = (int)(t & 3) * HSLOT;
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                const int oN = (0 * NR + j) * 64 + lane, oP = (1 * NR + j) * 64 + lane;
+                cE[j] = Ek[j];
+                bN[j] = a1 * Nk[j] + a2 * hist[s1 + oN] + a3 * hist[s2 + oN] + a4 * hist[s3 + oN] + a5 * hist[s4 + oN];
+                bP[j] = a1 * Pk[j] + a2 * hist[s1 + oP] + a3 * hist[s2 + oP] + a4 * hist[s3 + oP] + a5 * hist[s4 + oP];
+                bE[j] = a1 * Ek[j] + a2 * hE[0][j] + a3 * hE[1][j] + a4 * hE[2][j] + a5 * hE[3][j];
+                hist[s4 + oN] = Nk[j];
+                hist[s4 + oP] = Pk[j];
+            }
+        }
+        int it = MAX;
+        for (int iters = 0; iters < MAX; iters++) {
+            float lo_[NR], dg[NR], up[NR], bb[NR], Ep[NR];
+            nbrB_up<float, NR, 1>(Ek, Ep, lane);
+            assemble<true, NR, L>(mp, a0, Nk, Pk, Ek, Ep, bN, lo_, dg, up, bb, lane);
+            const bool okN = residual_below<NR>(lo_, dg, up, bb, Nk, TOL, lane);
+            pcr_solve<NR, L>(lo_, dg, up, bb, Nk, lane, xch);
+            assemble<false, NR, L>(mp, a0, Nk, Pk, Ek, Ep, bP, lo_, dg, up, bb, lane);
+            const bool okP = residual_below<NR>(lo_, dg, up, bb, Pk, TOL, lane);
+            pcr_solve<NR, L>(lo_, dg, up, bb, Pk, lane, xch);
+            update_field<NR>(mp, a0, Nk, Pk, bE, Ek, lane);
+            if (okN && okP) { it = iters + 1; break; }
+        }
+        itot += it;
+        if (it >= MAX) { status = 1 + (int)t; break; }
+
+        if (pl_step) {
+            const int64_t col = t / a.plT;
+            if (want_pl && lane == 0) {
+                if (a.pl_bytes == 4) ((float *)a.pl)[orow * a.pl_ld + col] = (float)plv / (float)cc.plnorm;
+                else                 ((double *)a.pl)[orow * a.pl_ld + col] = plv / cc.plnorm;
+            }
+            if (interp || col < ncol_ll) {
+                double lg;
+                if (a.flags & kFlagPlF32) {
+                    float f = (float)plv / (float)cc.plnorm;
+                    if (a.flags & kFlagNormalize) { if (col == 0) pl0_f = f; f = f / pl0_f; }
+                    if ((double)f < DBL_MIN) f = (float)DBL_MIN;
+                    lg = (double)(float)log10((double)f);
+                } else {
+                    double v = plv / cc.plnorm;
+                    if (a.flags & kFlagNormalize) { if (col == 0) pl0_d = v; v = v / pl0_d; }
+                    if (v < DBL_MIN) v = DBL_MIN;
+                    lg = log10(v);
+                }
+                if (!interp) {
+                    double err = lg + mag;
+                    err -= obs[col];
+                    sse += err * err;
+                } else {
+                    while (next_obs < ncol_ll && obs_hi[next_obs] == (int32_t)col) {
+                        const double dy = (a.flags & kFlagPlF32) ? (double)((float)lg - (float)lg_prev) : lg - lg_prev;
+                        double err = (dy / obs_h[next_obs]) * obs_dx[next_obs] + lg_prev + mag;
+                        err -= obs[next_obs];
+                        sse += err * err;
+                        next_obs++;
+                    }
+                    lg_prev = lg;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+#pragma unroll
+            for (int m = 3; m >= 1; m--) hE[m][j] = hE[m - 1][j];
+            hE[0][j] = cE[j];
+        }
+    }
+
+    if (lane == 0) {
+        if (status && want_pl) {
+            for (int64_t tt = status - 1; tt <= a.T; tt++)
+                if (tt % a.plT == 0) {
+                    const int64_t col = tt / a.plT;
+                    if (a.pl_bytes == 4) ((float *)a.pl)[orow * a.pl_ld + col] = __builtin_nanf("");
+                    else                 ((double *)a.pl)[orow * a.pl_ld + col] = __builtin_nan("");
+                }
+        }
+        if (want_ll) a.sse[orow] = status ? __builtin_inf() : sse;
+        if (a.status) a.status[orow] = status;
+        if (a.iters_total) a.iters_total[orow] = itot;
+    }
+}
+
+}  // namespace f32
+
+inline hipError_t launch_stepper_f32_impl(const StepArgs &a, hipStream_t stream)
+{
+    const int64_t nsys = a.S * a.C;
+    if (nsys <= 0) return hipSuccess;
+    dim3 grid((unsigned)nsys), block(64);
+    switch (a.L) {
+    case 128: hipLaunchKernelGGL((f32::stepper_kernel<128>), grid, block, 0, stream, a); break;
+    case 256: hipLaunchKernelGGL((f32::stepper_kernel<256>), grid, block, 0, stream, a); break;
+    case 512: hipLaunchKernelGGL((f32::stepper_kernel<512>), grid, block, 0, stream, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace trpl

@@ -59,6 +59,13 @@ int check_grid(int32_t L, int64_t T, int32_t plT, int32_t max_iter, double time_
 
 int launch(const trpl::StepArgs &a, uint32_t flags, hipStream_t st)
 {
+    if (flags & TRPL_FLAG_FP32) {
+        if (flags & TRPL_FLAG_STRICT) return fail(TRPL_ERR_ARG, "TRPL_FLAG_FP32 and TRPL_FLAG_STRICT exclude each other");
+        if (a.L < 128) return fail(TRPL_ERR_UNSUPPORTED, "the fp32 stepper is built for L >= 128 (got %d)", a.L);
+        hipError_t e32 = trpl::launch_stepper_f32(a, st);
+        if (e32 != hipSuccess) return fail(TRPL_ERR_HIP, "fp32 stepper launch: %s", hipGetErrorString(e32));
+        return TRPL_OK;
+    }
     hipError_t e = (flags & TRPL_FLAG_STRICT) ? trpl::launch_stepper_strict(a, st) : trpl::launch_stepper_fast(a, st);
     if (e != hipSuccess) return fail(TRPL_ERR_HIP, "stepper launch: %s", hipGetErrorString(e));
     return TRPL_OK;

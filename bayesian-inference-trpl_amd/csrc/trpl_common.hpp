@@ -46,6 +46,7 @@ struct StepArgs {
 // Launchers (one translation unit per arithmetic mode, see stepper_strict.hip / stepper_fast.hip).
 hipError_t launch_stepper_strict(const StepArgs &a, hipStream_t stream);
 hipError_t launch_stepper_fast(const StepArgs &a, hipStream_t stream);
+hipError_t launch_stepper_f32(const StepArgs &a, hipStream_t stream);   // stepper_f32.hip, L >= 128
 
 // likelihood.hip
 hipError_t launch_log10_clamp(void *x, int elem_bytes, int64_t rows, int64_t cols, int64_t ld, double mn,

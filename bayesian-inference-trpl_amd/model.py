@@ -11,7 +11,7 @@ def _as_f64(a):
 
 
 def solve_pl(matPar, Length, Time, L, T, dN, plT=1, tol=7, MAX=10000, out=None, dtype=np.float64,
-             strict=False, device=0):
+             strict=False, device=0, fp32=False):
     """PL(t) for S systems of one curve.  matPar (S,12) and dN (L,) in nm/ns units.
     Returns (plI, status, iters_total, seconds)."""
     matPar = _as_f64(matPar)
@@ -30,7 +30,7 @@ def solve_pl(matPar, Length, Time, L, T, dN, plT=1, tol=7, MAX=10000, out=None, 
     status = np.zeros(S, dtype=np.int32)
     iters = np.zeros(S, dtype=np.int64)
     sec = _abi.C.c_double(0.0)
-    flags = _abi.FLAG_STRICT if strict else 0
+    flags = (_abi.FLAG_STRICT if strict else 0) | (_abi.FLAG_FP32 if fp32 else 0)
     _abi.check(_abi.lib().trpl_solve_pl(_abi.ptr(matPar), S, float(Length), float(Time), int(L), int(T), int(plT),
                                         int(tol), int(MAX), _abi.ptr(dN), _abi.ptr(out), out.itemsize,
                                         out.strides[0] // out.itemsize, _abi.ptr(status), _abi.ptr(iters), flags,

@@ -51,6 +51,10 @@ extern "C" {
                                      reference's float32 plI buffer does (bayeslib.py:137) */
 #define TRPL_FLAG_NORMALIZE 0x4   /* trpl_loglik*: self-normalise each PL curve to its t = 0 value
                                      (bayeslib.py:150-154) */
+#define TRPL_FLAG_FP32 0x8        /* solver state, BDF history and PCR in fp32 (node sums, PL, log10 and the
+                                     squared error stay fp64); L >= 128, not combinable with STRICT; use
+                                     tol_exp 4-5 (fp32's residual floor is ~1e-7).  No reference exists for
+                                     this mode (the reference is fp64 only) */
 
 int trpl_abi_version(void);
 const char *trpl_last_error(void);

@@ -157,6 +157,36 @@ def test_pvsim_fine_grids_vs_oracle(gpu, oracle, L):
     assert np.all(np.abs(it - r["iters_total"]) <= 0.01 * r["iters_total"] + 1)
 
 
+@pytest.mark.parametrize("L,tol,pl_gate,ll_gate", [(128, 4, 2e-4, 1e-3), (512, 3, 2e-3, 1e-2)])
+def test_fp32_stepper_vs_fp64_oracle(gpu, oracle, L, tol, pl_gate, ll_gate):
+    """TRPL_FLAG_FP32 (BASELINE configs[4]: L = 512, fp32).  No reference exists for fp32 (the
+    reference is fp64 only and cannot run L = 512); the bar is the fp64 oracle at the accuracy an fp32
+    state allows.  Measured (tools/fp32_probe.py): L = 128, tol 4-5: 2-3e-5 relative PL error
+    (SURVEY App. B result 5 found <= 3.3e-5 dex on the emulated reference); L = 512: the diffusion
+    stencil amplifies fp32 rounding by D dt/dx^2 ~ 200, tol 3 converges everywhere with <= 1e-3
+    relative (4e-4 dex) PL error, tol >= 4 no longer converges for the high-mobility samples."""
+    w = gpu.workloads
+    X = w.samples(6)
+    T, Time, length = 60, 60 * 0.025, 2000.0
+    ini = np.stack([w.beer_lambert(A, length, L) for A in w.POWER_SCAN_A_CM3])
+    ref = [oracle.pvsim(X[:, :-1], length, Time, L, T, ini[c], nthreads=4) for c in range(3)]
+    for c in range(3):
+        pl, st, it, _ = gpu.solve_pl(X[:, :-1], length, Time, L, T, ini[c], tol=tol, fp32=True)
+        assert not st.any()
+        assert relerr(pl, ref[c]["plI"]) < pl_gate
+        assert np.all(it <= ref[c]["iters_total"])            # looser tolerance: never more iterations than tol 7
+    obs = [np.log10(r["plI"][-1]) + 0.03 for r in ref]
+    want = oracle.simulate_loglik(X, ini, length, Time, L, T, [([np.linspace(0, Time, T + 1)] * 3, obs)],
+                                  pl_dtype=np.float64, nthreads=4)[0]
+    info = {}
+    P = gpu.loglik(X, ini, length, Time, L, T, obs, tol=tol, fp32=True, info=info)
+    assert not info["status"].any() and np.max(np.abs(P - want) / np.abs(want)) < ll_gate
+    with pytest.raises(gpu.TrplError):
+        gpu.solve_pl(X[:, :-1], length, Time, 64, T, w.beer_lambert(1e17, length, 64), fp32=True)   # L < 128
+    with pytest.raises(gpu.TrplError):
+        gpu.solve_pl(X[:, :-1], length, Time, L, T, ini[0], fp32=True, strict=True)
+
+
 # ----------------------------------------------------------------------------- probs
 def test_fastlog_and_prob_vs_reference_golden(gpu, golden):
     g = golden("probs")
@@ -323,7 +353,7 @@ def test_full_size_properties(gpu):
     P(m) = P(0) - sum_c [ n_c m^2 + 2 m r_c ] holds through the fused kernel."""
     w = gpu.workloads
     ini, lens = w.power_scan(128)
-    S, T, Time = 4096, 64, 64 * 0.025
+    S, T, Time = 65536, 24, 24 * 0.025            # BASELINE configs[1] sample count
     X = w.samples(S)
     mark = (w.MARKED_POINT * gpu.UNIT_CONVERSIONS)[None, :]
     obs = []
@@ -339,8 +369,8 @@ def test_full_size_properties(gpu):
     assert abs(info_f["iters_total"].sum() / info_s["iters_total"].sum() - 1) < 1e-3
     Pf2 = gpu.loglik(X, ini, lens, Time, 128, T, obs)
     assert np.array_equal(Pf, Pf2)                                            # (iii)
-    sub = gpu.loglik(X[1000:1300], ini, lens, Time, 128, T, obs)
-    assert np.array_equal(sub, Pf[1000:1300])                                 # (ii)
+    sub = gpu.loglik(X[61000:61300], ini, lens, Time, 128, T, obs)
+    assert np.array_equal(sub, Pf[61000:61300])                               # (ii)
     m = 0.25
     Xm = X.copy(); Xm[:, -1] = m
     Pm = gpu.loglik(Xm, ini, lens, Time, 128, T, obs)
