@@ -397,7 +397,7 @@ __device__ __forceinline__ void static_for(F &&f)
 __device__ __forceinline__ double rcp_nr1(double d)      // one Newton step: 2e-15 relative (measured)
 {
     if constexpr ((TRPL_ABLATE & 2) != 0) return d * 0.999;
-    const double r = __builtin_amdgcn_rcp(d);
+    const double r = __builtin_amdgcn_rcp(d);     // (a cvt + v_rcp_f32 + cvt seed measured 4 % slower)
     return __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
 }
 __device__ __forceinline__ float rcp_nr1(float d) { return 1.0f / d; }

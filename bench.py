@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--samples-per-gpu", type=int, default=65536)
     ap.add_argument("--workload", default="power_scan", choices=["power_scan", "twothick"])
     ap.add_argument("--strict", action="store_true", help="bit-reproducible arithmetic mode")
+    ap.add_argument("--L", type=int, default=128, help="spatial nodes (configs[4]: 512)")
+    ap.add_argument("--fp32", action="store_true", help="fp32 solver state (configs[4]); implies --tol 3 at L=512, 4 otherwise")
+    ap.add_argument("--tol", type=int, default=None, help="convergence exponent (default 7, the reference's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcr", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -71,9 +74,9 @@ def main():
     # initialises the GPU.  Rank 0 at N = 1 only; bounded samples of the same workload.
     cpu_legs = {}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        ini_c, lens_c = wl.power_scan(128) if args.workload == "power_scan" else wl.twothick(128)
-        cpu_legs["cpu_baseline"] = cpu_baseline(wl, trpl_amd, ini_c, lens_c, args.T * 0.025, 128, args.T, args.cpu_seconds)
-        cpu_legs["cpu_baseline_scipy"] = cpu_baseline_scipy(wl, ini_c, lens_c, args.T * 0.025, 128, args.T)
+        ini_c, lens_c = wl.power_scan(args.L) if args.workload == "power_scan" else wl.twothick(args.L)
+        cpu_legs["cpu_baseline"] = cpu_baseline(wl, trpl_amd, ini_c, lens_c, args.T * 0.025, args.L, args.T, args.cpu_seconds)
+        cpu_legs["cpu_baseline_scipy"] = cpu_baseline_scipy(wl, ini_c, lens_c, args.T * 0.025, args.L, args.T)
 
     import torch
     import torch.distributed as dist
@@ -95,7 +98,8 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    L, T, dt_ns = 128, args.T, 0.025
+    L, T, dt_ns = args.L, args.T, 0.025
+    tol = args.tol if args.tol is not None else ((3 if L >= 512 else 4) if args.fp32 else 7)
     Time = T * dt_ns
     ini, lens = wl.power_scan(L) if args.workload == "power_scan" else wl.twothick(L)
     C = len(lens)
@@ -103,7 +107,7 @@ def main():
     lo, hi = trpl_amd.dist.shard_bounds(S_total, world, rank)
     S = hi - lo
     X_host = wl.samples(S_total)[lo:hi]                      # same seeded draw on every rank, own shard
-    flags = trpl_amd.FLAG_STRICT if args.strict else 0
+    flags = (trpl_amd.FLAG_STRICT if args.strict else 0) | (trpl_amd.FLAG_FP32 if args.fp32 else 0)
 
     # ---- inputs resident in HBM before anything is timed ----
     X = torch.from_numpy(np.ascontiguousarray(X_host)).to(dev)
@@ -112,7 +116,7 @@ def main():
     obs = torch.empty((C, T + 1), dtype=torch.float64, device=dev)
     for c in range(C):                                       # synthetic observations: the solver itself at the marked point
         pl = torch.empty((1, T + 1), dtype=torch.float64, device=dev)
-        tdev.solve_pl_device(mark, lens[c], Time, L, T, ini_d[c].contiguous(), pl, flags=trpl_amd.FLAG_STRICT)
+        tdev.solve_pl_device(mark, lens[c], Time, L, T, ini_d[c].contiguous(), pl, flags=trpl_amd.FLAG_STRICT, tol=7)
         obs[c] = torch.log10(pl[0])
     P = torch.zeros(S, dtype=torch.float64, device=dev)
     sse = torch.empty((C, S), dtype=torch.float64, device=dev)
@@ -127,7 +131,7 @@ def main():
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        tdev.loglik_device(X, ini_d, lens, Time, L, T, obs, n_obs, P, sse, status, iters, flags=flags)
+        tdev.loglik_device(X, ini_d, lens, Time, L, T, obs, n_obs, P, sse, status, iters, flags=flags, tol=tol)
         if record:
             e1.record()
             ev.append((e0, e1))
@@ -172,7 +176,7 @@ def main():
     achieved_tf = flop_launch / (kern_ms * 1e-3) / 1e12
 
     out = {
-        "metric": "TRPL system-timesteps/s at 128 nodes (fused solve + log-likelihood)",
+        "metric": "TRPL system-timesteps/s at %d nodes (fused solve + log-likelihood)" % L,
         "value": value,
         "unit": "system-timesteps/s",
         "n_gpus": world,
@@ -182,11 +186,12 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f64",
+        "dtype": "f32 state, f64 reductions" if args.fp32 else "f64",
         "data": "synthetic",
-        "config": {"workload": "%s x %d samples/GPU (%d total), %d curves, L=128 nodes, T=%d steps of dt=0.025 ns, "
-                               "tol=1e-7, MAX=10000, fp64, arithmetic=%s"
-                               % (args.workload, args.samples_per_gpu, S_total, C, T, "strict" if args.strict else "fast"),
+        "config": {"workload": "%s x %d samples/GPU (%d total), %d curves, L=%d nodes, T=%d steps of dt=0.025 ns, "
+                               "tol=1e-%d, MAX=10000, %s, arithmetic=%s"
+                               % (args.workload, args.samples_per_gpu, S_total, C, L, T, tol,
+                                  "fp32 state" if args.fp32 else "fp64", "strict" if args.strict else "fast"),
                    "samples_total": S_total, "curves": C, "L": L, "T": T, "parallelism": "sample-shard x%d" % world,
                    "collective": "none" if world == 1 else ("RCCL all_gather" if args.backend == "nccl" else "gloo all_gather (rehearsal)")},
         "likelihoods_per_s_at_T": S_total * args.steps / elapsed,
@@ -194,9 +199,10 @@ def main():
         "inner_iterations_per_s": it_all * args.steps / elapsed,
         "mean_inner_iterations_per_step": it_all / sys_steps,
         "nonconverged_systems": fail_all,
-        "roofline": {"kernel": "stepper_kernel<128> (fused time-stepper + likelihood)", "bound": "valu-fp64",
-                     "achieved": achieved_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved_tf / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+        "roofline": {"kernel": "%sstepper_kernel<%d> (fused time-stepper + likelihood)" % ("f32::" if args.fp32 else "", L),
+                     "bound": "valu-fp32" if args.fp32 else "valu-fp64",
+                     "achieved": achieved_tf, "peak": FP64_VECTOR_PEAK_TFLOPS * (2 if args.fp32 else 1), "unit": "TFLOP/s",
+                     "frac": achieved_tf / (FP64_VECTOR_PEAK_TFLOPS * (2 if args.fp32 else 1)), "traffic": None,
                      "flop_per_launch": flop_launch, "avg_launch_ms": kern_ms,
                      "note": "268*L flop per inner iteration x device-counted iterations; HBM traffic of this "
                              "kernel is ~0.1 KB per system by construction (see profiles/)"},
@@ -227,6 +233,8 @@ def attach_traffic(out):
         return
     t = json.load(open(files[-1]))
     src = os.path.basename(files[-1])
+    if "stepper_kernel<128>" not in out["roofline"]["kernel"] or "f32" in out["roofline"]["kernel"]:
+        return                                               # the committed PMC profile is of the fp64 L=128 kernels
     for key, obj in (("void trpl::stepper_kernel<128, false>", "roofline"),
                      ("void trpl::pcr_batched_kernel<double, 128, false>", "roofline_hbm_pcr")):
         if key in t and obj in out:
