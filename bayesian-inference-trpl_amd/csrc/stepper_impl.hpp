@@ -402,6 +402,25 @@ __device__ __forceinline__ double rcp_nr1(double d)      // one Newton step: 2e-
 }
 __device__ __forceinline__ float rcp_nr1(float d) { return 1.0f / d; }
 
+// Reciprocals of all NR values of a lane.  v_rcp_f64 costs ~3.5 fp64 multiplies, so values are
+// paired: r = 1/(a*b), 1/a = b*r, 1/b = a*r (one reciprocal + 3 multiplies instead of two
+// reciprocals).  The operands here are O(1e-4 .. 1e4), far from over/underflow of the product.
+template <int NR>
+__device__ __forceinline__ void rcp_rows(const double (&d)[NR], double (&r)[NR])
+{
+    if constexpr (NR % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < NR; j += 2) {
+            const double rp = rcp_nr1(d[j] * d[j + 1]);
+            r[j] = d[j + 1] * rp;
+            r[j + 1] = d[j] * rp;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NR; j++) r[j] = rcp_nr1(d[j]);
+    }
+}
+
 template <int K, typename T>
 __device__ __forceinline__ T lane_up(T v, int lane)       // value held by lane + K (mod 64)
 {
@@ -509,12 +528,10 @@ __device__ __forceinline__ void pcr_levels_L(double (&ld)[NR], double (&d)[NR], 
                                              int lane, double *xch)
 {
     if constexpr (L > 2 * RF) {
-        double nl[NR], nu[NR], nB[NR];
+        double nl[NR], nu[NR], nB[NR], rd[NR];
+        rcp_rows<NR>(d, rd);
 #pragma unroll
-        for (int j = 0; j < NR; j++) {
-            const double r = rcp_nr1(d[j]);
-            nl[j] = ld[j] * r; nu[j] = ud[j] * r; nB[j] = B[j] * r;
-        }
+        for (int j = 0; j < NR; j++) { nl[j] = ld[j] * rd[j]; nu[j] = ud[j] * rd[j]; nB[j] = B[j] * rd[j]; }
         double l_m[NR], u_m[NR], B_m[NR], l_p[NR], u_p[NR], B_p[NR];
         if constexpr (RF / NR <= 1) {              // lane shift 0 or 1: in-lane moves / DPP rotates (VALU only)
             nbrB_dn<double, NR, RF>(nl, l_m, lane);
@@ -562,6 +579,7 @@ __device__ __forceinline__ void pcr_solve_L(double (&ld)[NR], double (&d)[NR], d
     //     [ ld_hi d_hi  ] [x_hi] = [B_hi]        c = coupling to the partner row (ud for the lower, ld for the upper)
     // v_permlane32_swap delivers the partner's values on the VALU (the LDS is the scarcer resource).
     const bool low = lane < 32;
+    double det[NR], num[NR], rdet[NR];
 #pragma unroll
     for (int j = 0; j < NR; j++) {
         const double c_own = low ? +ud[j] : +ld[j];
@@ -574,9 +592,12 @@ __device__ __forceinline__ void pcr_solve_L(double (&ld)[NR], double (&d)[NR], d
             pair32(B[j], lo_h, hi_h);  B_oth = low ? hi_h : lo_h;
             pair32(c_own, lo_h, hi_h); c_oth = low ? hi_h : lo_h;
         }
-        const double det = d[j] * d_oth - c_own * c_oth;
-        x[j] = (B[j] * d_oth - c_own * B_oth) * rcp_nr1(det);
+        det[j] = d[j] * d_oth - c_own * c_oth;
+        num[j] = B[j] * d_oth - c_own * B_oth;
     }
+    rcp_rows<NR>(det, rdet);
+#pragma unroll
+    for (int j = 0; j < NR; j++) x[j] = num[j] * rdet[j];
 }
 
 // ---- layout dispatch: LAY 0 = blocked/strict, 1 = blocked/fast (L < 128), 2 = interleaved/fast ----
@@ -669,6 +690,13 @@ __device__ __forceinline__ void assemble(const MatPar &m, double a0, const doubl
     const double Cx = IS_N ? m.CP : m.CN;
     const double tauV = IS_N ? m.tauP : m.tauN;
     constexpr bool STRICT = LAY == 0;
+    double inv_tp[NR];
+    if constexpr (LAY == 2) {
+        double tpv[NR];
+#pragma unroll
+        for (int j = 0; j < NR; j++) tpv[j] = Nk[j] * m.tauP + Pk[j] * m.tauN;
+        rcp_rows<NR>(tpv, inv_tp);
+    }
 #pragma unroll
     for (int j = 0; j < NR; j++) {
         const int i = node_of<LAY, NR, W>(ln, j);
@@ -696,7 +724,7 @@ __device__ __forceinline__ void assemble(const MatPar &m, double a0, const doubl
             const double l_p = last ? 0.0 : __builtin_fma(hD, Ep[j], -D);
             const double tp = Nk[j] * m.tauP + Pk[j] * m.tauN;
             const double np_ = Nk[j] * Pk[j] - m.n0p0;
-            const double inv = LAY == 2 ? rcp_nr1(tp) : rcp_nr(tp);
+            const double inv = LAY == 2 ? inv_tp[j] : rcp_nr(tp);
             const double ds = -m.rate * V - (V * tp - tauV * np_) * (inv * inv)
                             - (Co * Nk[j] * Pk[j] + Cx * (V * V) + Co * np_);
             up[j] = u_i; lo[j] = l_i;
@@ -739,6 +767,18 @@ __device__ __forceinline__ void update_field(const MatPar &m, double a0, const d
     double Nm[NR], Pm[NR];
     shift_dn1<LAY, NR, W>(Nk, Nm, ln);
     shift_dn1<LAY, NR, W>(Pk, Pm, ln);
+    if constexpr (LAY == 2) {
+        double A[NR], b[NR], rA[NR];
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            A[j] = (0.5 * m.Lambda) * (m.DP * (Pk[j] + Pm[j]) + m.DN * (Nk[j] + Nm[j])) + a0;
+            b[j] = m.Lambda * (m.DP * (Pk[j] - Pm[j]) - m.DN * (Nk[j] - Nm[j])) - bE[j];
+        }
+        rcp_rows<NR>(A, rA);
+#pragma unroll
+        for (int j = 0; j < NR; j++) Ek[j] = node_of<LAY, NR, W>(ln, j) >= 1 ? b[j] * rA[j] : Ek[j];
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NR; j++) {
         const int i = node_of<LAY, NR, W>(ln, j);
@@ -750,7 +790,7 @@ __device__ __forceinline__ void update_field(const MatPar &m, double a0, const d
         } else {
             const double A = (0.5 * m.Lambda) * (m.DP * (Pk[j] + Pm[j]) + m.DN * (Nk[j] + Nm[j])) + a0;
             const double b = m.Lambda * (m.DP * (Pk[j] - Pm[j]) - m.DN * (Nk[j] - Nm[j])) - bE[j];
-            e = b * (LAY == 2 ? rcp_nr1(A) : rcp_nr(A));
+            e = b * rcp_nr(A);
         }
         Ek[j] = i >= 1 ? e : Ek[j];
     }
