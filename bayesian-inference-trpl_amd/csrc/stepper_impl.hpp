@@ -40,6 +40,9 @@
 #ifndef TRPL_ABLATE
 #define TRPL_ABLATE 0
 #endif
+#ifndef TRPL_RCP_PAIR
+#define TRPL_RCP_PAIR 1       // pair reciprocals (rcp_rows); 0 only for A/B measurements
+#endif
 
 namespace trpl {
 
@@ -408,7 +411,7 @@ __device__ __forceinline__ float rcp_nr1(float d) { return 1.0f / d; }
 template <int NR>
 __device__ __forceinline__ void rcp_rows(const double (&d)[NR], double (&r)[NR])
 {
-    if constexpr (NR % 2 == 0) {
+    if constexpr (NR % 2 == 0 && TRPL_RCP_PAIR != 0) {
 #pragma unroll
         for (int j = 0; j < NR; j += 2) {
             const double rp = rcp_nr1(d[j] * d[j + 1]);
@@ -797,7 +800,7 @@ __device__ __forceinline__ void update_field(const MatPar &m, double a0, const d
 }
 
 template <int L, bool STRICT>
-__global__ void __launch_bounds__(64, STRICT ? 2 : TRPL_FAST_WAVES) stepper_kernel(const StepArgs a)
+__global__ void __launch_bounds__(64, (STRICT || L > 128) ? (L > 256 ? 1 : 2) : TRPL_FAST_WAVES) stepper_kernel(const StepArgs a)
 {
     constexpr int W = L < 64 ? L : 64;
     constexpr int NR = L / W;
