@@ -192,7 +192,6 @@ __global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
     const int c = (int)(sys % a.C);
     const int64_t s = sys / a.C;
     const CurveConst &cc = a.curve[c];
-    const int64_t orow = (int64_t)c * a.S + s;
 
     const double *xs = a.X + s * a.xld;            // scaled in fp64 like the reference, then rounded once
     const double N0d = xs[0] * cc.scales[0], P0d = xs[1] * cc.scales[1], rated = xs[4] * cc.scales[4];
@@ -222,21 +221,11 @@ __global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
         }
     }
 
-    const bool want_pl = a.pl != nullptr, want_ll = a.sse != nullptr;
-    const int64_t ncol_ll = want_ll ? cc.n_obs : 0;
-    const double *obs = want_ll ? a.obs + (int64_t)c * a.obs_ld : nullptr;
-    const bool interp = want_ll && a.obs_hi != nullptr;
-    const int32_t *obs_hi = interp ? a.obs_hi + (int64_t)c * a.obs_ld : nullptr;
-    const double *obs_dx = interp ? a.obs_dx + (int64_t)c * a.obs_ld : nullptr;
-    const double *obs_h = interp ? a.obs_h + (int64_t)c * a.obs_ld : nullptr;
-    const int64_t t_last = want_pl ? a.T : (interp ? (int64_t)obs_hi[ncol_ll - 1] : (ncol_ll - 1) * a.plT);
-    int64_t next_obs = 0;
-    double lg_prev = 0.0, sse = 0.0, pl0_d = 1.0;
-    float pl0_f = 1.0f;
+    PlSink sink(a, cc, c, s, mag);
     int status = 0;
     int64_t itot = 0;
 
-    for (int64_t t = 0; t <= t_last; t++) {
+    for (int64_t t = 0; t <= sink.t_last; t++) {
         float a0, a1, a2, a3, a4, a5;              // BDF table, pvSimPCR.py:241-250
         if (t == 0)      { a0 = 1.0f; a1 = -1.0f; a2 = 0.0f; a3 = 0.0f; a4 = 0.0f; a5 = 0.0f; }
         else if (t == 1) { a0 = 1.5f; a1 = -2.0f; a2 = 0.5f; a3 = 0.0f; a4 = 0.0f; a5 = 0.0f; }
@@ -284,41 +273,7 @@ __global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
         itot += it;
         if (it >= MAX) { status = 1 + (int)t; break; }
 
-        if (pl_step) {
-            const int64_t col = t / a.plT;
-            if (want_pl && lane == 0) {
-                if (a.pl_bytes == 4) ((float *)a.pl)[orow * a.pl_ld + col] = (float)plv / (float)cc.plnorm;
-                else                 ((double *)a.pl)[orow * a.pl_ld + col] = plv / cc.plnorm;
-            }
-            if (interp || col < ncol_ll) {
-                double lg;
-                if (a.flags & kFlagPlF32) {
-                    float f = (float)plv / (float)cc.plnorm;
-                    if (a.flags & kFlagNormalize) { if (col == 0) pl0_f = f; f = f / pl0_f; }
-                    if ((double)f < DBL_MIN) f = (float)DBL_MIN;
-                    lg = (double)(float)log10((double)f);
-                } else {
-                    double v = plv / cc.plnorm;
-                    if (a.flags & kFlagNormalize) { if (col == 0) pl0_d = v; v = v / pl0_d; }
-                    if (v < DBL_MIN) v = DBL_MIN;
-                    lg = log10(v);
-                }
-                if (!interp) {
-                    double err = lg + mag;
-                    err -= obs[col];
-                    sse += err * err;
-                } else {
-                    while (next_obs < ncol_ll && obs_hi[next_obs] == (int32_t)col) {
-                        const double dy = (a.flags & kFlagPlF32) ? (double)((float)lg - (float)lg_prev) : lg - lg_prev;
-                        double err = (dy / obs_h[next_obs]) * obs_dx[next_obs] + lg_prev + mag;
-                        err -= obs[next_obs];
-                        sse += err * err;
-                        next_obs++;
-                    }
-                    lg_prev = lg;
-                }
-            }
-        }
+        if (pl_step) sink.emit(t, plv);
 #pragma unroll
         for (int j = 0; j < NR; j++) {
 #pragma unroll
@@ -327,19 +282,7 @@ __global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
         }
     }
 
-    if (lane == 0) {
-        if (status && want_pl) {
-            for (int64_t tt = status - 1; tt <= a.T; tt++)
-                if (tt % a.plT == 0) {
-                    const int64_t col = tt / a.plT;
-                    if (a.pl_bytes == 4) ((float *)a.pl)[orow * a.pl_ld + col] = __builtin_nanf("");
-                    else                 ((double *)a.pl)[orow * a.pl_ld + col] = __builtin_nan("");
-                }
-        }
-        if (want_ll) a.sse[orow] = status ? __builtin_inf() : sse;
-        if (a.status) a.status[orow] = status;
-        if (a.iters_total) a.iters_total[orow] = itot;
-    }
+    sink.finish(status, itot);
 }
 
 }  // namespace f32

@@ -674,6 +674,98 @@ __device__ __forceinline__ bool residual_below(const double (&l)[NR], const doub
     }
 }
 
+
+// What a system emits: PL(t) to memory (pvSim mode, pvSimPCR.py:281,:393) and/or the running squared
+// log-error against the observations (fused likelihood: bayeslib.py:150-157,:184-191, probs.py:29-44).
+// Shared by the fp64 and fp32 steppers; every member is wave-uniform.
+struct PlSink {
+    const StepArgs &a;
+    const CurveConst &cc;
+    int64_t orow;            // output row (curve-major: c*S + s)
+    const double *obs;
+    const int32_t *obs_hi;   // off-grid observation times (trpl_loglik_obs) or nullptr
+    const double *obs_dx, *obs_h;
+    int64_t ncol_ll;         // number of observations of this curve (0 outside likelihood mode)
+    int64_t t_last;          // last step that can influence an output
+    int64_t next_obs = 0;
+    double mag, lg_prev = 0.0, sse = 0.0, pl0_d = 1.0;
+    float pl0_f = 1.0f;
+    bool want_pl, want_ll, interp;
+
+    __device__ PlSink(const StepArgs &a_, const CurveConst &cc_, int c, int64_t s, double mag_)
+        : a(a_), cc(cc_), orow((int64_t)c * a_.S + s), mag(mag_)
+    {
+        want_pl = a.pl != nullptr;
+        want_ll = a.sse != nullptr;
+        ncol_ll = want_ll ? cc.n_obs : 0;
+        obs = want_ll ? a.obs + (int64_t)c * a.obs_ld : nullptr;
+        interp = want_ll && a.obs_hi != nullptr;
+        obs_hi = interp ? a.obs_hi + (int64_t)c * a.obs_ld : nullptr;
+        obs_dx = interp ? a.obs_dx + (int64_t)c * a.obs_ld : nullptr;
+        obs_h = interp ? a.obs_h + (int64_t)c * a.obs_ld : nullptr;
+        // all T+1 steps when PL is stored (the reference runs them all), otherwise up to the last
+        // observation
+        t_last = want_pl ? a.T : (interp ? (int64_t)obs_hi[ncol_ll - 1] : (ncol_ll - 1) * a.plT);
+    }
+
+    // plv = rate * (sum N P - L n0 p0) of the state at time t, non-dimensional
+    __device__ __forceinline__ void emit(int64_t t, double plv)
+    {
+        const int64_t col = t / a.plT;
+        if (want_pl && threadIdx.x == 0) {                                             // :281,:393
+            if (a.pl_bytes == 4) ((float *)a.pl)[orow * a.pl_ld + col] = (float)plv / (float)cc.plnorm;
+            else                 ((double *)a.pl)[orow * a.pl_ld + col] = plv / cc.plnorm;
+        }
+        if (!(interp || col < ncol_ll)) return;
+        double lg;
+        if (a.flags & kFlagPlF32) {                // the reference's float32 plI buffer (bayeslib.py:137)
+            float f = (float)plv / (float)cc.plnorm;
+            if (a.flags & kFlagNormalize) { if (col == 0) pl0_f = f; f = f / pl0_f; }
+            if ((double)f < DBL_MIN) f = (float)DBL_MIN;
+            lg = (double)(float)log10((double)f);
+        } else {
+            double v = plv / cc.plnorm;
+            if (a.flags & kFlagNormalize) { if (col == 0) pl0_d = v; v = v / pl0_d; }
+            if (v < DBL_MIN) v = DBL_MIN;
+            lg = log10(v);
+        }
+        if (!interp) {
+            double err = lg + mag;
+            err -= obs[col];
+            sse += err * err;
+        } else {
+            // every observation bracketed by grid points (col-1, col): scipy interp1d's
+            // slope * (x - x_lo) + y_lo (bayeslib.py:189)
+            while (next_obs < ncol_ll && obs_hi[next_obs] == (int32_t)col) {
+                const double dy = (a.flags & kFlagPlF32) ? (double)((float)lg - (float)lg_prev) : lg - lg_prev;
+                const double y = (dy / obs_h[next_obs]) * obs_dx[next_obs] + lg_prev;
+                double err = y + mag;
+                err -= obs[next_obs];
+                sse += err * err;
+                next_obs++;
+            }
+            lg_prev = lg;
+        }
+    }
+
+    // status = 0, or 1+t of the step whose iteration hit MAX (pvSimPCR.py:269)
+    __device__ __forceinline__ void finish(int status, int64_t itot)
+    {
+        if (threadIdx.x != 0) return;
+        if (status && want_pl) {                   // undefined in the reference; NaN here
+            for (int64_t tt = status - 1; tt <= a.T; tt++)
+                if (tt % a.plT == 0) {
+                    const int64_t col = tt / a.plT;
+                    if (a.pl_bytes == 4) ((float *)a.pl)[orow * a.pl_ld + col] = __builtin_nanf("");
+                    else                 ((double *)a.pl)[orow * a.pl_ld + col] = __builtin_nan("");
+                }
+        }
+        if (want_ll) a.sse[orow] = status ? __builtin_inf() : sse;
+        if (a.status) a.status[orow] = status;
+        if (a.iters_total) a.iters_total[orow] = itot;
+    }
+};
+
 // the 12 non-dimensional material parameters of one system (wave-uniform) + N0*P0
 struct MatPar {
     double N0, P0, DN, DP, rate, sr0, srL, CN, CP, tauN, tauP, Lambda, n0p0;
@@ -810,7 +902,6 @@ __global__ void __launch_bounds__(64, (STRICT || L > 128) ? (L > 256 ? 1 : 2) : 
     const int c = (int)(sys % a.C);
     const int64_t s = sys / a.C;
     const CurveConst &cc = a.curve[c];
-    const int64_t orow = (int64_t)c * a.S + s;
 
     // ---- non-dimensional material parameters (pvSimPCR.py:327-331) ----
     const double *xs = a.X + s * a.xld;
@@ -852,27 +943,11 @@ __global__ void __launch_bounds__(64, (STRICT || L > 128) ? (L > 256 ? 1 : 2) : 
         }
     }
 
-    const bool want_pl = a.pl != nullptr;
-    const bool want_ll = a.sse != nullptr;
-    const int64_t ncol_ll = want_ll ? cc.n_obs : 0;
-    // last step that can influence an output: all T+1 of them when PL is stored (the reference
-    // runs them all), otherwise up to the last compared column
-    const double *obs = want_ll ? a.obs + (int64_t)c * a.obs_ld : nullptr;
-    // off-grid observation times (trpl_loglik_obs): bracketing data per observation, sorted by time
-    const bool interp = want_ll && a.obs_hi != nullptr;
-    const int32_t *obs_hi = interp ? a.obs_hi + (int64_t)c * a.obs_ld : nullptr;
-    const double *obs_dx = interp ? a.obs_dx + (int64_t)c * a.obs_ld : nullptr;
-    const double *obs_h = interp ? a.obs_h + (int64_t)c * a.obs_ld : nullptr;
-    const int64_t t_last = want_pl ? a.T : (interp ? (int64_t)obs_hi[ncol_ll - 1] : (ncol_ll - 1) * a.plT);
-    int64_t next_obs = 0;
-    double lg_prev = 0.0;
-    double sse = 0.0;
-    double pl0_d = 1.0;
-    float pl0_f = 1.0f;
+    PlSink sink(a, cc, c, s, mag);
     int status = 0;
     int64_t itot = 0;
 
-    for (int64_t t = 0; t <= t_last; t++) {        // tEvol, pvSimPCR.py:237
+    for (int64_t t = 0; t <= sink.t_last; t++) {   // tEvol, pvSimPCR.py:237
         double a0, a1, a2, a3, a4, a5;             // :241-250
         if (t == 0)      { a0 = 1.0; a1 = -1.0; a2 = 0.0; a3 = 0.0; a4 = 0.0; a5 = 0.0; }
         else if (t == 1) { a0 = 1.5; a1 = -2.0; a2 = 0.5; a3 = 0.0; a4 = 0.0; a5 = 0.0; }
@@ -936,45 +1011,7 @@ __global__ void __launch_bounds__(64, (STRICT || L > 128) ? (L > 256 ? 1 : 2) : 
         itot += it;
         if (it >= MAX) { status = 1 + (int)t; break; }                                     // :269-274
 
-        // ---- emit PL(t) ----
-        if (pl_step) {
-            const int64_t col = t / a.plT;
-            if (want_pl && threadIdx.x == 0) {                                             // :281,:393
-                if (a.pl_bytes == 4) ((float *)a.pl)[orow * a.pl_ld + col] = (float)plv / (float)cc.plnorm;
-                else                 ((double *)a.pl)[orow * a.pl_ld + col] = plv / cc.plnorm;
-            }
-            if (interp || col < ncol_ll) {         // bayeslib.py:150-157, probs.py:29-44
-                double lg;
-                if (a.flags & kFlagPlF32) {
-                    float f = (float)plv / (float)cc.plnorm;
-                    if (a.flags & kFlagNormalize) { if (col == 0) pl0_f = f; f = f / pl0_f; }
-                    if ((double)f < DBL_MIN) f = (float)DBL_MIN;
-                    lg = (double)(float)log10((double)f);
-                } else {
-                    double v = plv / cc.plnorm;
-                    if (a.flags & kFlagNormalize) { if (col == 0) pl0_d = v; v = v / pl0_d; }
-                    if (v < DBL_MIN) v = DBL_MIN;
-                    lg = log10(v);
-                }
-                if (!interp) {
-                    double err = lg + mag;
-                    err -= obs[col];
-                    sse += err * err;
-                } else {
-                    // every observation bracketed by grid points (col-1, col): scipy interp1d's
-                    // slope * (x - x_lo) + y_lo (bayeslib.py:189)
-                    while (next_obs < ncol_ll && obs_hi[next_obs] == (int32_t)col) {
-                        const double dy = (a.flags & kFlagPlF32) ? (double)((float)lg - (float)lg_prev) : lg - lg_prev;
-                        const double y = (dy / obs_h[next_obs]) * obs_dx[next_obs] + lg_prev;
-                        double err = y + mag;
-                        err -= obs[next_obs];
-                        sse += err * err;
-                        next_obs++;
-                    }
-                    lg_prev = lg;
-                }
-            }
-        }
+        if (pl_step) sink.emit(t, plv);
 
 #pragma unroll
         for (int j = 0; j < NR; j++) {             // shift the register histories by one level
@@ -988,20 +1025,7 @@ __global__ void __launch_bounds__(64, (STRICT || L > 128) ? (L > 256 ? 1 : 2) : 
         }
     }
 
-    if (threadIdx.x == 0) {
-        if (status && want_pl) {                   // undefined in the reference; NaN here
-            const int64_t t0 = status - 1;
-            for (int64_t tt = t0; tt <= a.T; tt++)
-                if (tt % a.plT == 0) {
-                    const int64_t col = tt / a.plT;
-                    if (a.pl_bytes == 4) ((float *)a.pl)[orow * a.pl_ld + col] = __builtin_nanf("");
-                    else                 ((double *)a.pl)[orow * a.pl_ld + col] = __builtin_nan("");
-                }
-        }
-        if (want_ll) a.sse[orow] = status ? __builtin_inf() : sse;
-        if (a.status) a.status[orow] = status;
-        if (a.iters_total) a.iters_total[orow] = itot;
-    }
+    sink.finish(status, itot);
 }
 
 template <bool STRICT>
