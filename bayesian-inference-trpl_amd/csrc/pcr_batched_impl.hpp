@@ -3,7 +3,7 @@
 // of pcreduce (pvSimPCR.py:42-81).  Bound: HBM bandwidth, 5*L*sizeof(T) algorithmic bytes per
 // system (read ld, d, ud, b; write x).
 #pragma once
-#include "stepper_impl.hpp"
+#include "stepper_f32_impl.hpp"
 
 namespace trpl {
 
@@ -16,15 +16,15 @@ __global__ void __launch_bounds__(256) pcr_batched_kernel(const T *__restrict__ 
     constexpr int NR = L / W;
     const int lane = threadIdx.x & 63;
     const int ln = lane & (W - 1);
-    __shared__ __attribute__((aligned(16))) double xch_all[(!STRICT && L >= 128 && sizeof(T) == 8) ? 4 * 3 * L : 2];
-    double *xch = xch_all + (threadIdx.x >> 6) * 3 * L;         // this wave's private exchange buffer
+    __shared__ __attribute__((aligned(16))) T xch_all[(!STRICT && L >= 128) ? 4 * 3 * L : 4];
+    T *xch = xch_all + (threadIdx.x >> 6) * 3 * L;              // this wave's private exchange buffer
     (void)xch;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     for (int64_t s = wave; s < S; s += nwaves) {
         const int64_t base = s * L;
         T vl[NR], vd[NR], vu[NR], vb[NR], vx[NR];
-        if constexpr (!STRICT && L >= 128 && sizeof(T) == 8) {
+        if constexpr (!STRICT && L >= 128) {
             // interleaved layout: lane owns nodes NR*lane .. NR*lane+NR-1 -> 16-byte loads, fully
             // coalesced 1 KiB per wave-instruction
 #pragma unroll
@@ -32,7 +32,8 @@ __global__ void __launch_bounds__(256) pcr_batched_kernel(const T *__restrict__ 
                 const int64_t o = base + NR * lane + j;
                 vl[j] = ld[o]; vd[j] = d[o]; vu[j] = ud[o]; vb[j] = b[o];
             }
-            pcr_solve_L<NR, L>(vl, vd, vu, vb, vx, lane, xch);
+            if constexpr (sizeof(T) == 8) pcr_solve_L<NR, L>(vl, vd, vu, vb, vx, lane, xch);
+            else                          f32::pcr_solve<NR, L>(vl, vd, vu, vb, vx, lane, xch);
 #pragma unroll
             for (int j = 0; j < NR; j++) x[base + NR * lane + j] = vx[j];
         } else {

@@ -209,7 +209,8 @@ def main():
     }
 
     if rank == 0 and not args.no_pcr:
-        out["roofline_hbm_pcr"] = bench_pcr(torch, tdev, dev, flags)
+        out["roofline_hbm_pcr"] = bench_pcr(torch, tdev, dev, flags & trpl_amd.FLAG_STRICT, L=L,
+                                            dtype=torch.float32 if args.fp32 else torch.float64)
     if rank == 0:
         attach_traffic(out)
     out.update(cpu_legs)
@@ -237,19 +238,21 @@ def attach_traffic(out):
         return                                               # the committed PMC profile is of the fp64 L=128 kernels
     for key, obj in (("void trpl::stepper_kernel<128, false>", "roofline"),
                      ("void trpl::pcr_batched_kernel<double, 128, false>", "roofline_hbm_pcr")):
-        if key in t and obj in out:
+        if key in t and obj in out and (obj == "roofline" or "double,128" in out[obj]["kernel"]):
             out[obj]["traffic"] = t[key]["hbm_bytes_per_launch"]
             out[obj]["traffic_source"] = "profiles/" + src
 
 
-def bench_pcr(torch, tdev, dev, flags, S=65536, L=128, reps=50):
-    """U1: stand-alone batched PCR tridiagonal solve, HBM -> HBM, 5*L*8 B per system."""
+def bench_pcr(torch, tdev, dev, flags, S=65536, L=128, reps=50, dtype=None):
+    """U1: stand-alone batched PCR tridiagonal solve, HBM -> HBM, 5*L*w B per system."""
+    dtype = dtype or torch.float64
+    w = 8 if dtype == torch.float64 else 4
     g = torch.Generator(device=dev)
     g.manual_seed(7)
-    ld = torch.rand((S, L), dtype=torch.float64, device=dev, generator=g) * 2 - 1
-    ud = torch.rand((S, L), dtype=torch.float64, device=dev, generator=g) * 2 - 1
-    d = torch.rand((S, L), dtype=torch.float64, device=dev, generator=g) * 1.5 + 2.5
-    b = torch.randn((S, L), dtype=torch.float64, device=dev, generator=g)
+    ld = torch.rand((S, L), dtype=dtype, device=dev, generator=g) * 2 - 1
+    ud = torch.rand((S, L), dtype=dtype, device=dev, generator=g) * 2 - 1
+    d = torch.rand((S, L), dtype=dtype, device=dev, generator=g) * 1.5 + 2.5
+    b = torch.randn((S, L), dtype=dtype, device=dev, generator=g)
     ld[:, 0] = 0
     ud[:, -1] = 0
     x = torch.empty_like(d)
@@ -268,9 +271,9 @@ def bench_pcr(torch, tdev, dev, flags, S=65536, L=128, reps=50):
     r[:, 1:] += ld[:, 1:] * x[:, :-1]
     r[:, :-1] += ud[:, :-1] * x[:, 1:]
     res = float((r - b).abs().max().item())
-    nbytes = 5 * L * 8 * S
+    nbytes = 5 * L * w * S
     gbs = nbytes / (ms * 1e-3) / 1e9
-    return {"kernel": "pcr_batched_kernel<double,128>", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+    return {"kernel": "pcr_batched_kernel<%s,%d>" % ("double" if w == 8 else "float", L), "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "systems": S, "L": L,
             "bytes_per_launch": nbytes, "avg_launch_ms": ms, "systems_per_s": S / (ms * 1e-3),
             "max_abs_residual": res}

@@ -55,9 +55,19 @@ def test_pcr_batched_fp32_and_many_systems(gpu, oracle):
     r = d * x; r[:, 1:] += ld[:, 1:] * x[:, :-1]; r[:, :-1] += ud[:, :-1] * x[:, 1:]
     assert np.max(np.abs(r - b)) < 1e-12
     f = [a.astype(np.float32) for a in (ld, d, ud, b)]
-    x32 = np.zeros((S, L), dtype=np.float32)
-    gpu._abi.check(lib.trpl_pcr_solve_batched(*(a.ctypes.data for a in f), x32.ctypes.data, S, L, 4, 0, 0, None))
-    assert np.max(np.abs(x32 - x)) < 2e-5
+    for flags in (0, gpu.FLAG_STRICT):                               # interleaved/LDS-staged and blocked fp32 paths
+        x32 = np.zeros((S, L), dtype=np.float32)
+        gpu._abi.check(lib.trpl_pcr_solve_batched(*(a.ctypes.data for a in f), x32.ctypes.data, S, L, 4, flags, 0, None))
+        assert np.max(np.abs(x32 - x)) < 2e-5
+    # configs[4] shape: L = 512, fp32
+    L5 = 512
+    g5 = [rng.uniform(-1, 1, (64, L5)), rng.uniform(2.5, 4, (64, L5)), rng.uniform(-1, 1, (64, L5)), rng.normal(size=(64, L5))]
+    g5[0][:, 0] = 0; g5[2][:, -1] = 0
+    f5 = [a.astype(np.float32) for a in g5]
+    x5 = np.zeros((64, L5), dtype=np.float32)
+    gpu._abi.check(lib.trpl_pcr_solve_batched(*(a.ctypes.data for a in f5), x5.ctypes.data, 64, L5, 4, 0, 0, None))
+    want5 = np.array([oracle.pcreduce(g5[0][s], g5[1][s], g5[2][s], g5[3][s]) for s in range(64)])
+    assert np.max(np.abs(x5 - want5)) < 2e-5
 
 
 # ----------------------------------------------------------------------------- pvSim
@@ -91,6 +101,24 @@ def test_pvsim_twothick_vs_reference_golden(gpu, golden):
         pl, st, it = _run(gpu, X[:, :-1], float(length), float(g["time"]), 128, T, g["ini"][c])
         assert not st.any() and np.all(np.abs(it - want_it) <= 0.01 * want_it + 1)
         assert relerr(pl, want) < RTOL_FAST
+
+
+def test_pvsim_64_random_samples_vs_oracle(gpu, oracle):
+    """BASELINE configs[0] shape: Power_scan (3 excitations, 128 nodes) x 64 random parameter samples,
+    here against the pinned CPU oracle: STRICT iteration counts identical and PL to 1e-13, FAST PL to
+    1e-9 and iteration totals within 1 %."""
+    w = gpu.workloads
+    ini, lens = w.power_scan(128)
+    X = w.samples(64)
+    T, Time = 200, 200 * 0.025
+    for c in range(3):
+        r = oracle.pvsim(X[:, :-1], lens[c], Time, 128, T, ini[c], nthreads=8)
+        pl, st, it, _ = gpu.solve_pl(X[:, :-1], lens[c], Time, 128, T, ini[c], strict=True)
+        assert not st.any() and not r["status"].any()
+        assert np.array_equal(it, r["iters_total"]) and relerr(pl, r["plI"]) < RTOL_STRICT
+        pl, st, it, _ = gpu.solve_pl(X[:, :-1], lens[c], Time, 128, T, ini[c])
+        assert not st.any() and relerr(pl, r["plI"]) < RTOL_FAST
+        assert np.all(np.abs(it - r["iters_total"]) <= 0.01 * r["iters_total"] + 1)
 
 
 def test_pvsim_float32_buffer_matches_reference(gpu, golden):
