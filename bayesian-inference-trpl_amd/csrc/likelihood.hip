@@ -10,86 +10,157 @@ namespace trpl {
 
 // x <- log10(max(x, mn)) in the buffer's dtype.  For float the clamp value is stored as
 // (float)mn first -- 0.0f for mn = DBL_MIN, hence -inf -- exactly like an assignment into the
-// reference's float32 array (probs.py:72-75).
+// reference's float32 array (probs.py:72-75).  The logarithm is evaluated in fp64 and rounded to
+// the buffer's dtype (the CPU oracle's definition).
 template <typename T>
-__global__ void __launch_bounds__(256) log10_clamp_kernel(T *x, int64_t rows, int64_t cols, int64_t ld, double mn)
+__device__ __forceinline__ T log10_clamp_one(T v, double mn)
 {
-    const int64_t n = rows * cols;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = idx / cols, c = idx - r * cols;
-        T *p = x + r * ld + c;
-        T v = *p;
-        if ((double)v < mn) v = (T)mn;
-        *p = (T)log10((double)v);
+    if ((double)v < mn) v = (T)mn;
+    return (T)log10((double)v);
+}
+
+// contiguous buffer (ld == cols): 16 bytes per lane per access, no index arithmetic
+template <typename T>
+__global__ void __launch_bounds__(256) log10_clamp_flat_kernel(T *x, int64_t n, double mn)
+{
+    constexpr int V = 16 / sizeof(T);
+    struct alignas(16) Vec { T v[V]; };
+    const int64_t nvec = n / V;
+    Vec *xv = reinterpret_cast<Vec *>(x);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        Vec t = xv[i];
+#pragma unroll
+        for (int k = 0; k < V; k++) t.v[k] = log10_clamp_one<T>(t.v[k], mn);
+        xv[i] = t;
     }
+    const int64_t tail = nvec * V + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tail < n) x[tail] = log10_clamp_one<T>(x[tail], mn);      // n % V < V <= 4 elements, first lanes of block 0
+}
+
+// padded rows (ld > cols): rows over blockIdx.y, columns strided by the block
+template <typename T>
+__global__ void __launch_bounds__(256) log10_clamp_rows_kernel(T *x, int64_t rows, int64_t cols, int64_t ld, double mn)
+{
+    for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+        T *row = x + r * ld;
+        for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += (int64_t)gridDim.x * blockDim.x)
+            row[c] = log10_clamp_one<T>(row[c], mn);
+    }
+}
+
+template <typename T>
+static hipError_t launch_log10_clamp_t(T *x, int64_t rows, int64_t cols, int64_t ld, double mn, hipStream_t stream)
+{
+    if (ld == cols && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const int64_t n = rows * cols;
+        int64_t blocks = (n / (16 / sizeof(T)) + 255) / 256;
+        blocks = blocks < 1 ? 1 : (blocks > 256 * 32 ? 256 * 32 : blocks);
+        hipLaunchKernelGGL(log10_clamp_flat_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, x, n, mn);
+    } else {
+        const unsigned bx = (unsigned)((cols + 255) / 256 > 64 ? 64 : (cols + 255) / 256);
+        const unsigned by = (unsigned)(rows > 8192 ? 8192 : rows);
+        hipLaunchKernelGGL(log10_clamp_rows_kernel<T>, dim3(bx, by), dim3(256), 0, stream, x, rows, cols, ld, mn);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_log10_clamp(void *x, int elem_bytes, int64_t rows, int64_t cols, int64_t ld, double mn,
                               hipStream_t stream)
 {
-    const int64_t n = rows * cols;
-    if (n <= 0) return hipSuccess;
-    int64_t blocks = (n + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    if (elem_bytes == 4)
-        hipLaunchKernelGGL(log10_clamp_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, (float *)x, rows,
-                           cols, ld, mn);
-    else
-        hipLaunchKernelGGL(log10_clamp_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, stream, (double *)x,
-                           rows, cols, ld, mn);
-    return hipGetLastError();
+    if (rows <= 0 || cols <= 0) return hipSuccess;
+    return elem_bytes == 4 ? launch_log10_clamp_t<float>((float *)x, rows, cols, ld, mn, stream)
+                           : launch_log10_clamp_t<double>((double *)x, rows, cols, ld, mn, stream);
 }
 
 // P[j] -= sum_i (pl[j][i] + mag[j] - values[i])^2, accumulated in index order in fp64 so the
-// result is bit-identical to the reference's serial loop (probs.py:32-44).  A wavefront owns 64
-// rows: it loads [64 rows x 64 columns] tiles with the lanes along the columns (256/512-byte
-// contiguous segments), transposes through LDS, and each lane then adds its own row's 64 values
-// in order.
-template <typename T>
+// result is bit-identical to the reference's serial loop (probs.py:32-44).  The serial chain of
+// n_obs dependent fp64 adds per row is the floor of this formulation (~0.2 ms at 80 001 columns);
+// everything else is arranged around it: a wavefront owns R rows (R small when there are few
+// rows, so that the chip is covered with workgroups), loads [R rows x 64 columns] tiles with the
+// lanes along the columns (256/512-byte contiguous segments), squares the residuals in parallel,
+// transposes through LDS, and lanes 0..R-1 add their row's 64 values in order while the loads of
+// the next tile are already in flight.
+template <typename T, int R>
 __global__ void __launch_bounds__(64) sse_accumulate_kernel(double *P, const T *pl, int64_t rows, int64_t n_obs,
                                                             int64_t ld, const double *values, const double *mag)
 {
-    __shared__ double tile[64][65];
+    __shared__ double tile[R][65];
     const int lane = threadIdx.x;
-    const int64_t row0 = (int64_t)blockIdx.x * 64;
-    const int64_t myrow = row0 + lane;
-    const bool live = myrow < rows;
-    double acc = 0.0;
-    for (int64_t c0 = 0; c0 < n_obs; c0 += 64) {
-        const int64_t col = c0 + lane;
-        const int ncol = (int)((n_obs - c0) < 64 ? (n_obs - c0) : 64);
-        const double val = col < n_obs ? values[col] : 0.0;
-#pragma unroll 8
-        for (int r = 0; r < 64; r++) {
-            const int64_t rr = row0 + r;
-            double v = 0.0;
-            if (rr < rows && col < n_obs) {
-                double e = (double)pl[rr * ld + col] + mag[rr];     // probs.py:33
-                e -= val;                                           // :37
-                v = e * e;                                          // :39
-            }
-            tile[r][lane] = v;
-        }
-        __syncthreads();
-        for (int k = 0; k < ncol; k++) acc += tile[lane][k];        // :41, in index order
-        __syncthreads();
+    const int64_t row0 = (int64_t)blockIdx.x * R;
+    double mg[R];
+    const T *rowp[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {                 // rows past the end alias the last row: loaded, never stored
+        const int64_t rr = row0 + r < rows ? row0 + r : rows - 1;
+        mg[r] = mag[rr];
+        rowp[r] = pl + rr * ld;
     }
-    if (live) P[myrow] += (0.0 - acc);                              // :44, :57-60
+    // D tiles of loads stay in flight per wave: a ring of RAW register tiles, statically indexed.
+    // Loads are unconditional (column index clamped) and nothing depends on them until the slot is
+    // consumed D tiles later, so the compiler can keep them outstanding (a bounds branch around
+    // load+arithmetic made it wait for every single load: 0.1 % of HBM peak).
+    constexpr int D = 32 / R;
+    T raw[D][R];
+    double vraw[D];
+    auto issue = [&](int64_t c0, T (&v)[R], double &val) {
+        int64_t col = c0 + lane;
+        col = col < n_obs ? col : n_obs - 1;
+        val = values[col];
+#pragma unroll
+        for (int r = 0; r < R; r++) v[r] = rowp[r][col];
+    };
+    double acc = 0.0;
+    if (n_obs > 0) {
+#pragma unroll
+        for (int d = 0; d < D; d++) issue((int64_t)d * 64, raw[d], vraw[d]);
+    }
+    for (int64_t c0 = 0; c0 < n_obs; c0 += 64 * D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const int64_t cc = c0 + (int64_t)d * 64;
+            if (cc >= n_obs) break;                                // wave-uniform
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                double e = (double)raw[d][r] + mg[r];              // probs.py:33
+                e -= vraw[d];                                      // :37
+                tile[r][lane] = e * e;                             // :39
+            }
+            issue(cc + 64 * D, raw[d], vraw[d]);                   // refill this slot D tiles ahead
+            const int ncol = (int)((n_obs - cc) < 64 ? (n_obs - cc) : 64);
+            if (lane < R) {
+                const double *t = tile[lane];
+                if (ncol == 64) {
+#pragma unroll 16
+                    for (int k = 0; k < 64; k++) acc += t[k];      // :41, in index order
+                } else {
+                    for (int k = 0; k < ncol; k++) acc += t[k];    // columns >= n_obs are never read
+                }
+            }
+        }
+    }
+    if (lane < R && row0 + lane < rows) P[row0 + lane] += (0.0 - acc);   // :44, :57-60
+}
+
+template <typename T>
+static hipError_t launch_sse_t(double *P, const T *pl, int64_t rows, int64_t n_obs, int64_t ld, const double *values,
+                               const double *mag, hipStream_t stream)
+{
+#define TRPL_SSE(RR)                                                                                              \
+    hipLaunchKernelGGL((sse_accumulate_kernel<T, RR>), dim3((unsigned)((rows + RR - 1) / RR)), dim3(64), 0, stream, \
+                       P, pl, rows, n_obs, ld, values, mag)
+    if (rows <= 4 * 1024) TRPL_SSE(4);               // >= rows/4 workgroups: cover the 256 CUs
+    else if (rows <= 16 * 1024) TRPL_SSE(8);
+    else TRPL_SSE(16);
+#undef TRPL_SSE
+    return hipGetLastError();
 }
 
 hipError_t launch_sse_accumulate(double *P, const void *pl, int elem_bytes, int64_t rows, int64_t n_obs,
                                  int64_t ld, const double *values, const double *mag, hipStream_t stream)
 {
     if (rows <= 0) return hipSuccess;
-    const unsigned blocks = (unsigned)((rows + 63) / 64);
-    if (elem_bytes == 4)
-        hipLaunchKernelGGL(sse_accumulate_kernel<float>, dim3(blocks), dim3(64), 0, stream, P, (const float *)pl,
-                           rows, n_obs, ld, values, mag);
-    else
-        hipLaunchKernelGGL(sse_accumulate_kernel<double>, dim3(blocks), dim3(64), 0, stream, P, (const double *)pl,
-                           rows, n_obs, ld, values, mag);
-    return hipGetLastError();
+    return elem_bytes == 4 ? launch_sse_t<float>(P, (const float *)pl, rows, n_obs, ld, values, mag, stream)
+                           : launch_sse_t<double>(P, (const double *)pl, rows, n_obs, ld, values, mag, stream);
 }
 
 // P[s] -= sse[c][s] for c = 0..C-1 in curve order (the order bayeslib.simulate calls prob in,
