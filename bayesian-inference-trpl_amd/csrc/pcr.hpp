@@ -1,0 +1,306 @@
+// Tridiagonal solvers by parallel cyclic reduction, one wavefront per system (reference:
+// pcreduce, pvSimPCR.py:42-81).  Three flavours:
+//   pcr_solve       STRICT, blocked layout: the reference's operation order, IEEE divides, guards
+//   pcr_solve_fast  FAST, blocked layout (L < 128): normalised rows, Newton-refined reciprocals
+//   pcr_solve_L     FAST, interleaved layout (L >= 128): as above + exchange staged through LDS for
+//                   lane shifts >= 2, DPP for shifts <= 1, v_permlane32_swap + Cramer for the final pairs
+#pragma once
+#include "crosslane.hpp"
+
+namespace trpl {
+
+// One PCR level (pvSimPCR.py:57-69) with stride RF on the snapshot semantics of :49-54.
+template <typename T, int NR, int W, int L, int RF>
+__device__ __forceinline__ void pcr_level(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], int ln)
+{
+    T ld_m[NR], d_m[NR], ud_m[NR], B_m[NR], ld_p[NR], d_p[NR], ud_p[NR], B_p[NR];
+    fetch_dn<T, NR, W, RF>(ld, ld_m, ln);
+    fetch_dn<T, NR, W, RF>(d, d_m, ln);
+    fetch_dn<T, NR, W, RF>(ud, ud_m, ln);
+    fetch_dn<T, NR, W, RF>(B, B_m, ln);
+    fetch_up<T, NR, W, RF>(ld, ld_p, ln);
+    fetch_up<T, NR, W, RF>(d, d_p, ln);
+    fetch_up<T, NR, W, RF>(ud, ud_p, ln);
+    fetch_up<T, NR, W, RF>(B, B_p, ln);
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        const int i = ln + W * j;
+        const bool lo = i >= RF, hi = i < L - RF;
+        const T k1 = lo ? ld[j] / d_m[j] : T(0);
+        const T k2 = hi ? ud[j] / d_p[j] : T(0);
+        T dn = d[j] - ud_m[j] * k1;
+        T Bn = B[j] - B_m[j] * k1;
+        const T ldn = lo ? -ld_m[j] * k1 : ld[j];
+        dn = dn - ld_p[j] * k2;
+        Bn = Bn - B_p[j] * k2;
+        const T udn = hi ? -ud_p[j] * k2 : ud[j];
+        d[j] = dn; B[j] = Bn; ld[j] = ldn; ud[j] = udn;
+    }
+}
+
+template <typename T, int NR, int W, int L, int RF>
+__device__ __forceinline__ void pcr_levels(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], int ln)
+{
+    if constexpr (L > 2 * RF) {
+        pcr_level<T, NR, W, L, RF>(ld, d, ud, B, ln);
+        pcr_levels<T, NR, W, L, RF * 2>(ld, d, ud, B, ln);
+    }
+}
+
+// Tridiagonal solve (pcreduce, pvSimPCR.py:42-81): destroys ld,d,ud,B; result in x.
+template <typename T, int NR, int W, int L>
+__device__ __forceinline__ void pcr_solve(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], T (&x)[NR],
+                                          int ln)
+{
+    pcr_levels<T, NR, W, L, 1>(ld, d, ud, B, ln);
+    if constexpr (NR >= 2) {                       // pairs (i, i+L/2) are (j, j+NR/2) in-lane
+        constexpr int H = NR / 2;
+#pragma unroll
+        for (int j = 0; j < H; j++) {              // pvSimPCR.py:75-79
+            const T k = ud[j] / d[j + H];
+            x[j] = (B[j] - B[j + H] * k) / (d[j] - ld[j + H] * k);
+            x[j + H] = (B[j + H] - ld[j + H] * x[j]) / d[j + H];
+        }
+    } else {                                        // L <= 64: partner lane ln ^ L/2
+        constexpr int H = W / 2;
+        const bool low = (ln & H) == 0;
+        const T ud_o = __shfl_xor(ud[0], H, 64), d_o = __shfl_xor(d[0], H, 64),
+                B_o = __shfl_xor(B[0], H, 64), ld_o = __shfl_xor(ld[0], H, 64);
+        const T l_ud = low ? ud[0] : ud_o, l_d = low ? d[0] : d_o, l_B = low ? B[0] : B_o;
+        const T h_d = low ? d_o : d[0], h_B = low ? B_o : B[0], h_ld = low ? ld_o : ld[0];
+        const T k = l_ud / h_d;
+        const T xl = (l_B - h_B * k) / (l_d - h_ld * k);
+        const T xh = (h_B - h_ld * xl) / h_d;
+        x[0] = low ? xl : xh;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// FAST-mode building blocks (STRICT=false).  Same mathematics, cheaper arithmetic:
+//   * 1/x by v_rcp_f64 + two Newton steps (~1 ulp) instead of the IEEE divide expansion;
+//   * PCR on normalised rows: each row publishes (ld, ud, B)/d, so a neighbour fetch moves 3
+//     values instead of 4 and one reciprocal per row per level replaces two divides; boundary
+//     rows need no guards because their ld / ud are exact zeros (pvSimPCR.py:59,:65 guard the
+//     same rows);
+//   * unit shifts (i +- 1) by DPP wave rotates on the VALU instead of ds_bpermute through LDS.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rcp_nr(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ float rcp_nr(float d) { return 1.0f / d; }
+
+template <typename T, int NR, int W, int L, int RF>
+__device__ __forceinline__ void pcr_level_fast(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], int ln)
+{
+    T nl[NR], nu[NR], nB[NR];
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        const T r = rcp_nr(d[j]);
+        nl[j] = ld[j] * r; nu[j] = ud[j] * r; nB[j] = B[j] * r;
+    }
+    T l_m[NR], u_m[NR], B_m[NR], l_p[NR], u_p[NR], B_p[NR];
+    nb_dn<T, NR, W, RF>(nl, l_m, ln);
+    nb_dn<T, NR, W, RF>(nu, u_m, ln);
+    nb_dn<T, NR, W, RF>(nB, B_m, ln);
+    nb_up<T, NR, W, RF>(nl, l_p, ln);
+    nb_up<T, NR, W, RF>(nu, u_p, ln);
+    nb_up<T, NR, W, RF>(nB, B_p, ln);
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        // rows i < RF have ld == 0 and rows i >= L-RF have ud == 0 (exactly), so the wrapped
+        // neighbour values they fetched drop out
+        d[j] = d[j] - ld[j] * u_m[j] - ud[j] * l_p[j];
+        B[j] = B[j] - ld[j] * B_m[j] - ud[j] * B_p[j];
+        ld[j] = -ld[j] * l_m[j];
+        ud[j] = -ud[j] * u_p[j];
+    }
+}
+
+template <typename T, int NR, int W, int L, int RF>
+__device__ __forceinline__ void pcr_levels_fast(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], int ln)
+{
+    if constexpr (L > 2 * RF) {
+        pcr_level_fast<T, NR, W, L, RF>(ld, d, ud, B, ln);
+        pcr_levels_fast<T, NR, W, L, RF * 2>(ld, d, ud, B, ln);
+    }
+}
+
+template <typename T, int NR, int W, int L>
+__device__ __forceinline__ void pcr_solve_fast(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], T (&x)[NR],
+                                               int ln)
+{
+    pcr_levels_fast<T, NR, W, L, 1>(ld, d, ud, B, ln);
+    if constexpr (NR >= 2) {
+        constexpr int H = NR / 2;
+#pragma unroll
+        for (int j = 0; j < H; j++) {
+            const T r1 = rcp_nr(d[j + H]);
+            const T k = ud[j] * r1;
+            const T den = d[j] - ld[j + H] * k;
+            const T num = B[j] - B[j + H] * k;
+            x[j] = num * rcp_nr(den);
+            x[j + H] = (B[j + H] - ld[j + H] * x[j]) * r1;
+        }
+    } else {
+        constexpr int H = W / 2;
+        const bool low = (ln & H) == 0;
+        const T ud_o = __shfl_xor(ud[0], H, 64), d_o = __shfl_xor(d[0], H, 64), B_o = __shfl_xor(B[0], H, 64),
+                ld_o = __shfl_xor(ld[0], H, 64);
+        const T l_ud = low ? ud[0] : ud_o, l_d = low ? d[0] : d_o, l_B = low ? B[0] : B_o;
+        const T h_d = low ? d_o : d[0], h_B = low ? B_o : B[0], h_ld = low ? ld_o : ld[0];
+        const T r1 = rcp_nr(h_d);
+        const T k = l_ud * r1;
+        const T xl = (l_B - h_B * k) * rcp_nr(l_d - h_ld * k);
+        const T xh = (h_B - h_ld * xl) * r1;
+        x[0] = low ? xl : xh;
+    }
+}
+
+// mode dispatch
+template <bool STRICT, typename T, int NR, int W, int L>
+__device__ __forceinline__ void tridiag_solve(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], T (&x)[NR], int ln)
+{
+    if constexpr (STRICT) pcr_solve<T, NR, W, L>(ld, d, ud, B, x, ln);
+    else                  pcr_solve_fast<T, NR, W, L>(ld, d, ud, B, x, ln);
+}
+
+__device__ __forceinline__ double rcp_nr1(double d)      // one Newton step: 2e-15 relative (measured)
+{
+    if constexpr ((TRPL_ABLATE & 2) != 0) return d * 0.999;
+    const double r = __builtin_amdgcn_rcp(d);     // (a cvt + v_rcp_f32 + cvt seed measured 4 % slower)
+    return __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+}
+__device__ __forceinline__ float rcp_nr1(float d) { return 1.0f / d; }
+
+// Reciprocals of all NR values of a lane.  v_rcp_f64 costs ~3.5 fp64 multiplies, so values are
+// paired: r = 1/(a*b), 1/a = b*r, 1/b = a*r (one reciprocal + 3 multiplies instead of two
+// reciprocals).  The operands here are O(1e-4 .. 1e4), far from over/underflow of the product.
+template <int NR>
+__device__ __forceinline__ void rcp_rows(const double (&d)[NR], double (&r)[NR])
+{
+    if constexpr (NR % 2 == 0 && TRPL_RCP_PAIR != 0) {
+#pragma unroll
+        for (int j = 0; j < NR; j += 2) {
+            const double rp = rcp_nr1(d[j] * d[j + 1]);
+            r[j] = d[j + 1] * rp;
+            r[j + 1] = d[j] * rp;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NR; j++) r[j] = rcp_nr1(d[j]);
+    }
+}
+
+// PCR in the interleaved layout with the neighbour exchange STAGED THROUGH LDS: each level the
+// wave stores its normalised rows (ld, ud, B)/d as three node-indexed arrays (one 16-byte store
+// per array: a lane's NR rows are adjacent nodes) and loads the rows at i-RF and i+RF with one
+// 16-byte load per array and direction: 9 DS instructions per level instead of 24
+// ds_bpermute_b32.  A wavefront executes its DS instructions in order, so no barrier is needed
+// and the 3*L-double buffer is reused by every level.  The LDS (shared by the CU's 4 SIMDs) and
+// the VALU are the two near-saturated resources of this kernel (tools/iter_bench.hip), so the
+// strides whose lane shift is 0 or 1 stay on DPP rotates and the final pairing on
+// v_permlane32_swap; only lane shifts 2..16 go through LDS.  Out-of-range neighbours wrap to
+// in-array values that are multiplied by exact zeros.
+template <int NR>
+struct vecN { double v[NR]; };
+
+template <int NR, int L>
+__device__ __forceinline__ void xch_store(double *xch, int arr, int lane, const double (&x)[NR])
+{
+    vecN<NR> t;
+#pragma unroll
+    for (int j = 0; j < NR; j++) t.v[j] = x[j];
+    *reinterpret_cast<vecN<NR> *>(xch + arr * L + NR * lane) = t;
+}
+template <int NR, int L>
+__device__ __forceinline__ void xch_load(const double *xch, int arr, int node0, double (&y)[NR])
+{
+    const vecN<NR> t = *reinterpret_cast<const vecN<NR> *>(xch + arr * L + node0);
+#pragma unroll
+    for (int j = 0; j < NR; j++) y[j] = t.v[j];
+}
+
+template <int NR, int L, int RF>
+__device__ __forceinline__ void pcr_levels_L(double (&ld)[NR], double (&d)[NR], double (&ud)[NR], double (&B)[NR],
+                                             int lane, double *xch)
+{
+    if constexpr (L > 2 * RF) {
+        double nl[NR], nu[NR], nB[NR], rd[NR];
+        rcp_rows<NR>(d, rd);
+#pragma unroll
+        for (int j = 0; j < NR; j++) { nl[j] = ld[j] * rd[j]; nu[j] = ud[j] * rd[j]; nB[j] = B[j] * rd[j]; }
+        double l_m[NR], u_m[NR], B_m[NR], l_p[NR], u_p[NR], B_p[NR];
+        if constexpr (RF / NR <= 1) {              // lane shift 0 or 1: in-lane moves / DPP rotates (VALU only)
+            nbrB_dn<double, NR, RF>(nl, l_m, lane);
+            nbrB_dn<double, NR, RF>(nu, u_m, lane);
+            nbrB_dn<double, NR, RF>(nB, B_m, lane);
+            nbrB_up<double, NR, RF>(nl, l_p, lane);
+            nbrB_up<double, NR, RF>(nu, u_p, lane);
+            nbrB_up<double, NR, RF>(nB, B_p, lane);
+        } else if constexpr ((TRPL_ABLATE & 1) != 0) {
+#pragma unroll
+            for (int j = 0; j < NR; j++) { l_m[j] = nl[j]; u_m[j] = nu[j]; B_m[j] = nB[j]; l_p[j] = nu[j]; u_p[j] = nl[j]; B_p[j] = -nB[j]; }
+        } else {
+            xch_store<NR, L>(xch, 0, lane, nl);
+            xch_store<NR, L>(xch, 1, lane, nu);
+            xch_store<NR, L>(xch, 2, lane, nB);
+            const int dn = (NR * lane - RF) & (L - 1), up = (NR * lane + RF) & (L - 1);
+            xch_load<NR, L>(xch, 0, dn, l_m);
+            xch_load<NR, L>(xch, 1, dn, u_m);
+            xch_load<NR, L>(xch, 2, dn, B_m);
+            xch_load<NR, L>(xch, 0, up, l_p);
+            xch_load<NR, L>(xch, 1, up, u_p);
+            xch_load<NR, L>(xch, 2, up, B_p);
+        }
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            // rows i < RF have ld == 0 and rows i >= L-RF have ud == 0 exactly: wrapped values drop out
+            d[j] = d[j] - ld[j] * u_m[j] - ud[j] * l_p[j];
+            B[j] = B[j] - ld[j] * B_m[j] - ud[j] * B_p[j];
+            ld[j] = -ld[j] * l_m[j];
+            ud[j] = -ud[j] * u_p[j];
+        }
+        pcr_levels_L<NR, L, RF * 2>(ld, d, ud, B, lane, xch);
+    }
+}
+
+// PCR solve, interleaved layout, L >= 128 (the final pairs i, i+L/2 sit in lanes l, l^32).
+template <int NR, int L>
+__device__ __forceinline__ void pcr_solve_L(double (&ld)[NR], double (&d)[NR], double (&ud)[NR], double (&B)[NR],
+                                            double (&x)[NR], int lane, double *xch)
+{
+    pcr_levels_L<NR, L, 1>(ld, d, ud, B, lane, xch);
+    // final 2x2 solves (pvSimPCR.py:75-79) between lanes l and l^32, by Cramer's rule so that each
+    // lane computes only its own unknown with ONE reciprocal:
+    //     [ d_lo  ud_lo ] [x_lo]   [B_lo]        x_own = (B_own d_oth - c_own B_oth) / (d_own d_oth - c_own c_oth)
+    //     [ ld_hi d_hi  ] [x_hi] = [B_hi]        c = coupling to the partner row (ud for the lower, ld for the upper)
+    // v_permlane32_swap delivers the partner's values on the VALU (the LDS is the scarcer resource).
+    const bool low = lane < 32;
+    double det[NR], num[NR], rdet[NR];
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        const double c_own = low ? +ud[j] : +ld[j];
+        double d_oth, B_oth, c_oth;
+        if constexpr ((TRPL_ABLATE & 1) != 0) {
+            d_oth = d[j] * 1.5; B_oth = -B[j]; c_oth = c_own;
+        } else {
+            double lo_h, hi_h;
+            pair32(d[j], lo_h, hi_h);  d_oth = low ? hi_h : lo_h;
+            pair32(B[j], lo_h, hi_h);  B_oth = low ? hi_h : lo_h;
+            pair32(c_own, lo_h, hi_h); c_oth = low ? hi_h : lo_h;
+        }
+        det[j] = d[j] * d_oth - c_own * c_oth;
+        num[j] = B[j] * d_oth - c_own * B_oth;
+    }
+    rcp_rows<NR>(det, rdet);
+#pragma unroll
+    for (int j = 0; j < NR; j++) x[j] = num[j] * rdet[j];
+}
+
+}  // namespace trpl

@@ -1,607 +1,31 @@
 // TRPL time-stepper for gfx950: ONE WAVEFRONT OWNS ONE SYSTEM (sample x curve) FOR ALL T STEPS.
 //
 // What it computes (reference: pvSimPCR.py tEvol :227-306, iterate :93-225, pcreduce :42-81,
-// norm2 :14-40; likelihood probs.py:20-47, :64-75): variable-order BDF in time; per step a
-// Newton/Picard iteration whose two tridiagonal systems are solved by parallel cyclic
-// reduction; PL(t) by midpoint quadrature; optionally log10 + squared error against
-// observations, fused, so PL never reaches memory.
+// norm2 :14-40; likelihood probs.py:20-47, :64-75, time interpolation bayeslib.py:184-191):
+// variable-order BDF in time; per step a Newton/Picard iteration whose two tridiagonal systems are
+// solved by parallel cyclic reduction; PL(t) by midpoint quadrature; optionally log10 + squared error
+// against observations (on the grid or interpolated), fused, so PL never reaches memory.
 //
-// Layout: node i = ln + W*j, ln = lane (W = min(L,64) lanes), j < NR = L/W rows per lane.
-//   * PCR strides 1..W/2 are cross-lane rotations, strides >= W and the final 2x2 solves
-//     (pairs i, i+L/2) are intra-lane when NR >= 2;
-//   * the reference's power-of-two reduction tree (norm2 :32-38) becomes intra-lane adds
-//     followed by an xor butterfly: same association, so the residual norms -- and with
-//     them every convergence decision -- are bit-identical in STRICT mode.
-// State (N,P,E), the 5 BDF history levels and the BDF right-hand sides live in VGPRs for the
-// whole run; the 12 material parameters are wave-uniform.  HBM traffic per system is 13
-// doubles in, one double out (likelihood mode) -- the kernel is fp64-VALU / cross-lane bound
-// by construction, not HBM bound.
-//
-// Included by stepper_strict.hip (compiled -ffp-contract=off, STRICT=true: IEEE divides,
-// reference operation order -> bit-identical state) and stepper_fast.hip (contraction on,
-// STRICT=false).
+// Two arithmetic modes share this source (stepper_strict.hip: -ffp-contract=off, STRICT = true;
+// stepper_fast.hip: contraction on, STRICT = false) and differ in node layout (LAY):
+//   LAY 0  STRICT, blocked layout i = lane + W*j: the reference's operation order and IEEE divides;
+//          its power-of-two reduction tree (norm2 :32-38) becomes in-lane adds + an xor butterfly
+//          with the same association, so residual norms, every convergence decision and the N/P/E
+//          state are bit-identical to the sequentially executed reference.  History in registers.
+//   LAY 2  FAST, L >= 128, interleaved layout i = NR*lane + j: select-free lane shifts (crosslane.hpp),
+//          LDS-staged PCR exchange (pcr.hpp), DPP reductions, reciprocals by v_rcp_f64 + one Newton
+//          step, N/P history in a 4-slot LDS ring, 3 waves per SIMD.
+//   LAY 1  FAST for L < 128 (blocked layout, DPP unit shifts): small grids, not performance critical.
+// The 12 material parameters are wave-uniform (SGPRs).  HBM traffic per system is 13 doubles in and
+// one double out in likelihood mode: the kernel is bound by fp64 VALU issue and the CU's LDS, not by
+// HBM (tools/iter_bench.hip for the cost breakdown).
 #pragma once
-#include <math.h>
-#include <float.h>
-#include <stdlib.h>
-
-#include <type_traits>
-#include <utility>
-
-#include "trpl_common.hpp"
-
-// Development-only ablation switches for tools/iter_bench.hip (cost breakdown of one inner
-// iteration).  Always 0 in the library build; non-zero values compute WRONG results by design.
-//   1: no LDS exchange in the PCR levels   2: reciprocals replaced by a multiply
-//   4: no wave reductions                  8: no DPP shifts
-#ifndef TRPL_FAST_WAVES
-#define TRPL_FAST_WAVES 3      // waves per SIMD the fast stepper is register-budgeted for
-#endif
-#ifndef TRPL_ABLATE
-#define TRPL_ABLATE 0
-#endif
-#ifndef TRPL_RCP_PAIR
-#define TRPL_RCP_PAIR 1       // pair reciprocals (rcp_rows); 0 only for A/B measurements
-#endif
+#include "pcr.hpp"
 
 namespace trpl {
 
 constexpr uint32_t kFlagPlF32 = 0x2;       // TRPL_FLAG_PL_F32
 constexpr uint32_t kFlagNormalize = 0x4;   // TRPL_FLAG_NORMALIZE
-
-__device__ __forceinline__ double uniform_d(double v)
-{
-    // broadcast lane 0's value through SGPRs so the compiler knows it is wave-uniform
-    union { double d; int i[2]; } u;
-    u.d = v;
-    u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
-    u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
-    return u.d;
-}
-
-// y[j] = x at node i+RF (any finite in-array value when i+RF >= L)
-template <typename T, int NR, int W, int RF>
-__device__ __forceinline__ void fetch_up(const T (&x)[NR], T (&y)[NR], int ln)
-{
-    if constexpr (RF >= W) {
-        constexpr int m = RF / W;
-#pragma unroll
-        for (int j = 0; j < NR; j++) y[j] = x[(j + m) % NR];
-    } else {
-        const int src = (ln + RF) & (W - 1);
-        const bool wrap = ln + RF >= W;
-        T s[NR];
-#pragma unroll
-        for (int j = 0; j < NR; j++) s[j] = __shfl(x[j], src, 64);
-#pragma unroll
-        for (int j = 0; j < NR; j++) y[j] = wrap ? +s[(j + 1) % NR] : +s[j];
-    }
-}
-
-// y[j] = x at node i-RF (any finite in-array value when i < RF)
-template <typename T, int NR, int W, int RF>
-__device__ __forceinline__ void fetch_dn(const T (&x)[NR], T (&y)[NR], int ln)
-{
-    if constexpr (RF >= W) {
-        constexpr int m = RF / W;
-#pragma unroll
-        for (int j = 0; j < NR; j++) y[j] = x[(j + NR - m) % NR];
-    } else {
-        const int src = (ln - RF) & (W - 1);
-        const bool wrap = ln < RF;
-        T s[NR];
-#pragma unroll
-        for (int j = 0; j < NR; j++) s[j] = __shfl(x[j], src, 64);
-#pragma unroll
-        for (int j = 0; j < NR; j++) y[j] = wrap ? +s[(j + NR - 1) % NR] : +s[j];
-    }
-}
-
-// Sum over all L nodes with the reference's tree association (norm2, pvSimPCR.py:32-38):
-// level rf pairs (i, i+rf), rf = L/2 ... 1.  Every lane ends with the same value.
-template <typename T, int NR, int W>
-__device__ __forceinline__ T tree_sum(T (&v)[NR])
-{
-#pragma unroll
-    for (int m = NR / 2; m >= 1; m /= 2)
-#pragma unroll
-        for (int j = 0; j < m; j++) v[j] = v[j] + v[j + m];
-    T r = v[0];
-#pragma unroll
-    for (int off = W / 2; off >= 1; off /= 2) r = r + __shfl_xor(r, off, 64);
-    return r;
-}
-
-// One PCR level (pvSimPCR.py:57-69) with stride RF on the snapshot semantics of :49-54.
-template <typename T, int NR, int W, int L, int RF>
-__device__ __forceinline__ void pcr_level(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], int ln)
-{
-    T ld_m[NR], d_m[NR], ud_m[NR], B_m[NR], ld_p[NR], d_p[NR], ud_p[NR], B_p[NR];
-    fetch_dn<T, NR, W, RF>(ld, ld_m, ln);
-    fetch_dn<T, NR, W, RF>(d, d_m, ln);
-    fetch_dn<T, NR, W, RF>(ud, ud_m, ln);
-    fetch_dn<T, NR, W, RF>(B, B_m, ln);
-    fetch_up<T, NR, W, RF>(ld, ld_p, ln);
-    fetch_up<T, NR, W, RF>(d, d_p, ln);
-    fetch_up<T, NR, W, RF>(ud, ud_p, ln);
-    fetch_up<T, NR, W, RF>(B, B_p, ln);
-#pragma unroll
-    for (int j = 0; j < NR; j++) {
-        const int i = ln + W * j;
-        const bool lo = i >= RF, hi = i < L - RF;
-        const T k1 = lo ? ld[j] / d_m[j] : T(0);
-        const T k2 = hi ? ud[j] / d_p[j] : T(0);
-        T dn = d[j] - ud_m[j] * k1;
-        T Bn = B[j] - B_m[j] * k1;
-        const T ldn = lo ? -ld_m[j] * k1 : ld[j];
-        dn = dn - ld_p[j] * k2;
-        Bn = Bn - B_p[j] * k2;
-        const T udn = hi ? -ud_p[j] * k2 : ud[j];
-        d[j] = dn; B[j] = Bn; ld[j] = ldn; ud[j] = udn;
-    }
-}
-
-template <typename T, int NR, int W, int L, int RF>
-__device__ __forceinline__ void pcr_levels(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], int ln)
-{
-    if constexpr (L > 2 * RF) {
-        pcr_level<T, NR, W, L, RF>(ld, d, ud, B, ln);
-        pcr_levels<T, NR, W, L, RF * 2>(ld, d, ud, B, ln);
-    }
-}
-
-// Tridiagonal solve (pcreduce, pvSimPCR.py:42-81): destroys ld,d,ud,B; result in x.
-template <typename T, int NR, int W, int L>
-__device__ __forceinline__ void pcr_solve(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], T (&x)[NR],
-                                          int ln)
-{
-    pcr_levels<T, NR, W, L, 1>(ld, d, ud, B, ln);
-    if constexpr (NR >= 2) {                       // pairs (i, i+L/2) are (j, j+NR/2) in-lane
-        constexpr int H = NR / 2;
-#pragma unroll
-        for (int j = 0; j < H; j++) {              // pvSimPCR.py:75-79
-            const T k = ud[j] / d[j + H];
-            x[j] = (B[j] - B[j + H] * k) / (d[j] - ld[j + H] * k);
-            x[j + H] = (B[j + H] - ld[j + H] * x[j]) / d[j + H];
-        }
-    } else {                                        // L <= 64: partner lane ln ^ L/2
-        constexpr int H = W / 2;
-        const bool low = (ln & H) == 0;
-        const T ud_o = __shfl_xor(ud[0], H, 64), d_o = __shfl_xor(d[0], H, 64),
-                B_o = __shfl_xor(B[0], H, 64), ld_o = __shfl_xor(ld[0], H, 64);
-        const T l_ud = low ? ud[0] : ud_o, l_d = low ? d[0] : d_o, l_B = low ? B[0] : B_o;
-        const T h_d = low ? d_o : d[0], h_B = low ? B_o : B[0], h_ld = low ? ld_o : ld[0];
-        const T k = l_ud / h_d;
-        const T xl = (l_B - h_B * k) / (l_d - h_ld * k);
-        const T xh = (h_B - h_ld * xl) / h_d;
-        x[0] = low ? xl : xh;
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------
-// FAST-mode building blocks (STRICT=false).  Same mathematics, cheaper arithmetic:
-//   * 1/x by v_rcp_f64 + two Newton steps (~1 ulp) instead of the IEEE divide expansion;
-//   * PCR on normalised rows: each row publishes (ld, ud, B)/d, so a neighbour fetch moves 3
-//     values instead of 4 and one reciprocal per row per level replaces two divides; boundary
-//     rows need no guards because their ld / ud are exact zeros (pvSimPCR.py:59,:65 guard the
-//     same rows);
-//   * unit shifts (i +- 1) by DPP wave rotates on the VALU instead of ds_bpermute through LDS.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double rcp_nr(double d)
-{
-    double r = __builtin_amdgcn_rcp(d);
-    double e = __builtin_fma(-d, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-d, r, 1.0);
-    return __builtin_fma(r, e, r);
-}
-__device__ __forceinline__ float rcp_nr(float d) { return 1.0f / d; }
-
-// Hide a value's provenance from the optimiser.  Without it LLVM packs the shuffled rows into a
-// vector and turns `wrap ? s[j+1] : s[j]` into a dynamically indexed extract, which lands in
-// scratch memory (seen at the stride-32 level, where the up and down sources coincide).
-template <typename T>
-__device__ __forceinline__ T pick(bool c, T a, T b)
-{
-    asm volatile("" : "+v"(a));
-    asm volatile("" : "+v"(b));
-    return c ? a : b;
-}
-
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov(double v)
-{
-    union { double d; int i[2]; } u, r;
-    u.d = v;
-    r.i[0] = __builtin_amdgcn_mov_dpp(u.i[0], CTRL, 0xF, 0xF, false);   // every lane is written:
-    r.i[1] = __builtin_amdgcn_mov_dpp(u.i[1], CTRL, 0xF, 0xF, false);   // no destination init needed
-    return r.d;
-}
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
-}
-constexpr int kDppWaveRol1 = 0x134;   // lane l <- lane (l+1) & 63
-constexpr int kDppWaveRor1 = 0x13C;   // lane l <- lane (l-1) & 63
-
-// y[j] = x at node i+1 / i-1; the out-of-range entry (last row's last lane / first row's first
-// lane) holds an arbitrary in-array value.  W == 64 uses DPP, narrower systems the generic path.
-template <typename T, int NR, int W>
-__device__ __forceinline__ void fetch_up1(const T (&x)[NR], T (&y)[NR], int ln)
-{
-    if constexpr (W == 64) {
-        T r[NR];
-#pragma unroll
-        for (int j = 0; j < NR; j++) r[j] = dpp_mov<kDppWaveRol1>(x[j]);
-#pragma unroll
-        for (int j = 0; j < NR - 1; j++) y[j] = ln == 63 ? +r[j + 1] : +r[j];
-        y[NR - 1] = r[NR - 1];
-    } else {
-        fetch_up<T, NR, W, 1>(x, y, ln);
-    }
-}
-template <typename T, int NR, int W>
-__device__ __forceinline__ void fetch_dn1(const T (&x)[NR], T (&y)[NR], int ln)
-{
-    if constexpr (W == 64) {
-        T r[NR];
-#pragma unroll
-        for (int j = 0; j < NR; j++) r[j] = dpp_mov<kDppWaveRor1>(x[j]);
-        y[0] = r[0];
-#pragma unroll
-        for (int j = 1; j < NR; j++) y[j] = ln == 0 ? +r[j - 1] : +r[j];
-    } else {
-        fetch_dn<T, NR, W, 1>(x, y, ln);
-    }
-}
-
-// neighbour fetch for the fast PCR: like fetch_up/fetch_dn but the entry that is always out of
-// range is not fixed up (saves the select), and stride 1 goes through DPP.
-template <typename T, int NR, int W, int RF>
-__device__ __forceinline__ void nb_up(const T (&x)[NR], T (&y)[NR], int ln)
-{
-    if constexpr (RF == 1) {
-        fetch_up1<T, NR, W>(x, y, ln);
-    } else if constexpr (RF >= W) {
-        constexpr int m = RF / W;
-#pragma unroll
-        for (int j = 0; j < NR; j++) y[j] = x[(j + m) % NR];
-    } else {
-        const int src = (ln + RF) & (W - 1);
-        const bool wrap = ln + RF >= W;
-        T s[NR];
-#pragma unroll
-        for (int j = 0; j < NR; j++) s[j] = __shfl(x[j], src, 64);
-#pragma unroll
-        for (int j = 0; j < NR - 1; j++) y[j] = pick(wrap, s[j + 1], s[j]);
-        y[NR - 1] = s[NR - 1];
-    }
-}
-template <typename T, int NR, int W, int RF>
-__device__ __forceinline__ void nb_dn(const T (&x)[NR], T (&y)[NR], int ln)
-{
-    if constexpr (RF == 1) {
-        fetch_dn1<T, NR, W>(x, y, ln);
-    } else if constexpr (RF >= W) {
-        constexpr int m = RF / W;
-#pragma unroll
-        for (int j = 0; j < NR; j++) y[j] = x[(j + NR - m) % NR];
-    } else {
-        const int src = (ln - RF) & (W - 1);
-        const bool wrap = ln < RF;
-        T s[NR];
-#pragma unroll
-        for (int j = 0; j < NR; j++) s[j] = __shfl(x[j], src, 64);
-        y[0] = s[0];
-#pragma unroll
-        for (int j = 1; j < NR; j++) y[j] = pick(wrap, s[j - 1], s[j]);
-    }
-}
-
-template <typename T, int NR, int W, int L, int RF>
-__device__ __forceinline__ void pcr_level_fast(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], int ln)
-{
-    T nl[NR], nu[NR], nB[NR];
-#pragma unroll
-    for (int j = 0; j < NR; j++) {
-        const T r = rcp_nr(d[j]);
-        nl[j] = ld[j] * r; nu[j] = ud[j] * r; nB[j] = B[j] * r;
-    }
-    T l_m[NR], u_m[NR], B_m[NR], l_p[NR], u_p[NR], B_p[NR];
-    nb_dn<T, NR, W, RF>(nl, l_m, ln);
-    nb_dn<T, NR, W, RF>(nu, u_m, ln);
-    nb_dn<T, NR, W, RF>(nB, B_m, ln);
-    nb_up<T, NR, W, RF>(nl, l_p, ln);
-    nb_up<T, NR, W, RF>(nu, u_p, ln);
-    nb_up<T, NR, W, RF>(nB, B_p, ln);
-#pragma unroll
-    for (int j = 0; j < NR; j++) {
-        // rows i < RF have ld == 0 and rows i >= L-RF have ud == 0 (exactly), so the wrapped
-        // neighbour values they fetched drop out
-        d[j] = d[j] - ld[j] * u_m[j] - ud[j] * l_p[j];
-        B[j] = B[j] - ld[j] * B_m[j] - ud[j] * B_p[j];
-        ld[j] = -ld[j] * l_m[j];
-        ud[j] = -ud[j] * u_p[j];
-    }
-}
-
-template <typename T, int NR, int W, int L, int RF>
-__device__ __forceinline__ void pcr_levels_fast(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], int ln)
-{
-    if constexpr (L > 2 * RF) {
-        pcr_level_fast<T, NR, W, L, RF>(ld, d, ud, B, ln);
-        pcr_levels_fast<T, NR, W, L, RF * 2>(ld, d, ud, B, ln);
-    }
-}
-
-template <typename T, int NR, int W, int L>
-__device__ __forceinline__ void pcr_solve_fast(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], T (&x)[NR],
-                                               int ln)
-{
-    pcr_levels_fast<T, NR, W, L, 1>(ld, d, ud, B, ln);
-    if constexpr (NR >= 2) {
-        constexpr int H = NR / 2;
-#pragma unroll
-        for (int j = 0; j < H; j++) {
-            const T r1 = rcp_nr(d[j + H]);
-            const T k = ud[j] * r1;
-            const T den = d[j] - ld[j + H] * k;
-            const T num = B[j] - B[j + H] * k;
-            x[j] = num * rcp_nr(den);
-            x[j + H] = (B[j + H] - ld[j + H] * x[j]) * r1;
-        }
-    } else {
-        constexpr int H = W / 2;
-        const bool low = (ln & H) == 0;
-        const T ud_o = __shfl_xor(ud[0], H, 64), d_o = __shfl_xor(d[0], H, 64), B_o = __shfl_xor(B[0], H, 64),
-                ld_o = __shfl_xor(ld[0], H, 64);
-        const T l_ud = low ? ud[0] : ud_o, l_d = low ? d[0] : d_o, l_B = low ? B[0] : B_o;
-        const T h_d = low ? d_o : d[0], h_B = low ? B_o : B[0], h_ld = low ? ld_o : ld[0];
-        const T r1 = rcp_nr(h_d);
-        const T k = l_ud * r1;
-        const T xl = (l_B - h_B * k) * rcp_nr(l_d - h_ld * k);
-        const T xh = (h_B - h_ld * xl) * r1;
-        x[0] = low ? xl : xh;
-    }
-}
-
-// mode dispatch
-template <bool STRICT, typename T, int NR, int W, int L>
-__device__ __forceinline__ void tridiag_solve(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], T (&x)[NR], int ln)
-{
-    if constexpr (STRICT) pcr_solve<T, NR, W, L>(ld, d, ud, B, x, ln);
-    else                  pcr_solve_fast<T, NR, W, L>(ld, d, ud, B, x, ln);
-}
-
-
-// ------------------------------------------------------------------------------------------
-// FAST mode, L >= 128: INTERLEAVED layout  node i = NR*lane + j  (NR = L/64 consecutive nodes per
-// lane).  Every neighbour i +- RF is then (lane +- K, row j') with K and j' known at compile
-// time, so a fetch is a pure lane shift -- no per-lane selects at all:
-//      K = 0 : in-lane register move          K = 1 : DPP wave rotate (VALU, no LDS)
-//      K >= 2: ds_bpermute                    final pairing (lane ^ 32): v_permlane32_swap
-// Wave-wide sums (residual norms, PL) are DPP row reductions ending in lane 63 + v_readlane.
-// The reduction order differs from the reference's tree, which is why STRICT mode keeps the
-// blocked layout above.
-// ------------------------------------------------------------------------------------------
-template <typename F, int... I>
-__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>)
-{
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F &&f)
-{
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-__device__ __forceinline__ double rcp_nr1(double d)      // one Newton step: 2e-15 relative (measured)
-{
-    if constexpr ((TRPL_ABLATE & 2) != 0) return d * 0.999;
-    const double r = __builtin_amdgcn_rcp(d);     // (a cvt + v_rcp_f32 + cvt seed measured 4 % slower)
-    return __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
-}
-__device__ __forceinline__ float rcp_nr1(float d) { return 1.0f / d; }
-
-// Reciprocals of all NR values of a lane.  v_rcp_f64 costs ~3.5 fp64 multiplies, so values are
-// paired: r = 1/(a*b), 1/a = b*r, 1/b = a*r (one reciprocal + 3 multiplies instead of two
-// reciprocals).  The operands here are O(1e-4 .. 1e4), far from over/underflow of the product.
-template <int NR>
-__device__ __forceinline__ void rcp_rows(const double (&d)[NR], double (&r)[NR])
-{
-    if constexpr (NR % 2 == 0 && TRPL_RCP_PAIR != 0) {
-#pragma unroll
-        for (int j = 0; j < NR; j += 2) {
-            const double rp = rcp_nr1(d[j] * d[j + 1]);
-            r[j] = d[j + 1] * rp;
-            r[j + 1] = d[j] * rp;
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < NR; j++) r[j] = rcp_nr1(d[j]);
-    }
-}
-
-template <int K, typename T>
-__device__ __forceinline__ T lane_up(T v, int lane)       // value held by lane + K (mod 64)
-{
-    if constexpr (K == 0 || (TRPL_ABLATE & 8) != 0) return v;
-    else if constexpr (K == 1) return dpp_mov<kDppWaveRol1>(v);
-    else return __shfl(v, (lane + K) & 63, 64);
-}
-template <int K, typename T>
-__device__ __forceinline__ T lane_dn(T v, int lane)       // value held by lane - K (mod 64)
-{
-    if constexpr (K == 0 || (TRPL_ABLATE & 8) != 0) return v;
-    else if constexpr (K == 1) return dpp_mov<kDppWaveRor1>(v);
-    else return __shfl(v, (lane - K) & 63, 64);
-}
-
-// y[j] = x at node i+RF / i-RF in the interleaved layout (wrapped lanes give in-array values)
-template <typename T, int NR, int RF>
-__device__ __forceinline__ void nbrB_up(const T (&x)[NR], T (&y)[NR], int lane)
-{
-    static_for<NR>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        y[j] = lane_up<(j + RF) / NR>(x[(j + RF) % NR], lane);
-    });
-}
-template <typename T, int NR, int RF>
-__device__ __forceinline__ void nbrB_dn(const T (&x)[NR], T (&y)[NR], int lane)
-{
-    static_for<NR>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        constexpr int K = RF > j ? (RF - j + NR - 1) / NR : 0;
-        y[j] = lane_dn<K>(x[((j - RF) % NR + NR) % NR], lane);
-    });
-}
-
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ double dpp_add(double v)
-{
-    int lo, hi;
-    if constexpr (ROWMASK == 0xF) {      // all rows written (out-of-row sources read 0): no init
-        lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
-        hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
-    } else {                             // masked rows keep the 0 they are initialised with
-        lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xF, true);
-        hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xF, true);
-    }
-    return v + __hiloint2double(hi, lo);
-}
-// Sum of v over the 64 lanes, returned wave-uniform (SGPRs).
-__device__ __forceinline__ double wave_sum(double v)
-{
-    if constexpr ((TRPL_ABLATE & 4) != 0) return uniform_d(v);
-    v = dpp_add<0x111, 0xF>(v);          // row_shr:1
-    v = dpp_add<0x112, 0xF>(v);          // row_shr:2
-    v = dpp_add<0x114, 0xF>(v);          // row_shr:4
-    v = dpp_add<0x118, 0xF>(v);          // row_shr:8   -> lane 15 of each row holds the row sum
-    v = dpp_add<0x142, 0xA>(v);          // row_bcast:15 into rows 1,3
-    v = dpp_add<0x143, 0xC>(v);          // row_bcast:31 into rows 2,3 -> lane 63 holds the total
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-    return __hiloint2double(hi, lo);
-}
-
-// (value of the lower-half lane, value of the upper-half lane) of each lane pair (l, l^32), in
-// every lane: v_permlane32_swap on two copies of v.
-__device__ __forceinline__ void pair32(double v, double &lo_half, double &hi_half)
-{
-    const unsigned a = (unsigned)__double2loint(v), b = (unsigned)__double2hiint(v);
-    const auto r0 = __builtin_amdgcn_permlane32_swap(a, a, false, false);
-    const auto r1 = __builtin_amdgcn_permlane32_swap(b, b, false, false);
-    lo_half = __hiloint2double((int)r1[0], (int)r0[0]);
-    hi_half = __hiloint2double((int)r1[1], (int)r0[1]);
-}
-
-// PCR in the interleaved layout with the neighbour exchange STAGED THROUGH LDS: each level the
-// wave stores its normalised rows (ld, ud, B)/d as three node-indexed arrays (one 16-byte store
-// per array: a lane's NR rows are adjacent nodes) and loads the rows at i-RF and i+RF with one
-// 16-byte load per array and direction: 9 DS instructions per level instead of 24
-// ds_bpermute_b32.  A wavefront executes its DS instructions in order, so no barrier is needed
-// and the 3*L-double buffer is reused by every level.  The LDS (shared by the CU's 4 SIMDs) and
-// the VALU are the two near-saturated resources of this kernel (tools/iter_bench.hip), so the
-// strides whose lane shift is 0 or 1 stay on DPP rotates and the final pairing on
-// v_permlane32_swap; only lane shifts 2..16 go through LDS.  Out-of-range neighbours wrap to
-// in-array values that are multiplied by exact zeros.
-template <int NR>
-struct vecN { double v[NR]; };
-
-template <int NR, int L>
-__device__ __forceinline__ void xch_store(double *xch, int arr, int lane, const double (&x)[NR])
-{
-    vecN<NR> t;
-#pragma unroll
-    for (int j = 0; j < NR; j++) t.v[j] = x[j];
-    *reinterpret_cast<vecN<NR> *>(xch + arr * L + NR * lane) = t;
-}
-template <int NR, int L>
-__device__ __forceinline__ void xch_load(const double *xch, int arr, int node0, double (&y)[NR])
-{
-    const vecN<NR> t = *reinterpret_cast<const vecN<NR> *>(xch + arr * L + node0);
-#pragma unroll
-    for (int j = 0; j < NR; j++) y[j] = t.v[j];
-}
-
-template <int NR, int L, int RF>
-__device__ __forceinline__ void pcr_levels_L(double (&ld)[NR], double (&d)[NR], double (&ud)[NR], double (&B)[NR],
-                                             int lane, double *xch)
-{
-    if constexpr (L > 2 * RF) {
-        double nl[NR], nu[NR], nB[NR], rd[NR];
-        rcp_rows<NR>(d, rd);
-#pragma unroll
-        for (int j = 0; j < NR; j++) { nl[j] = ld[j] * rd[j]; nu[j] = ud[j] * rd[j]; nB[j] = B[j] * rd[j]; }
-        double l_m[NR], u_m[NR], B_m[NR], l_p[NR], u_p[NR], B_p[NR];
-        if constexpr (RF / NR <= 1) {              // lane shift 0 or 1: in-lane moves / DPP rotates (VALU only)
-            nbrB_dn<double, NR, RF>(nl, l_m, lane);
-            nbrB_dn<double, NR, RF>(nu, u_m, lane);
-            nbrB_dn<double, NR, RF>(nB, B_m, lane);
-            nbrB_up<double, NR, RF>(nl, l_p, lane);
-            nbrB_up<double, NR, RF>(nu, u_p, lane);
-            nbrB_up<double, NR, RF>(nB, B_p, lane);
-        } else if constexpr ((TRPL_ABLATE & 1) != 0) {
-#pragma unroll
-            for (int j = 0; j < NR; j++) { l_m[j] = nl[j]; u_m[j] = nu[j]; B_m[j] = nB[j]; l_p[j] = nu[j]; u_p[j] = nl[j]; B_p[j] = -nB[j]; }
-        } else {
-            xch_store<NR, L>(xch, 0, lane, nl);
-            xch_store<NR, L>(xch, 1, lane, nu);
-            xch_store<NR, L>(xch, 2, lane, nB);
-            const int dn = (NR * lane - RF) & (L - 1), up = (NR * lane + RF) & (L - 1);
-            xch_load<NR, L>(xch, 0, dn, l_m);
-            xch_load<NR, L>(xch, 1, dn, u_m);
-            xch_load<NR, L>(xch, 2, dn, B_m);
-            xch_load<NR, L>(xch, 0, up, l_p);
-            xch_load<NR, L>(xch, 1, up, u_p);
-            xch_load<NR, L>(xch, 2, up, B_p);
-        }
-#pragma unroll
-        for (int j = 0; j < NR; j++) {
-            // rows i < RF have ld == 0 and rows i >= L-RF have ud == 0 exactly: wrapped values drop out
-            d[j] = d[j] - ld[j] * u_m[j] - ud[j] * l_p[j];
-            B[j] = B[j] - ld[j] * B_m[j] - ud[j] * B_p[j];
-            ld[j] = -ld[j] * l_m[j];
-            ud[j] = -ud[j] * u_p[j];
-        }
-        pcr_levels_L<NR, L, RF * 2>(ld, d, ud, B, lane, xch);
-    }
-}
-
-// PCR solve, interleaved layout, L >= 128 (the final pairs i, i+L/2 sit in lanes l, l^32).
-template <int NR, int L>
-__device__ __forceinline__ void pcr_solve_L(double (&ld)[NR], double (&d)[NR], double (&ud)[NR], double (&B)[NR],
-                                            double (&x)[NR], int lane, double *xch)
-{
-    pcr_levels_L<NR, L, 1>(ld, d, ud, B, lane, xch);
-    // final 2x2 solves (pvSimPCR.py:75-79) between lanes l and l^32, by Cramer's rule so that each
-    // lane computes only its own unknown with ONE reciprocal:
-    //     [ d_lo  ud_lo ] [x_lo]   [B_lo]        x_own = (B_own d_oth - c_own B_oth) / (d_own d_oth - c_own c_oth)
-    //     [ ld_hi d_hi  ] [x_hi] = [B_hi]        c = coupling to the partner row (ud for the lower, ld for the upper)
-    // v_permlane32_swap delivers the partner's values on the VALU (the LDS is the scarcer resource).
-    const bool low = lane < 32;
-    double det[NR], num[NR], rdet[NR];
-#pragma unroll
-    for (int j = 0; j < NR; j++) {
-        const double c_own = low ? +ud[j] : +ld[j];
-        double d_oth, B_oth, c_oth;
-        if constexpr ((TRPL_ABLATE & 1) != 0) {
-            d_oth = d[j] * 1.5; B_oth = -B[j]; c_oth = c_own;
-        } else {
-            double lo_h, hi_h;
-            pair32(d[j], lo_h, hi_h);  d_oth = low ? hi_h : lo_h;
-            pair32(B[j], lo_h, hi_h);  B_oth = low ? hi_h : lo_h;
-            pair32(c_own, lo_h, hi_h); c_oth = low ? hi_h : lo_h;
-        }
-        det[j] = d[j] * d_oth - c_own * c_oth;
-        num[j] = B[j] * d_oth - c_own * B_oth;
-    }
-    rcp_rows<NR>(det, rdet);
-#pragma unroll
-    for (int j = 0; j < NR; j++) x[j] = num[j] * rdet[j];
-}
 
 // ---- layout dispatch: LAY 0 = blocked/strict, 1 = blocked/fast (L < 128), 2 = interleaved/fast ----
 template <int LAY, int NR, int W>
