@@ -54,10 +54,24 @@ SIGNATURES = {
 _lib = None
 
 
+def _build_if_missing():
+    """A fresh checkout has no shared object (it is git-ignored): build the HIP library in-tree with
+    the package Makefile when hipcc is present.  This is a build step, not a fallback -- the result
+    is the same gfx950 library; set TRPL_AUTOBUILD=0 to forbid it."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if os.path.isfile("/opt/rocm/bin/hipcc") else None)
+    if os.environ.get("TRPL_AUTOBUILD", "1") == "0" or hipcc is None or "TRPL_LIBRARY" in os.environ:
+        return
+    subprocess.check_call(["make", "-s", "-j4", "-C", _HERE, "libtrpl_hip.so", "HIPCC=" + hipcc])
+
+
 def lib():
-    """Load libtrpl_hip.so once; raise loudly if it has not been built."""
+    """Load libtrpl_hip.so once; raise loudly if it is absent and cannot be built."""
     global _lib
     if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            _build_if_missing()
         if not os.path.isfile(LIB_PATH):
             raise ImportError("%s not found: build it with `make -C %s` (hipcc, gfx950); "
                               "there is no CPU fallback" % (LIB_PATH, _HERE))
