@@ -22,6 +22,9 @@
 #ifndef TRPL_ABLATE
 #define TRPL_ABLATE 0
 #endif
+#ifndef TRPL_CR_HYBRID
+#define TRPL_CR_HYBRID 1      // L = 128 fast solve: in-lane cyclic-reduction step + PCR on 64 unknowns
+#endif
 #ifndef TRPL_RCP_PAIR
 #define TRPL_RCP_PAIR 1       // pair reciprocals (rcp_rows); 0 only for A/B measurements
 #endif

@@ -64,6 +64,7 @@ __device__ __forceinline__ void solve_lay(double (&ld)[NR], double (&d)[NR], dou
 {
     if constexpr (LAY == 0) pcr_solve<double, NR, W, L>(ld, d, ud, B, x, ln);
     else if constexpr (LAY == 1) pcr_solve_fast<double, NR, W, L>(ld, d, ud, B, x, ln);
+    else if constexpr (NR == 2 && TRPL_CR_HYBRID != 0) pcr_solve_cr128(ld, d, ud, B, x, ln, xch);
     else pcr_solve_L<NR, L>(ld, d, ud, B, x, ln, xch);
 }
 
