@@ -347,7 +347,8 @@ __global__ void __launch_bounds__(64, (STRICT || L > 128) ? (L > 256 ? 1 : 2) : 
     // then overwrites the oldest with U^t (8 KB per wave for L = 128); E's stay in registers so
     // that ring + 3 KB PCR exchange buffer leave room for 3 waves per SIMD (12 x 11 KB <= 160 KB).
     constexpr int HSLOT = 2 * NR * 64;              // N and P; the E history stays in registers
-    __shared__ __attribute__((aligned(16))) double lds[STRICT ? 2 : 4 * HSLOT + (LAY == 2 ? 3 * L : 2)];
+    constexpr int XCH = LAY != 2 ? 2 : ((NR == 2 && TRPL_CR_HYBRID != 0) ? 3 * 64 : 3 * L);   // PCR exchange buffer, doubles
+    __shared__ __attribute__((aligned(16))) double lds[STRICT ? 2 : 4 * HSLOT + XCH];
     double *hist = lds;
     double *xch = lds + (STRICT ? 0 : 4 * HSLOT);   // PCR exchange buffer (LAY 2)
     const int hl = threadIdx.x;                     // this lane's column of the ring
