@@ -4,8 +4,8 @@
 //   pcr_solve_fast  FAST, blocked layout (L < 128): normalised rows, Newton-refined reciprocals
 //   pcr_solve_L     FAST, interleaved layout (L >= 128): as above + exchange staged through LDS for
 //                   lane shifts >= 2, DPP for shifts <= 1, v_permlane32_swap + Cramer for the final pairs
-//   pcr_solve_cr128 FAST, L = 128: one in-lane cyclic-reduction step, then the same PCR on 64 unknowns
-//                   (one row per lane), back-substitution -- the production path of the benchmark config
+//   cr_pcr_solve    FAST, L >= 128, fp64 or fp32: log2(NR) in-lane cyclic-reduction levels, then PCR on
+//                   64 unknowns (one row per lane), back-substitution -- the production path
 #pragma once
 #include "crosslane.hpp"
 
@@ -305,80 +305,131 @@ __device__ __forceinline__ void pcr_solve_L(double (&ld)[NR], double (&d)[NR], d
     for (int j = 0; j < NR; j++) x[j] = num[j] * rdet[j];
 }
 
-// FAST solve for L = 128 (two adjacent rows per lane): ONE IN-LANE CYCLIC-REDUCTION STEP, THEN PCR ON
-// 64 UNKNOWNS.  Lane l holds rows e = 2l and o = 2l+1.  The odd unknowns are eliminated from the
-// even equations (x_o = b_o - a_o x_{o-1} - c_o x_{o+1} after normalising the odd row by 1/d_o; the
-// odd row of lane l-1 comes by one DPP rotate), leaving a tridiagonal system in X_l = x_{2l} with one
-// row per lane:
-//     A_l = -a_e a^_{e-1},  C_l = -c_e c^_{e+1},  D_l = d_e - a_e c^_{e-1} - c_e a^_{e+1},
-//     B_l = b_e - a_e b^_{e-1} - c_e b^_{e+1}
-// PCR then needs 5 levels (lane shifts 1..16) + the lane^32 pairing on ONE row per lane instead of 6
-// levels on two, and x_o follows by back-substitution.  Same solution as the reference's pure PCR
-// up to rounding (both are exact eliminations of a diagonally dominant system); ~40 % fewer solve
-// flops and half the LDS exchange bytes.  The corner coefficients stay exact zeros (a_0 = 0 and
-// c_{L-1} = 0 propagate), so wrapped neighbour values drop out as in pcr_levels_L.
-__device__ __forceinline__ void xch1_store(double *xch, int arr, int lane, double v) { xch[arr * 64 + lane] = v; }
-__device__ __forceinline__ double xch1_load(const double *xch, int arr, int lane) { return xch[arr * 64 + lane]; }
+// FAST solve for L >= 128, interleaved layout (lane l holds the NR = 2^k adjacent rows NR*l .. NR*l+NR-1):
+// k IN-LANE CYCLIC-REDUCTION LEVELS, THEN PCR ON 64 UNKNOWNS, THEN BACK-SUBSTITUTION.
+//   forward, level h = 1, 2, .. NR/2: rows j = h (mod 2h) are normalised by 1/d and eliminated from
+//     the rows j = 0 (mod 2h):  with L = row j-h and R = row j+h (normalised: a^, c^, b^)
+//         A_j = -a_j a^_L,  C_j = -c_j c^_R,  D_j = d_j - a_j c^_L - c_j a^_R,  B_j = b_j - a_j b^_L - c_j b^_R
+//     everything is in-lane except L of row 0, which is row NR-h of lane l-1 (one DPP rotate);
+//   PCR on the remaining row 0 of every lane: 5 levels (lane shifts 1..16: DPP for 1, 8 bytes per
+//     lane through LDS for the rest) + the lane^32 pairs by Cramer's rule;
+//   backward: x_j = b^_j - a^_j x_{j-h} - c^_j x_{j+h}, where x_{NR} is row 0 of lane l+1 (one DPP).
+// Versus pure PCR (log2(L)-1 levels on NR rows per lane) this is (NR-1) eliminations + 6 one-row
+// levels: ~40 % fewer solve flops at L = 128, ~4x fewer at L = 512, and the LDS only ever carries
+// one value per lane.  Same solution as the reference's PCR up to rounding (both are exact
+// eliminations of a diagonally dominant system).  The corner coefficients stay exact zeros (a of
+// row 0 and c of row L-1 propagate), so wrapped neighbour values drop out.
+template <typename T> __device__ __forceinline__ T rcp_fast(T d);
+template <> __device__ __forceinline__ double rcp_fast<double>(double d) { return rcp_nr1(d); }
+template <> __device__ __forceinline__ float rcp_fast<float>(float d)
+{
+    const float r = __builtin_amdgcn_rcpf(d);      // v_rcp_f32 (1 ulp) + one Newton step
+    return __builtin_fmaf(r, __builtin_fmaf(-d, r, 1.0f), r);
+}
 
-template <int S>
-__device__ __forceinline__ void pcr64_levels(double &A, double &D, double &C, double &Bv, int lane, double *xch)
+// value held by lane ^ 32
+__device__ __forceinline__ double partner32(double v, bool low)
+{
+    double lo_h, hi_h;
+    pair32(v, lo_h, hi_h);
+    return low ? hi_h : lo_h;
+}
+__device__ __forceinline__ float partner32(float v, bool low)
+{
+    const unsigned a = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);   // r[0] = (lo,lo), r[1] = (hi,hi)
+    return __builtin_bit_cast(float, low ? r[1] : r[0]);
+}
+
+template <typename T, int S>
+__device__ __forceinline__ void pcr64_levels(T &A, T &D, T &C, T &Bv, int lane, T *xch)
 {
     if constexpr (S < 32) {
-        const double r = rcp_nr1(D);
-        const double nA = A * r, nC = C * r, nB = Bv * r;
-        double Am, Cm, Bm, Ap, Cp, Bp;
+        const T r = rcp_fast<T>(D);
+        const T nA = A * r, nC = C * r, nB = Bv * r;
+        T Am, Cm, Bm, Ap, Cp, Bp;
         if constexpr ((TRPL_ABLATE & 1) != 0 && S > 1) {
             Am = nA; Cm = nC; Bm = nB; Ap = nC; Cp = nA; Bp = -nB;
         } else if constexpr (S == 1) {             // DPP wave rotates
             Am = lane_dn<1>(nA, lane); Cm = lane_dn<1>(nC, lane); Bm = lane_dn<1>(nB, lane);
             Ap = lane_up<1>(nA, lane); Cp = lane_up<1>(nC, lane); Bp = lane_up<1>(nB, lane);
-        } else {                                   // staged through LDS, 8 bytes per lane
-            xch1_store(xch, 0, lane, nA);
-            xch1_store(xch, 1, lane, nC);
-            xch1_store(xch, 2, lane, nB);
+        } else {                                   // staged through LDS, one value per lane and array
+            xch[0 * 64 + lane] = nA;
+            xch[1 * 64 + lane] = nC;
+            xch[2 * 64 + lane] = nB;
             const int dn = (lane - S) & 63, up = (lane + S) & 63;
-            Am = xch1_load(xch, 0, dn); Cm = xch1_load(xch, 1, dn); Bm = xch1_load(xch, 2, dn);
-            Ap = xch1_load(xch, 0, up); Cp = xch1_load(xch, 1, up); Bp = xch1_load(xch, 2, up);
+            Am = xch[0 * 64 + dn]; Cm = xch[1 * 64 + dn]; Bm = xch[2 * 64 + dn];
+            Ap = xch[0 * 64 + up]; Cp = xch[1 * 64 + up]; Bp = xch[2 * 64 + up];
         }
         D = D - A * Cm - C * Ap;
         Bv = Bv - A * Bm - C * Bp;
         A = -A * Am;
         C = -C * Cp;
-        pcr64_levels<S * 2>(A, D, C, Bv, lane, xch);
+        pcr64_levels<T, S * 2>(A, D, C, Bv, lane, xch);
     }
 }
 
-__device__ __forceinline__ void pcr_solve_cr128(double (&ld)[2], double (&d)[2], double (&ud)[2], double (&B)[2],
-                                                double (&x)[2], int lane, double *xch)
+// one forward cyclic-reduction level with in-lane stride H (rows H, 3H, .. eliminated)
+template <typename T, int NR, int H>
+__device__ __forceinline__ void cr_forward(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], int lane)
 {
-    // 1. normalised odd row of this lane and of lane-1
-    const double ro = rcp_nr1(d[1]);
-    const double ao = ld[1] * ro, co = ud[1] * ro, bo = B[1] * ro;
-    const double am = lane_dn<1>(ao, lane), cm = lane_dn<1>(co, lane), bm = lane_dn<1>(bo, lane);
-    // 2. the even equations with the odd unknowns eliminated
-    double A = -ld[0] * am;
-    double C = -ud[0] * co;
-    double D = d[0] - ld[0] * cm - ud[0] * ao;
-    double Bv = B[0] - ld[0] * bm - ud[0] * bo;
-    // 3. PCR on the 64 even unknowns: lane shifts 1..16, then the lane^32 pairs by Cramer's rule
-    pcr64_levels<1>(A, D, C, Bv, lane, xch);
-    const bool low = lane < 32;
-    const double c_own = low ? C : A;
-    double D_oth, B_oth, c_oth;
-    if constexpr ((TRPL_ABLATE & 1) != 0) {
-        D_oth = D * 1.5; B_oth = -Bv; c_oth = c_own;
-    } else {
-        double lo_h, hi_h;
-        pair32(D, lo_h, hi_h);     D_oth = low ? hi_h : lo_h;
-        pair32(Bv, lo_h, hi_h);    B_oth = low ? hi_h : lo_h;
-        pair32(c_own, lo_h, hi_h); c_oth = low ? hi_h : lo_h;
+    if constexpr (H < NR) {
+        // normalise the eliminated rows in place: (ld, ud, B)[q] become (a^, c^, b^)
+#pragma unroll
+        for (int q = H; q < NR; q += 2 * H) {
+            const T r = rcp_fast<T>(d[q]);
+            ld[q] *= r; ud[q] *= r; B[q] *= r;
+        }
+        // the left neighbour of row 0 is row NR-H of lane l-1
+        const T aL0 = lane_dn<1>(ld[NR - H], lane), cL0 = lane_dn<1>(ud[NR - H], lane), bL0 = lane_dn<1>(B[NR - H], lane);
+#pragma unroll
+        for (int p = 0; p < NR; p += 2 * H) {
+            const T aL = p == 0 ? aL0 : ld[p == 0 ? 0 : p - H], cL = p == 0 ? cL0 : ud[p == 0 ? 0 : p - H],
+                    bL = p == 0 ? bL0 : B[p == 0 ? 0 : p - H];
+            const T aR = ld[p + H], cR = ud[p + H], bR = B[p + H];
+            const T a = ld[p], c = ud[p];
+            d[p] = d[p] - a * cL - c * aR;
+            B[p] = B[p] - a * bL - c * bR;
+            ld[p] = -a * aL;
+            ud[p] = -c * cR;
+        }
+        cr_forward<T, NR, 2 * H>(ld, d, ud, B, lane);
     }
-    const double X = (Bv * D_oth - c_own * B_oth) * rcp_nr1(D * D_oth - c_own * c_oth);
-    // 4. back-substitution of the odd unknown: x_o = b^_o - a^_o x_{2l} - c^_o x_{2l+2}
-    const double Xp = lane_up<1>(X, lane);         // lane 63 receives a wrapped value times c^_{L-1} = 0
-    x[0] = X;
-    x[1] = bo - ao * X - co * Xp;
 }
 
+// back-substitution of the rows eliminated at stride H (after all coarser levels); xnext = row 0 of lane l+1
+template <typename T, int NR, int H>
+__device__ __forceinline__ void cr_backward(const T (&ld)[NR], const T (&ud)[NR], const T (&B)[NR], T (&x)[NR], T xnext)
+{
+    if constexpr (H >= 1) {
+#pragma unroll
+        for (int q = H; q < NR; q += 2 * H) {
+            const T xr = q + H < NR ? x[q + H < NR ? q + H : 0] : xnext;
+            x[q] = B[q] - ld[q] * x[q - H] - ud[q] * xr;
+        }
+        cr_backward<T, NR, H / 2>(ld, ud, B, x, xnext);
+    }
+}
+
+template <typename T, int NR>
+__device__ __forceinline__ void cr_pcr_solve(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], T (&x)[NR], int lane,
+                                             T *xch)
+{
+    cr_forward<T, NR, 1>(ld, d, ud, B, lane);
+    T A = ld[0], D = d[0], C = ud[0], Bv = B[0];
+    pcr64_levels<T, 1>(A, D, C, Bv, lane, xch);
+    const bool low = lane < 32;                    // lane^32 pairs by Cramer's rule, own unknown only
+    const T c_own = low ? C : A;
+    T D_oth, B_oth, c_oth;
+    if constexpr ((TRPL_ABLATE & 1) != 0) {
+        D_oth = D * T(1.5); B_oth = -Bv; c_oth = c_own;
+    } else {
+        D_oth = partner32(D, low); B_oth = partner32(Bv, low); c_oth = partner32(c_own, low);
+    }
+    const T X = (Bv * D_oth - c_own * B_oth) * rcp_fast<T>(D * D_oth - c_own * c_oth);
+    x[0] = X;
+    const T xnext = lane_up<1>(X, lane);           // lane 63 receives a wrapped value times c^ = 0
+    cr_backward<T, NR, NR / 2>(ld, ud, B, x, xnext);
+}
 
 }  // namespace trpl

@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(256) pcr_batched_kernel(const T *__restrict__ 
                 const int64_t o = base + NR * lane + j;
                 vl[j] = ld[o]; vd[j] = d[o]; vu[j] = ud[o]; vb[j] = b[o];
             }
-            if constexpr (sizeof(T) == 8 && NR == 2 && TRPL_CR_HYBRID != 0) pcr_solve_cr128(vl, vd, vu, vb, vx, lane, xch);
+            if constexpr (TRPL_CR_HYBRID != 0) cr_pcr_solve<T, NR>(vl, vd, vu, vb, vx, lane, xch);
             else if constexpr (sizeof(T) == 8) pcr_solve_L<NR, L>(vl, vd, vu, vb, vx, lane, xch);
             else                          f32::pcr_solve<NR, L>(vl, vd, vu, vb, vx, lane, xch);
 #pragma unroll

@@ -43,14 +43,6 @@ __device__ __forceinline__ void xload(const float *xch, int arr, int node0, floa
     for (int j = 0; j < NR; j++) y[j] = t.v[j];
 }
 
-__device__ __forceinline__ float partner32(float v)       // value held by lane ^ 32
-{
-    const unsigned a = __builtin_bit_cast(unsigned, v);
-    const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
-    // r[0] = (lo,lo) halves, r[1] = (hi,hi): the other half's value is r[1] in low lanes, r[0] in high lanes
-    return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
-}
-
 template <int NR, int L, int RF>
 __device__ __forceinline__ void pcr_levels(float (&ld)[NR], float (&d)[NR], float (&ud)[NR], float (&B)[NR], int lane,
                                            float *xch)
@@ -102,7 +94,7 @@ __device__ __forceinline__ void pcr_solve(float (&ld)[NR], float (&d)[NR], float
 #pragma unroll
     for (int j = 0; j < NR; j++) {
         const float c_own = low ? +ud[j] : +ld[j];
-        const float d_oth = partner32(d[j]), B_oth = partner32(B[j]), c_oth = partner32(c_own);
+        const float d_oth = partner32(d[j], low), B_oth = partner32(B[j], low), c_oth = partner32(c_own, low);
         const float det = d[j] * d_oth - c_own * c_oth;
         x[j] = (B[j] * d_oth - c_own * B_oth) * rcp1(det);
     }
@@ -185,7 +177,7 @@ __global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
 {
     constexpr int NR = L / 64;
     constexpr int HSLOT = 2 * NR * 64;
-    __shared__ __attribute__((aligned(16))) float lds[4 * HSLOT + 3 * L];
+    __shared__ __attribute__((aligned(16))) float lds[4 * HSLOT + 3 * 64];
     float *hist = lds, *xch = lds + 4 * HSLOT;
     const int lane = threadIdx.x;
     const int64_t sys = blockIdx.x;
@@ -263,10 +255,10 @@ __global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
             nbrB_up<float, NR, 1>(Ek, Ep, lane);
             assemble<true, NR, L>(mp, a0, Nk, Pk, Ek, Ep, bN, lo_, dg, up, bb, lane);
             const bool okN = residual_below<NR>(lo_, dg, up, bb, Nk, TOL, lane);
-            pcr_solve<NR, L>(lo_, dg, up, bb, Nk, lane, xch);
+            cr_pcr_solve<float, NR>(lo_, dg, up, bb, Nk, lane, xch);
             assemble<false, NR, L>(mp, a0, Nk, Pk, Ek, Ep, bP, lo_, dg, up, bb, lane);
             const bool okP = residual_below<NR>(lo_, dg, up, bb, Pk, TOL, lane);
-            pcr_solve<NR, L>(lo_, dg, up, bb, Pk, lane, xch);
+            cr_pcr_solve<float, NR>(lo_, dg, up, bb, Pk, lane, xch);
             update_field<NR>(mp, a0, Nk, Pk, bE, Ek, lane);
             if (okN && okP) { it = iters + 1; break; }
         }

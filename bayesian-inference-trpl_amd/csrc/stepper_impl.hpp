@@ -64,7 +64,7 @@ __device__ __forceinline__ void solve_lay(double (&ld)[NR], double (&d)[NR], dou
 {
     if constexpr (LAY == 0) pcr_solve<double, NR, W, L>(ld, d, ud, B, x, ln);
     else if constexpr (LAY == 1) pcr_solve_fast<double, NR, W, L>(ld, d, ud, B, x, ln);
-    else if constexpr (NR == 2 && TRPL_CR_HYBRID != 0) pcr_solve_cr128(ld, d, ud, B, x, ln, xch);
+    else if constexpr (TRPL_CR_HYBRID != 0) cr_pcr_solve<double, NR>(ld, d, ud, B, x, ln, xch);
     else pcr_solve_L<NR, L>(ld, d, ud, B, x, ln, xch);
 }
 
@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(64, (STRICT || L > 128) ? (L > 256 ? 1 : 2) : 
     // then overwrites the oldest with U^t (8 KB per wave for L = 128); E's stay in registers so
     // that ring + 3 KB PCR exchange buffer leave room for 3 waves per SIMD (12 x 11 KB <= 160 KB).
     constexpr int HSLOT = 2 * NR * 64;              // N and P; the E history stays in registers
-    constexpr int XCH = LAY != 2 ? 2 : ((NR == 2 && TRPL_CR_HYBRID != 0) ? 3 * 64 : 3 * L);   // PCR exchange buffer, doubles
+    constexpr int XCH = LAY != 2 ? 2 : (TRPL_CR_HYBRID != 0 ? 3 * 64 : 3 * L);   // PCR exchange buffer, doubles
     __shared__ __attribute__((aligned(16))) double lds[STRICT ? 2 : 4 * HSLOT + XCH];
     double *hist = lds;
     double *xch = lds + (STRICT ? 0 : 4 * HSLOT);   // PCR exchange buffer (LAY 2)
