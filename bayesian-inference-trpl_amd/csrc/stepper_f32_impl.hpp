@@ -265,7 +265,10 @@ __global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
         itot += it;
         if (it >= MAX) { status = 1 + (int)t; break; }
 
-        if (pl_step) sink.emit(t, plv);
+        if (pl_step) {
+            if (sink.interp) sink.emit(t, plv);
+            else sink.push(t, plv);
+        }
 #pragma unroll
         for (int j = 0; j < NR; j++) {
 #pragma unroll
@@ -274,6 +277,10 @@ __global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
         }
     }
 
+    if (!sink.interp) {
+        const int64_t done = status ? (int64_t)(status - 1) : sink.t_last + 1;
+        sink.flush_batch((int)((done + a.plT - 1) / a.plT - sink.base));
+    }
     sink.finish(status, itot);
 }
 

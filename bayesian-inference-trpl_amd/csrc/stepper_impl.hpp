@@ -116,6 +116,9 @@ struct PlSink {
     double mag, lg_prev = 0.0, sse = 0.0, pl0_d = 1.0;
     float pl0_f = 1.0f;
     bool want_pl, want_ll, interp;
+    // batched emission (FAST): lane k parks column base+k; a batch of up to 64 columns is processed at once
+    double pend = 0.0;
+    int64_t base = 0;
 
     __device__ PlSink(const StepArgs &a_, const CurveConst &cc_, int c, int64_t s, double mag_)
         : a(a_), cc(cc_), orow((int64_t)c * a_.S + s), mag(mag_)
@@ -170,6 +173,58 @@ struct PlSink {
                 next_obs++;
             }
             lg_prev = lg;
+        }
+    }
+
+    // FAST-mode emission, batched over time: push() parks PL(t) in lane (col - base); every 64 columns
+    // (and at the end) flush_batch() does ONE vectorised pass for up to 64 time points -- the
+    // re-dimensionalisation, the float32 staging if requested, log10, the squared error against a
+    // coalesced load of 64 observations, a coalesced PL store -- instead of a wave-uniform fp64 log10,
+    // an IEEE divide, a scalar load and a single-lane store on every step.  The squared errors of a
+    // batch are added by a wave reduction, so the likelihood sum is associated differently from the
+    // reference's serial loop (~1e-16 relative; STRICT keeps emit()).  Not used for off-grid
+    // observation times, which need consecutive values in order (emit()).
+    __device__ __forceinline__ void push(int64_t t, double plv)
+    {
+        const int64_t col = t / a.plT;
+        if ((int64_t)threadIdx.x == col - base) pend = plv;
+        if (col - base == 63) flush_batch(64);
+    }
+
+    __device__ __forceinline__ void flush_batch(int n)      // columns base .. base+n-1, wave-uniform n in [0, 64]
+    {
+        if (n > 0) {
+            const int lane = threadIdx.x;
+            const int64_t col = base + lane;
+            const bool live = lane < n;
+            const bool f32 = (a.flags & kFlagPlF32) != 0;
+            double v;                                       // re-dimensionalised PL (pvSimPCR.py:393)
+            float vf = 0.0f;
+            if (f32) { vf = (float)pend / (float)cc.plnorm; v = (double)vf; }
+            else     { v = pend / cc.plnorm; }
+            if (want_pl && live) {                                                         // :281
+                if (a.pl_bytes == 4) ((float *)a.pl)[orow * a.pl_ld + col] = (float)pend / (float)cc.plnorm;
+                else                 ((double *)a.pl)[orow * a.pl_ld + col] = pend / cc.plnorm;
+            }
+            if (base < ncol_ll) {                           // bayeslib.py:150-157, probs.py:29-44
+                if (a.flags & kFlagNormalize) {
+                    if (base == 0) { pl0_d = uniform_d(v); pl0_f = (float)pl0_d; }
+                    if (f32) { vf = vf / pl0_f; v = (double)vf; } else { v = v / pl0_d; }
+                }
+                double lg;
+                if (f32) {
+                    if ((double)vf < DBL_MIN) vf = (float)DBL_MIN;
+                    lg = (double)(float)log10((double)vf);
+                } else {
+                    if (v < DBL_MIN) v = DBL_MIN;
+                    lg = log10(v);
+                }
+                const bool use = live && col < ncol_ll;
+                double err = lg + mag;
+                err -= obs[use ? col : 0];
+                sse += wave_sum(use ? err * err : 0.0);
+            }
+            base += n;
         }
     }
 
@@ -437,7 +492,10 @@ __global__ void __launch_bounds__(64, (STRICT || L > 128) ? (L > 256 ? 1 : 2) : 
         itot += it;
         if (it >= MAX) { status = 1 + (int)t; break; }                                     // :269-274
 
-        if (pl_step) sink.emit(t, plv);
+        if (pl_step) {
+            if (STRICT || sink.interp) sink.emit(t, plv);
+            else sink.push(t, plv);
+        }
 
 #pragma unroll
         for (int j = 0; j < NR; j++) {             // shift the register histories by one level
@@ -451,6 +509,10 @@ __global__ void __launch_bounds__(64, (STRICT || L > 128) ? (L > 256 ? 1 : 2) : 
         }
     }
 
+    if (!(STRICT || sink.interp)) {                // columns parked since the last full batch
+        const int64_t done = status ? (int64_t)(status - 1) : sink.t_last + 1;      // steps whose PL was emitted
+        sink.flush_batch((int)((done + a.plT - 1) / a.plT - sink.base));
+    }
     sink.finish(status, itot);
 }
 
