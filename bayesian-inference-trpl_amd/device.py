@@ -38,6 +38,26 @@ def loglik_device(X, init_params, lengths, Time, L, T, obs, n_obs, P, sse, statu
         None if iters_total is None else _chk(iters_total, torch.int64, "iters_total"), int(flags), _stream()))
 
 
+def loglik_obs_device(X, init_params, lengths, Time, L, T, obs, obs_hi, obs_dx, obs_h, n_obs, P, sse, status=None,
+                      iters_total=None, tol=7, MAX=10000, flags=0):
+    """trpl_loglik_obs_dev: observation times off the simulation grid.  obs / obs_dx / obs_h (C,obs_ld)
+    f64 and obs_hi (C,obs_ld) int32 are the bracketing arrays of driver.bracket_times, on the device."""
+    import torch
+    S, Cn = X.shape[0], init_params.shape[0]
+    if X.shape[1] != 13 or init_params.shape[1] != L or tuple(sse.shape) != (Cn, S) or tuple(P.shape) != (S,) \
+            or not (obs.shape == obs_hi.shape == obs_dx.shape == obs_h.shape) or obs.shape[0] != Cn:
+        raise ValueError("shape mismatch")
+    lengths = np.ascontiguousarray(np.broadcast_to(np.asarray(lengths, dtype=np.float64), (Cn,)))
+    n_obs = np.ascontiguousarray(np.broadcast_to(np.asarray(n_obs, dtype=np.int64), (Cn,)))
+    _abi.check(_abi.lib().trpl_loglik_obs_dev(
+        _chk(X, torch.float64, "X"), S, Cn, _abi.ptr(lengths), float(Time), int(L), int(T), int(tol), int(MAX),
+        _chk(init_params, torch.float64, "init_params"), _chk(obs, torch.float64, "obs"),
+        _chk(obs_hi, torch.int32, "obs_hi"), _chk(obs_dx, torch.float64, "obs_dx"), _chk(obs_h, torch.float64, "obs_h"),
+        obs.shape[1], _abi.ptr(n_obs), _chk(P, torch.float64, "P"), _chk(sse, torch.float64, "sse"),
+        None if status is None else _chk(status, torch.int32, "status"),
+        None if iters_total is None else _chk(iters_total, torch.int64, "iters_total"), int(flags), _stream()))
+
+
 def solve_pl_device(matPar, Length, Time, L, T, dN, plI, status=None, iters_total=None, tol=7, MAX=10000, plT=1,
                     flags=0):
     """trpl_solve_pl_dev: matPar (S,12) f64, dN (L,) f64, plI (S, T//plT+1) f32/f64 out."""

@@ -352,6 +352,19 @@ def test_fused_loglik_real_data_and_offgrid_times(gpu, oracle, golden):
         info = {}
         P64 = gpu.loglik(X, ini, 2000.0, Time, 128, T, v1, times=t1, strict=strict, info=info)
         assert not info["status"].any() and np.max(np.abs(P64 - want) / np.abs(want)) < tol
+    # the device-resident entry point (torch tensors) gives the same numbers as the host-buffer one
+    import torch
+    from trpl_amd import device as tdev
+    dev = torch.device("cuda", 0)
+    sim_t = np.linspace(0, Time, T + 1)
+    br = [gpu.bracket_times(sim_t, t) for t in t1]
+    n1 = len(t1[0])
+    td = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
+    Pd = torch.zeros(len(X), dtype=torch.float64, device=dev); ssed = torch.empty((3, len(X)), dtype=torch.float64, device=dev)
+    tdev.loglik_obs_device(td(X, torch.float64), td(ini, torch.float64), 2000.0, Time, 128, T, td(np.array(v1), torch.float64),
+                           td(np.array([b[0] for b in br]), torch.int32), td(np.array([b[1] for b in br]), torch.float64),
+                           td(np.array([b[2] for b in br]), torch.float64), [n1] * 3, Pd, ssed)
+    assert np.array_equal(Pd.cpu().numpy(), P64)
     # unsorted input is sorted by time; observation order does not matter beyond rounding
     perm = np.random.default_rng(0).permutation(len(t1[0]))
     Pp = gpu.loglik(X, ini, 2000.0, Time, 128, T, [v1[0][perm], v1[1], v1[2]], times=[t1[0][perm], t1[1], t1[2]])
