@@ -150,6 +150,42 @@ def test_pvsim_small_grids_plT_and_nonconvergence(gpu, golden):
     assert st[0] == 1 + t and np.isnan(pl[0, t:]).all()
 
 
+def test_fast_mode_plT_and_midrun_nonconvergence(gpu, oracle):
+    """FAST mode batches its PL output over 64 time points: check plT > 1 (columns != steps), a column
+    count that is not a multiple of 64, and a non-convergence in the middle of a run -- PL before the
+    failing step must be valid and everything from it on NaN -- against the oracle."""
+    w = gpu.workloads
+    ini, lens = w.power_scan(128)
+    X = w.samples(4)
+    T, Time = 150, 150 * 0.025
+    r = oracle.pvsim(X[:, :-1], lens[2], Time, 128, T, ini[2], plT=3, want_step_iters=True)
+    pl, st, it, _ = gpu.solve_pl(X[:, :-1], lens[2], Time, 128, T, ini[2], plT=3)
+    assert pl.shape == (4, 51) and not st.any() and relerr(pl, r["plI"]) < RTOL_FAST
+    # MAX just above the iteration count of the late steps: the early (stiffer) steps pass only for some samples
+    steps = oracle.pvsim(X[:, :-1], lens[2], Time, 128, T, ini[2], want_step_iters=True)["step_iters"]
+    MAXc = int(np.sort(steps.max(axis=1))[1]) + 1          # at least one sample exceeds it, at least one does not
+    ro = oracle.pvsim(X[:, :-1], lens[2], Time, 128, T, ini[2], MAX=MAXc)
+    assert ro["status"].any() and not ro["status"].all()
+    for dtype in (np.float64, np.float32):
+        pl, st, it, _ = gpu.solve_pl(X[:, :-1], lens[2], Time, 128, T, ini[2], MAX=MAXc, dtype=dtype)
+        assert np.array_equal(st, ro["status"])
+        for s_ in range(4):
+            t_fail = st[s_] - 1 if st[s_] else T + 1
+            good = slice(0, t_fail)
+            tol = RTOL_FAST if dtype == np.float64 else 2.0 ** -22
+            assert np.all(np.abs(pl[s_, good] / ro["plI"][s_, good] - 1) < tol)
+            assert np.isnan(pl[s_, t_fail:]).all()
+    # likelihood mode: the failing samples get -inf, the others match the oracle
+    obs = [np.log10(ro["plI"][~ro["status"].astype(bool)][0]) + 0.05]
+    info = {}
+    P = gpu.loglik(X, ini[2:3], lens[2:3], Time, 128, T, obs, MAX=MAXc, info=info)
+    assert np.array_equal(info["status"][0], ro["status"]) and np.all(np.isneginf(P[ro["status"] != 0]))
+    want = oracle.simulate_loglik(X, ini[2:3], lens[2:3], Time, 128, T, [([np.linspace(0, Time, T + 1)], obs)],
+                                  pl_dtype=np.float64, MAX=MAXc)[0]
+    ok = ro["status"] == 0
+    assert np.max(np.abs(P[ok] - want[ok]) / np.abs(want[ok])) < 1e-8
+
+
 def test_pvsim_dropin_signature(gpu, golden):
     """Called exactly the way bayeslib.simulate calls the model (bayeslib.py:144-146)."""
     g = golden("pvsim_power")
