@@ -14,6 +14,7 @@ Reference entry points exercised (file:line):
   bayeslib.random_grid :18-32, bayeslib.bayes :207-252      -> bayes_e2e.npz, sampler.npz
   pvSim_fallback.pvSim_cpu_fallback :80-117 (as shipped)    -> fallback.npz
   bayes_io.get_initpoints :106-119, get_data :15-104 + bayes -> bayes_realdata.npz
+  Legacy/pvSim.pvSim :129-173; Testing/PV_tester2.dydt :13-49 + odeint -> legacy_odeint.npz
 
 Usage:  python oracle/gen_golden.py [case ...]     (default: all cases)
 """
@@ -298,7 +299,59 @@ def case_csv_fixture():
                 w.writerow(row)
 
 
-CASES = {"csv_fixture": case_csv_fixture, "bayes_realdata": case_bayes_realdata, "pcr_norm": case_pcr_norm, "probs": case_probs, "sampler": case_sampler,
+def case_legacy_odeint():
+    """The two independent solvers the north star names as parity references, run on the same inputs
+    (Length 311 nm, L = 128, exponential excitation a = 1e18 cm^-3, l = 100 nm like Testing/pvSetup.py
+    :49-90, no Auger):
+      Legacy/pvSim.pvSim (:129-173): same discretisation, BDF2 only, Thomas solve -- identical to the
+        PCR path for PL[0..2], ~3e-4 apart afterwards (BDF order), SURVEY 8c T-C;
+      Testing/PV_tester2.dydt (:13-49) + scipy odeint as in its __main__ (:91-99) with tight
+        tolerances -- the time-converged solution of the same spatial scheme, SURVEY 8c T-D."""
+    sys.path.insert(0, os.path.join(REF, "Legacy"))
+    sys.path.insert(0, os.path.join(REF, "Testing"))
+    import io
+    import contextlib
+    import pvSim as legacy
+    import PV_tester2 as tester
+    from scipy.integrate import odeint
+    X = np.vstack([draw(2), MARK * UNIT])
+    m10 = X[:, [0, 1, 2, 3, 4, 5, 6, 9, 10, 11]]                        # no CN, CP
+    Length, L, T, dt = 311.0, 128, 240, 0.025
+    Time = T * dt
+    a_nm3, l_nm = 1e18 * 1e-21, 100.0
+    simPar = [Length, Time, L, T, 1, (0, 1), 7, 10000]
+    with contextlib.redirect_stdout(io.StringIO()):
+        itrs, (plN, plP, plE, plI) = legacy.pvSim(m10.copy(), simPar, (a_nm3, l_nm))
+    # PV_tester2's recipe, non-dimensional (its __main__ :55-99)
+    dx = Length / L
+    dx3 = dx ** 3; dtdx = dt / dx; dtdx2 = dtdx / dx
+    scales = np.array([dx3, dx3, dtdx2, dtdx2, dtdx2 / dx, dtdx, dtdx, 1 / dt, 1 / dt, 1 / dx])
+    mp = m10 * scales
+    xg = np.arange(L) + 0.5
+    dN = (a_nm3 * dx3) * np.exp(-xg / (l_nm / dx))
+    tSteps = np.linspace(0, T, T + 1)
+    pl_ode = np.zeros((len(mp), T + 1))
+    for thr in range(len(mp)):
+        y0 = np.concatenate([mp[thr, 0] + dN, mp[thr, 1] + dN, np.zeros(L + 1)])
+        # the tester halves hmax while a density is negative (:101-118), treating negatives as
+        # integration artefacts; with random parameter samples the spatial scheme itself can
+        # undershoot slightly, so time-convergence is established by two tolerance levels instead
+        sols = []
+        for rtol, atol in ((1e-8, 1e-12), (1e-10, 1e-14)):
+            data, info = odeint(tester.dydt, y0, tSteps, args=(L, *mp[thr]), tfirst=True, rtol=rtol, atol=atol, hmax=0.5,
+                                mxstep=50000, full_output=True)
+            assert info["message"] == "Integration successful."
+            sols.append(data)
+        N, P = sols[1][:, :L], sols[1][:, L:2 * L]
+        N9, P9 = sols[0][:, :L], sols[0][:, L:2 * L]
+        conv = np.max(np.abs(np.sum(N * P, axis=1) / np.sum(N9 * P9, axis=1) - 1))
+        assert conv < 1e-7, (thr, conv)
+        pl_ode[thr] = mp[thr, 4] * np.sum(N * P - mp[thr, 0] * mp[thr, 1], axis=1) / (dx ** 2 * dt)   # pvSim's units
+    np.savez_compressed(os.path.join(OUT, "legacy_odeint.npz"), X=X, length=Length, L=L, T=T, time=Time,
+                        a_nm3=a_nm3, l_nm=l_nm, plI_legacy=plI, iters_legacy=np.array(itrs), plI_odeint=pl_ode)
+
+
+CASES = {"legacy_odeint": case_legacy_odeint, "csv_fixture": case_csv_fixture, "bayes_realdata": case_bayes_realdata, "pcr_norm": case_pcr_norm, "probs": case_probs, "sampler": case_sampler,
          "pvsim_small": case_pvsim_small, "pvsim_power": case_pvsim_power,
          "pvsim_twothick": case_pvsim_twothick, "bayes_e2e": case_bayes_e2e,
          "fallback": case_fallback}

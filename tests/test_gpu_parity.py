@@ -121,6 +121,24 @@ def test_pvsim_64_random_samples_vs_oracle(gpu, oracle):
         assert np.all(np.abs(it - r["iters_total"]) <= 0.01 * r["iters_total"] + 1)
 
 
+def test_against_legacy_pvsim_and_odeint(gpu, golden):
+    """North-star parity references run by the reference itself (oracle/gen_golden.py):
+    Legacy/pvSim.pvSim -- bit-level agreement on the steps where the schemes coincide (PL[0..2]), BDF
+    order difference afterwards; PV_tester2.dydt + odeint -- the time-converged solution."""
+    g = golden("legacy_odeint")
+    X = g["X"].copy(); X[:, 7] = 0.0; X[:, 8] = 0.0
+    L, T, length, Time = int(g["L"]), int(g["T"]), float(g["length"]), float(g["time"])
+    sim_params = [length, Time, L, T, 1, (0,), 7, 10000]
+    for strict in (True, False):
+        plI = np.empty((len(X), T + 1))
+        gpu.pvSim(plI, None, None, None, X[:, :-1], sim_params, (float(g["a_nm3"]), float(g["l_nm"])),
+                  init_mode="exp", strict=strict)
+        assert np.max(np.abs(plI[:, :3] / g["plI_legacy"][:, :3] - 1)) < 1e-12
+        assert np.max(np.abs(plI / g["plI_legacy"] - 1)) < 1e-3
+        assert np.max(np.abs(plI / g["plI_odeint"] - 1)) < 2e-2
+        assert np.max(np.abs(plI[:, -1] / g["plI_odeint"][:, -1] - 1)) < 5e-4
+
+
 def test_pvsim_float32_buffer_matches_reference(gpu, golden):
     g = golden("pvsim_power")
     T = int(g["T32"])

@@ -128,3 +128,28 @@ def test_scipy_port_matches_reference_fallback(golden):
     import oracle
     mid = oracle.pvsim(X[:1, :-1], float(g["length"]), Time, 128, T, g["ini"][2])["plI"][0]
     assert 0.02 < abs(np.log10(mid[0] / g["plI"][2][0][0])) < 0.05
+
+
+def _legacy_inputs(g):
+    X = g["X"].copy()
+    X[:, 7] = 0.0; X[:, 8] = 0.0                       # the legacy solvers have no Auger terms
+    L, T, length = int(g["L"]), int(g["T"]), float(g["length"])
+    x = np.arange(L) + 0.5
+    dN = float(g["a_nm3"]) * np.exp(-x / (float(g["l_nm"]) / (length / L)))      # pvSimPCR.py:347-353 ("exp" init)
+    return X, L, T, length, float(g["time"]), dN
+
+
+def test_against_legacy_pvsim_and_odeint(oracle, golden):
+    """The two independent solvers the north star names: Legacy/pvSim.py (same scheme, BDF2 only,
+    Thomas solve: identical on the BDF1/BDF2 steps, ~4e-4 apart later) and PV_tester2.dydt + scipy
+    odeint (the time-converged solution of the same spatial scheme: first-order error on step 1,
+    ~2e-4 at the end of this 6 ns window)."""
+    g = golden("legacy_odeint")
+    X, L, T, length, Time, dN = _legacy_inputs(g)
+    r = oracle.pvsim(X[:, :-1], length, Time, L, T, dN)
+    pl = r["plI"]
+    assert np.max(np.abs(pl[:, :3] / g["plI_legacy"][:, :3] - 1)) < 1e-13
+    assert np.array_equal(r["iters_max"], g["iters_legacy"])            # the stiff step 0 takes the same iterations
+    assert np.max(np.abs(pl / g["plI_legacy"] - 1)) < 1e-3
+    assert np.max(np.abs(pl / g["plI_odeint"] - 1)) < 2e-2
+    assert np.max(np.abs(pl[:, -1] / g["plI_odeint"][:, -1] - 1)) < 5e-4
