@@ -25,6 +25,13 @@
 #ifndef TRPL_CR_HYBRID
 #define TRPL_CR_HYBRID 1      // L = 128 fast solve: in-lane cyclic-reduction step + PCR on 64 unknowns
 #endif
+#ifndef TRPL_PARTNER_BPERMUTE
+#define TRPL_PARTNER_BPERMUTE 1   // lane^32 exchange: 0 = v_permlane32_swap (VALU), 1 = ds_bpermute (LDS; +1.9 % measured:
+                                  // the VALU is the saturated unit, the LDS has slack)
+#endif
+#ifndef TRPL_PCR_S1_LDS
+#define TRPL_PCR_S1_LDS 0         // stride-1 level of the 64-unknown PCR: 0 = DPP rotates, 1 = staged through LDS
+#endif
 #ifndef TRPL_RCP_PAIR
 #define TRPL_RCP_PAIR 1       // pair reciprocals (rcp_rows); 0 only for A/B measurements
 #endif

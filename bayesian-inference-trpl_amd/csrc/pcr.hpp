@@ -328,6 +328,11 @@ template <> __device__ __forceinline__ float rcp_fast<float>(float d)
 }
 
 // value held by lane ^ 32
+#if TRPL_PARTNER_BPERMUTE
+// through the LDS crossbar: the VALU is this kernel's saturated unit (97 % busy), the LDS is not
+__device__ __forceinline__ double partner32(double v, bool) { return __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ float partner32(float v, bool) { return __shfl_xor(v, 32, 64); }
+#else
 __device__ __forceinline__ double partner32(double v, bool low)
 {
     double lo_h, hi_h;
@@ -340,6 +345,7 @@ __device__ __forceinline__ float partner32(float v, bool low)
     const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);   // r[0] = (lo,lo), r[1] = (hi,hi)
     return __builtin_bit_cast(float, low ? r[1] : r[0]);
 }
+#endif
 
 template <typename T, int S>
 __device__ __forceinline__ void pcr64_levels(T &A, T &D, T &C, T &Bv, int lane, T *xch)
@@ -350,7 +356,7 @@ __device__ __forceinline__ void pcr64_levels(T &A, T &D, T &C, T &Bv, int lane, 
         T Am, Cm, Bm, Ap, Cp, Bp;
         if constexpr ((TRPL_ABLATE & 1) != 0 && S > 1) {
             Am = nA; Cm = nC; Bm = nB; Ap = nC; Cp = nA; Bp = -nB;
-        } else if constexpr (S == 1) {             // DPP wave rotates
+        } else if constexpr (S == 1 && TRPL_PCR_S1_LDS == 0) {   // DPP wave rotates
             Am = lane_dn<1>(nA, lane); Cm = lane_dn<1>(nC, lane); Bm = lane_dn<1>(nB, lane);
             Ap = lane_up<1>(nA, lane); Cp = lane_up<1>(nC, lane); Bp = lane_up<1>(nB, lane);
         } else {                                   // staged through LDS, one value per lane and array
