@@ -227,11 +227,11 @@ __global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
 
         double plv = 0.0;
         const bool pl_step = (t % a.plT) == 0;
-        if (pl_step) {                             // midpoint PL in fp64 (pvSimPCR.py:276-281)
+        if (pl_step) {                             // midpoint PL in fp64 (pvSimPCR.py:276-281), per-node excess first
             double q = 0.0;
 #pragma unroll
-            for (int j = 0; j < NR; j++) q += (double)Nk[j] * (double)Pk[j];
-            plv = rated * (wave_sum(q) - (double)L * n0p0d);
+            for (int j = 0; j < NR; j++) q += __builtin_fma((double)Nk[j], (double)Pk[j], -n0p0d);
+            plv = rated * wave_sum(q);
         }
 
         float bN[NR], bP[NR], bE[NR], cE[NR];

@@ -436,16 +436,31 @@ __global__ void __launch_bounds__(64, (STRICT || L > 128) ? (L > 256 ? 1 : 2) : 
         else if (t == 3) { a0 = 25.0 / 12; a1 = -4.0; a2 = 3.0; a3 = -4.0 / 3; a4 = 0.25; a5 = 0.0; }
         else             { a0 = 137.0 / 60; a1 = -5.0; a2 = 5.0; a3 = -10.0 / 3; a4 = 1.25; a5 = -0.2; }
 
-        // PL of the state at time t (level k), pvSimPCR.py:276-281.  Summation order: tree
-        // instead of the reference's serial loop (documented deviation, ~1e-16 relative).
+        // PL of the state at time t (level k), pvSimPCR.py:276-281: rate * (sum_i N_i P_i - L N0 P0).
         double plv = 0.0;
         const bool pl_step = (t % a.plT) == 0;
         if (pl_step) {
-            double q[NR];
+            if constexpr (STRICT) {
+                // the reference's serial loop, node by node (:278-280), so that PL is bit-identical
+                // too (blocked layout: node i = lane + W*j)
+                double Sum = -(double)L * n0p0;
 #pragma unroll
-            for (int j = 0; j < NR; j++) q[j] = Nk[j] * Pk[j];
-            const double Sum = sum_nodes<LAY, NR, W>(q) + (-(double)L * n0p0);
-            plv = rate * Sum;
+                for (int j = 0; j < NR; j++) {
+                    const double q = Nk[j] * Pk[j];
+                    for (int l = 0; l < W; l++)
+                        Sum += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(q), l),
+                                                __builtin_amdgcn_readlane(__double2loint(q), l));
+                }
+                plv = rate * Sum;
+            } else {
+                // per-node excess N_i P_i - N0 P0 by one fma, then the sum: algebraically the same, but
+                // the cancellation happens before the accumulation, so a fully decayed system's PL is
+                // limited by the solver's state error instead of the rounding of a 128-term sum
+                double q[NR];
+#pragma unroll
+                for (int j = 0; j < NR; j++) q[j] = __builtin_fma(Nk[j], Pk[j], -n0p0);
+                plv = rate * sum_nodes<LAY, NR, W>(q);
+            }
         }
 
         // ---------------- iterate, pvSimPCR.py:93-225 ----------------

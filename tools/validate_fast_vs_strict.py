@@ -30,3 +30,13 @@ rel = np.abs(Pf[ok] - Ps[ok]) / np.abs(Ps[ok])
 print(f"S={S} T={T}: max |P_fast-P_strict|/|P_strict| = {rel.max():.3e} (median {np.median(rel):.1e}); "
       f"systems with different iteration totals: {int((itf != its).sum())} of {itf.size} "
       f"(max |diff| {int(np.abs(itf - its).max())}); total iterations ratio {itf.sum() / its.sum():.6f}")
+bad = rel > 1e-6
+print(f"samples with rel diff > 1e-6: {int(bad.sum())} of {int(ok.sum())}")
+if bad.any():
+    idx = np.where(ok)[0][bad]
+    order = np.argsort(-rel[bad])[:8]
+    Xh = X.cpu().numpy() / trpl_amd.UNIT_CONVERSIONS
+    for k in order:
+        i = idx[k]
+        print(f"  sample {i}: P_fast {Pf[i]:.6e} P_strict {Ps[i]:.6e}  tau_n {Xh[i,9]:.1f} tau_p {Xh[i,10]:.1f} Sf {Xh[i,5]:.2f} Sb {Xh[i,6]:.2f} mu_n {Xh[i,2]:.1f} p0 {Xh[i,1]:.2e}")
+    print(f"  |P| of affected samples: min {np.abs(Ps[idx]).min():.3e}, median {np.median(np.abs(Ps[idx])):.3e};  |P| of unaffected: median {np.median(np.abs(Ps[ok][~bad])):.3e}")
