@@ -381,6 +381,121 @@ int trpl_loglik_obs(const double *X, int64_t S, int32_t C, const double *lengths
                             obs_ld, n_obs, P, sse, status, iters_total, flags, device, seconds);
 }
 
+/* ------------------------------------------------------------------ multi-device -------- */
+int trpl_shard_bounds(int64_t S, int32_t n_shards, int32_t shard, int64_t *lo, int64_t *hi)
+{
+    if (S < 0 || n_shards < 1 || shard < 0 || shard >= n_shards || !lo || !hi)
+        return fail(TRPL_ERR_ARG, "shard %d of %d over S=%lld is not a valid request", shard, n_shards, (long long)S);
+    const int64_t base = S / n_shards, rem = S % n_shards;
+    *lo = shard * base + (shard < rem ? shard : rem);
+    *hi = *lo + base + (shard < rem ? 1 : 0);
+    return TRPL_OK;
+}
+
+namespace {
+struct Shard {                       // one device's share of the samples; released on its own device
+    int dev = 0;
+    int64_t lo = 0, hi = 0;
+    hipStream_t st = nullptr;
+    DevBuf X, dN, obs, ohi, odx, oh, P, sse, status, iters;
+    ~Shard()
+    {
+        (void)hipSetDevice(dev);
+        if (st) (void)hipStreamDestroy(st);
+    }
+};
+}  // namespace
+
+int trpl_loglik_multi(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns, int32_t L,
+                      int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN, const double *obs,
+                      const int32_t *obs_hi, const double *obs_dx, const double *obs_h, int64_t obs_ld,
+                      const int64_t *n_obs, double *P, double *sse, int32_t *status, int64_t *iters_total,
+                      uint32_t flags, const int32_t *devices, int32_t n_devices, double *seconds)
+{
+    if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
+    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (C < 1 || C > trpl::kMaxCurves) return fail(TRPL_ERR_ARG, "C=%d must be in [1, %d]", C, trpl::kMaxCurves);
+    if (seconds) *seconds = 0.0;
+    if (!X || !lengths_nm || !dN || !obs || !n_obs || !P) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (obs_ld < 1) return fail(TRPL_ERR_ARG, "obs_ld must be >= 1");
+    const bool interp = obs_hi || obs_dx || obs_h;
+    if (interp && !(obs_hi && obs_dx && obs_h)) return fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h go together");
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) return fail(TRPL_ERR_NODEVICE, "no HIP device visible");
+    if (n_devices <= 0) {
+        if (devices) return fail(TRPL_ERR_ARG, "a device list needs n_devices >= 1");
+        n_devices = visible;
+    }
+    if (n_devices > 64) return fail(TRPL_ERR_ARG, "n_devices=%d exceeds 64", n_devices);
+    for (int r = 0; devices && r < n_devices; r++)
+        if (devices[r] < 0 || devices[r] >= visible)
+            return fail(TRPL_ERR_ARG, "devices[%d]=%d out of range (%d visible)", r, devices[r], visible);
+    if (S == 0) return TRPL_OK;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+
+    std::vector<Shard> sh(n_devices);
+    const size_t nobs = (size_t)C * obs_ld;
+    const double t0 = now_s();
+    int rc = TRPL_OK;
+    // enqueue everything on every device before waiting for any of them
+    for (int r = 0; r < n_devices && rc == TRPL_OK; r++) {
+        Shard &q = sh[r];
+        q.dev = devices ? devices[r] : r;
+        (void)trpl_shard_bounds(S, n_devices, r, &q.lo, &q.hi);
+        const int64_t n = q.hi - q.lo;
+        if (n == 0) continue;
+        const size_t nsys = (size_t)n * C;
+        rc = [&]() -> int {
+            HIP_TRY(hipSetDevice(q.dev));
+            HIP_TRY(hipStreamCreateWithFlags(&q.st, hipStreamNonBlocking));
+            HIP_TRY(q.X.alloc((size_t)n * 13 * 8)); HIP_TRY(q.dN.alloc((size_t)C * L * 8)); HIP_TRY(q.obs.alloc(nobs * 8));
+            HIP_TRY(q.P.alloc((size_t)n * 8)); HIP_TRY(q.sse.alloc(nsys * 8)); HIP_TRY(q.status.alloc(nsys * 4));
+            HIP_TRY(q.iters.alloc(nsys * 8));
+            HIP_TRY(hipMemcpyAsync(q.X.p, X + q.lo * 13, (size_t)n * 13 * 8, hipMemcpyHostToDevice, q.st));
+            HIP_TRY(hipMemcpyAsync(q.dN.p, dN, (size_t)C * L * 8, hipMemcpyHostToDevice, q.st));
+            HIP_TRY(hipMemcpyAsync(q.obs.p, obs, nobs * 8, hipMemcpyHostToDevice, q.st));
+            HIP_TRY(hipMemcpyAsync(q.P.p, P + q.lo, (size_t)n * 8, hipMemcpyHostToDevice, q.st));
+            if (interp) {
+                HIP_TRY(q.ohi.alloc(nobs * 4)); HIP_TRY(q.odx.alloc(nobs * 8)); HIP_TRY(q.oh.alloc(nobs * 8));
+                HIP_TRY(hipMemcpyAsync(q.ohi.p, obs_hi, nobs * 4, hipMemcpyHostToDevice, q.st));
+                HIP_TRY(hipMemcpyAsync(q.odx.p, obs_dx, nobs * 8, hipMemcpyHostToDevice, q.st));
+                HIP_TRY(hipMemcpyAsync(q.oh.p, obs_h, nobs * 8, hipMemcpyHostToDevice, q.st));
+            }
+            if (int e = loglik_dev_impl(q.X.as<double>(), n, C, lengths_nm, time_ns, L, T, plT, tol_exp, max_iter,
+                                        q.dN.as<double>(), q.obs.as<double>(), interp ? q.ohi.as<int32_t>() : nullptr,
+                                        interp ? q.odx.as<double>() : nullptr, interp ? q.oh.as<double>() : nullptr,
+                                        obs_ld, n_obs, q.P.as<double>(), q.sse.as<double>(), q.status.as<int32_t>(),
+                                        q.iters.as<int64_t>(), flags, q.st))
+                return e;
+            HIP_TRY(hipMemcpyAsync(P + q.lo, q.P.p, (size_t)n * 8, hipMemcpyDeviceToHost, q.st));
+            // per-curve outputs are [C][S] on the host and [C][n] on the device: one strided copy each
+            if (sse)
+                HIP_TRY(hipMemcpy2DAsync(sse + q.lo, (size_t)S * 8, q.sse.p, (size_t)n * 8, (size_t)n * 8, C,
+                                         hipMemcpyDeviceToHost, q.st));
+            if (status)
+                HIP_TRY(hipMemcpy2DAsync(status + q.lo, (size_t)S * 4, q.status.p, (size_t)n * 4, (size_t)n * 4, C,
+                                         hipMemcpyDeviceToHost, q.st));
+            if (iters_total)
+                HIP_TRY(hipMemcpy2DAsync(iters_total + q.lo, (size_t)S * 8, q.iters.p, (size_t)n * 8, (size_t)n * 8, C,
+                                         hipMemcpyDeviceToHost, q.st));
+            return TRPL_OK;
+        }();
+    }
+    // drain every stream that was started, also after a failure (the host buffers are borrowed)
+    for (int r = 0; r < n_devices; r++) {
+        if (!sh[r].st) continue;
+        hipError_t e = hipSetDevice(sh[r].dev);
+        if (e == hipSuccess) e = hipStreamSynchronize(sh[r].st);
+        if (e != hipSuccess && rc == TRPL_OK)
+            rc = fail(TRPL_ERR_HIP, "device %d (shard %d): %s", sh[r].dev, r, hipGetErrorString(e));
+    }
+    if (seconds) *seconds = now_s() - t0;
+    sh.clear();
+    (void)hipSetDevice(prev);
+    return rc;
+}
+
 /* ------------------------------------------------------------------ batched PCR --------- */
 int trpl_pcr_solve_batched_dev(const void *ld, const void *d, const void *ud, const void *b, void *x, int64_t S,
                                int32_t L, int32_t elem_bytes, uint32_t flags, void *stream)

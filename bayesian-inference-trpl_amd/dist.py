@@ -10,7 +10,8 @@ import numpy as np
 
 
 def shard_bounds(S, world, rank):
-    """[lo, hi) of rank's contiguous share of S samples; the first S % world ranks get one more."""
+    """[lo, hi) of rank's contiguous share of S samples; the first S % world ranks get one more
+    (the same rule as trpl_shard_bounds in the C ABI, which trpl_loglik_multi shards by)."""
     if not 0 <= rank < world:
         raise ValueError("rank %d outside world %d" % (rank, world))
     base, rem = divmod(int(S), int(world))

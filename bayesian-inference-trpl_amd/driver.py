@@ -69,14 +69,16 @@ def bracket_times(sim_t, times):
 
 
 def loglik(X, init_params, lengths, Time, L, T, obs, tol=7, MAX=10000, plT=1, P=None, pl_f32=False,
-           normalize=False, strict=False, device=0, info=None, times=None, fp32=False):
-    """Fused likelihood of one experiment (trpl_loglik / trpl_loglik_obs).
+           normalize=False, strict=False, device=0, info=None, times=None, fp32=False, devices=None):
+    """Fused likelihood of one experiment (trpl_loglik / trpl_loglik_obs / trpl_loglik_multi).
 
     X (S,13) solver units; init_params (C,L) nm^-3; lengths scalar or (C,); obs = list of C
     arrays of log10 observations.  With times=None they sit on the first len(obs[c])
     simulation-grid points; otherwise times = list of C arrays of observation times in
     [0, Time] (any spacing), interpolated like the reference does (bayeslib.py:184-191).
     Accumulates into P (S,) if given (like probs.prob), else starts from zeros.  Returns P.
+    devices: None = the single `device`; "all" = every visible device; or a list of device ordinals
+    (contiguous sample shards, one per entry, run concurrently from this host thread).
     """
     X = np.ascontiguousarray(X, dtype=np.float64)
     if X.ndim != 2 or X.shape[1] != 13:
@@ -123,7 +125,21 @@ def loglik(X, init_params, lengths, Time, L, T, obs, tol=7, MAX=10000, plT=1, P=
         | (_abi.FLAG_NORMALIZE if normalize else 0) | (_abi.FLAG_FP32 if fp32 else 0)
     sec = _abi.C.c_double(0.0)
     lib = _abi.lib()
-    if times is None:
+    if devices is not None:
+        dev = None if isinstance(devices, str) else np.ascontiguousarray(devices, dtype=np.int32)
+        if isinstance(devices, str) and devices != "all":
+            raise ValueError("devices must be None, 'all' or a list of device ordinals")
+        if dev is not None and (dev.ndim != 1 or len(dev) < 1):
+            raise ValueError("devices must name at least one device")
+        off = times is not None
+        rc = lib.trpl_loglik_multi(_abi.ptr(X), S, Cn, _abi.ptr(lengths), float(Time), int(L), int(T), int(plT),
+                                   int(tol), int(MAX), _abi.ptr(ini), _abi.ptr(obs_mat),
+                                   _abi.ptr(hi_mat) if off else None, _abi.ptr(dx_mat) if off else None,
+                                   _abi.ptr(h_mat) if off else None, obs_ld, _abi.ptr(n_obs), _abi.ptr(P),
+                                   _abi.ptr(sse), _abi.ptr(status), _abi.ptr(iters), flags,
+                                   None if dev is None else _abi.ptr(dev), 0 if dev is None else len(dev),
+                                   _abi.C.byref(sec))
+    elif times is None:
         rc = lib.trpl_loglik(_abi.ptr(X), S, Cn, _abi.ptr(lengths), float(Time), int(L), int(T), int(plT), int(tol),
                              int(MAX), _abi.ptr(ini), _abi.ptr(obs_mat), obs_ld, _abi.ptr(n_obs), _abi.ptr(P),
                              _abi.ptr(sse), _abi.ptr(status), _abi.ptr(iters), flags, int(device), _abi.C.byref(sec))
@@ -145,7 +161,8 @@ def simulate(model, e_data, P, X, plI, plI_int, num_curves, sim_params, init_par
     Loop order curves -> sample blocks of gpu_info['sims_per_gpu'] (blocks gpu_id, gpu_id +
     num_gpus, ...) -> experiments; float32 PL buffer (:137); X[:, :-1] to the model and
     X[:, -1] as the log offset (:144,:195).  With gpu_info['fused'] true and every observation
-    grid a prefix of the simulation grid, each (curve-set, block, experiment) is one fused launch.
+    grid a prefix of the simulation grid, each (curve-set, block, experiment) is one fused launch
+    (spread over gpu_info['devices'] when that is given, see loglik).
     """
     group = int(gpu_info["sims_per_gpu"])
     num_gpus = int(gpu_info["num_gpus"])
@@ -179,7 +196,7 @@ def simulate(model, e_data, P, X, plI, plI_int, num_curves, sim_params, init_par
                 loglik(X[blk:blk + size], init_params, thicknesses, Time, L, T,
                        [exp[1][c] for c in range(num_curves)], tol=sim_params[6], MAX=sim_params[7],
                        P=P[e, blk:blk + size], pl_f32=(pl_dtype == np.float32), normalize=NORMALIZE,
-                       device=device, info=info,
+                       device=device, info=info, devices=gpu_info.get("devices"),
                        times=None if on_grid else [exp[0][c] for c in range(num_curves)])
                 solver_time[gpu_id] += info["seconds"]
         return

@@ -156,6 +156,32 @@ int trpl_loglik_obs_dev(const double *X, int64_t S, int32_t C, const double *len
                         double *sse, int32_t *status, int64_t *iters_total, uint32_t flags, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * trpl_loglik_multi -- trpl_loglik / trpl_loglik_obs over several devices from ONE host thread:
+ * replaces the reference's distribution of 1024-sample blocks over GPUs (bayeslib.py:131 and the
+ * commented-out threaded driver :235-246; one SLURM array task per GPU, :231).  The samples are cut
+ * into n_devices contiguous shards (trpl_shard_bounds); every shard is staged, solved and copied back
+ * on its own device and stream, all devices run concurrently, and the call returns when the host
+ * arrays P[S], sse[C][S], status[C][S], iters_total[C][S] (the last three nullable) are complete.  There is
+ * no device-to-device exchange: the systems are independent and the result lives on the host.
+ *   devices   [n_devices] HIP device ordinals (an ordinal may repeat: each entry gets its own stream),
+ *             or NULL for 0..n_devices-1;  n_devices <= 0 with devices == NULL means every visible device.
+ *   obs_hi / obs_dx / obs_h  all NULL: observations on the simulation grid (as trpl_loglik);
+ *             all non-NULL: off-grid observations (as trpl_loglik_obs, plT must be 1).
+ * Results are identical to a single-device call (each system is computed by one wavefront either way).
+ * ------------------------------------------------------------------------------------- */
+int trpl_loglik_multi(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns,
+                      int32_t L, int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter,
+                      const double *dN, const double *obs, const int32_t *obs_hi, const double *obs_dx,
+                      const double *obs_h, int64_t obs_ld, const int64_t *n_obs, double *P, double *sse,
+                      int32_t *status, int64_t *iters_total, uint32_t flags, const int32_t *devices,
+                      int32_t n_devices, double *seconds);
+
+/* [lo, hi) of shard `shard` of S samples cut into n_shards contiguous ranges; the first S % n_shards
+ * shards hold one more.  The same rule shards the samples over ranks in the one-process-per-GPU
+ * driver (bench.py, trpl_amd.dist.shard_bounds). */
+int trpl_shard_bounds(int64_t S, int32_t n_shards, int32_t shard, int64_t *lo, int64_t *hi);
+
+/* ---------------------------------------------------------------------------------------
  * trpl_pcr_solve_batched_dev -- the stand-alone batched tridiagonal solve (unit U1 of the
  * measurement plan): S independent systems  ld[i] x[i-1] + d[i] x[i] + ud[i] x[i+1] = b[i],
  * i < L, by parallel cyclic reduction with pcreduce's elimination order (pvSimPCR.py:42-81),

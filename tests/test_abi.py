@@ -67,6 +67,31 @@ def test_no_cpu_fallback_without_a_device(trpl):
         trpl.fastlog(np.ones((2, 3)))
 
 
+def test_shard_bounds_is_the_rule_the_rank_driver_uses(trpl):
+    """trpl_shard_bounds (the sharding of trpl_loglik_multi) == trpl_amd.dist.shard_bounds (ranks)."""
+    import ctypes as C
+    lib = trpl._abi.lib()
+    lo, hi = C.c_int64(), C.c_int64()
+    for S in (0, 1, 5, 64, 1000, 65537):
+        for n in (1, 2, 3, 8):
+            cover = []
+            for r in range(n):
+                assert lib.trpl_shard_bounds(S, n, r, C.byref(lo), C.byref(hi)) == 0
+                assert (lo.value, hi.value) == trpl.dist.shard_bounds(S, n, r)
+                cover.append((lo.value, hi.value))
+            assert cover[0][0] == 0 and cover[-1][1] == S and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+    assert lib.trpl_shard_bounds(10, 2, 2, C.byref(lo), C.byref(hi)) == trpl._abi.ERR_ARG
+
+
+def test_multi_device_call_fails_loudly_without_a_device(trpl):
+    if trpl._abi.lib().trpl_device_count() > 0:
+        pytest.skip("a device is present")
+    X = np.ones((4, 13))
+    with pytest.raises(trpl.TrplError) as ei:
+        trpl.loglik(X, np.ones((1, 16)), 100.0, 1.0, 16, 10, [np.zeros(5)], devices="all")
+    assert ei.value.code == trpl._abi.ERR_NODEVICE
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "bayesian-inference-trpl_amd")
     for dirpath, _, files in os.walk(pkg):

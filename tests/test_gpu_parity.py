@@ -474,3 +474,30 @@ def test_full_size_properties(gpu):
     Pm2 = gpu.loglik(Xm2, ini, lens, Time, 128, T, obs)
     n_tot = 3 * (T + 1)
     assert np.max(np.abs((Pm[ok] + Pm2[ok]) / 2 - (Pf[ok] - n_tot * m * m)) / np.abs(Pf[ok])) < 1e-9
+
+
+def test_multi_device_entry_point_equals_single_device(trpl, gpu):
+    """trpl_loglik_multi: the shards of one host thread's call (three streams on this box's one device,
+    uneven shard sizes) give bit-for-bit the single-launch result, on- and off-grid, all outputs."""
+    X = trpl.workloads.samples(50, seed=5)
+    ini, lengths = trpl.workloads.power_scan(128)
+    T, Time = 120, 3.0
+    ref_info = {}
+    obs0 = [np.full(T + 1, 20.0) - 0.01 * np.arange(T + 1)] * 3
+    want = trpl.loglik(X, ini, lengths, Time, 128, T, obs0, info=ref_info)
+    for devices in ([0], [0, 0, 0], "all"):
+        info = {}
+        got = trpl.loglik(X, ini, lengths, Time, 128, T, obs0, info=info, devices=devices)
+        assert np.array_equal(got, want)
+        for k in ("sse", "status", "iters_total"):
+            assert np.array_equal(info[k], ref_info[k]), (devices, k)
+    times = [np.sort(np.random.default_rng(c).uniform(0, Time, 40)) for c in range(3)]
+    obs1 = [np.full(40, 19.5)] * 3
+    want = trpl.loglik(X, ini, lengths, Time, 128, T, obs1, times=times)
+    got = trpl.loglik(X, ini, lengths, Time, 128, T, obs1, times=times, devices=[0, 0])
+    assert np.array_equal(got, want)
+    # more shards than samples: empty shards are skipped
+    got = trpl.loglik(X[:2], ini, lengths, Time, 128, T, obs0, devices=[0, 0, 0, 0])
+    assert np.array_equal(got, trpl.loglik(X[:2], ini, lengths, Time, 128, T, obs0))
+    with pytest.raises(trpl.TrplError):
+        trpl.loglik(X, ini, lengths, Time, 128, T, obs0, devices=[0, 99])
