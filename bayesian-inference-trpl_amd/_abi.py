@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("TRPL_LIBRARY", os.path.join(_HERE, "libtrpl_hip.so"))
 # status codes / flags (include/trpl.h)
 OK, ERR_ARG, ERR_HIP, ERR_NODEVICE, ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 FLAG_STRICT, FLAG_PL_F32, FLAG_NORMALIZE, FLAG_FP32 = 0x1, 0x2, 0x4, 0x8
+KERNEL_FAST, KERNEL_FAST_PAIR, KERNEL_STRICT, KERNEL_FP32 = 0, 1, 2, 3
 
 
 class TrplError(RuntimeError):
@@ -50,6 +51,7 @@ SIGNATURES = {
     "trpl_loglik_multi": [_vp, _i64, _i32, _vp, _f64, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64,
                           _vp, _vp, _vp, _vp, _vp, _u32, _vp, _i32, _pd],
     "trpl_shard_bounds": [_i64, _i32, _i32, _vp, _vp],
+    "trpl_kernel_variant": [_i64, _i32, _u32],
     "trpl_pcr_solve_batched": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _u32, _i32, _pd],
     "trpl_pcr_solve_batched_dev": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _u32, _vp],
 }

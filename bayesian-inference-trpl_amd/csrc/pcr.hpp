@@ -347,23 +347,54 @@ __device__ __forceinline__ float partner32(float v, bool low)
 }
 #endif
 
-template <typename T, int S>
+// Two systems per wavefront (stepper_pair_impl.hpp) run this solver on WS = 32 lanes each: the wave's
+// 2 x 32 reduced unknowns form one block-diagonal system whose coupling across the seams is exactly
+// zero, so the same lane shifts work; with ISO the values that cross a seam are replaced by 0 (and
+// the LDS indices stay inside the half) so that a non-finite value of one system can never reach
+// the other through a 0 * NaN.
+// A voided fp64 value only has its HIGH dword cleared (one v_cndmask instead of two): what is left is
+// a denormal (|v| < 2^-1022), finite whatever the original was, and the exact-zero coefficient it
+// meets turns it into +-0.  void_value() clears both dwords where the value itself matters.
+template <typename T>
+__device__ __forceinline__ T void_hi(bool c, T v)
+{
+    if constexpr (sizeof(T) == 8) return __hiloint2double(c ? 0 : __double2hiint(v), __double2loint(v));
+    else return c ? T(0) : v;
+}
+template <bool ISO, int WS, typename T>
+__device__ __forceinline__ T seam_first(T v, int lane)      // v arrived from lane-1: void on a system's first lane
+{
+    if constexpr (ISO) return void_hi((lane & (WS - 1)) == 0, v);
+    else return v;
+}
+template <bool ISO, int WS, typename T>
+__device__ __forceinline__ T seam_last(T v, int lane)       // v arrived from lane+1: void on a system's last lane
+{
+    if constexpr (ISO) return void_hi((lane & (WS - 1)) == WS - 1, v);
+    else return v;
+}
+
+template <typename T, int S, int WS = 64, bool ISO = false>
 __device__ __forceinline__ void pcr64_levels(T &A, T &D, T &C, T &Bv, int lane, T *xch)
 {
-    if constexpr (S < 32) {
+    if constexpr (S < WS / 2) {
         const T r = rcp_fast<T>(D);
         const T nA = A * r, nC = C * r, nB = Bv * r;
         T Am, Cm, Bm, Ap, Cp, Bp;
         if constexpr ((TRPL_ABLATE & 1) != 0 && S > 1) {
             Am = nA; Cm = nC; Bm = nB; Ap = nC; Cp = nA; Bp = -nB;
         } else if constexpr (S == 1 && TRPL_PCR_S1_LDS == 0) {   // DPP wave rotates
-            Am = lane_dn<1>(nA, lane); Cm = lane_dn<1>(nC, lane); Bm = lane_dn<1>(nB, lane);
-            Ap = lane_up<1>(nA, lane); Cp = lane_up<1>(nC, lane); Bp = lane_up<1>(nB, lane);
+            Am = seam_first<ISO, WS>(lane_dn<1>(nA, lane), lane); Cm = seam_first<ISO, WS>(lane_dn<1>(nC, lane), lane);
+            Bm = seam_first<ISO, WS>(lane_dn<1>(nB, lane), lane);
+            Ap = seam_last<ISO, WS>(lane_up<1>(nA, lane), lane); Cp = seam_last<ISO, WS>(lane_up<1>(nC, lane), lane);
+            Bp = seam_last<ISO, WS>(lane_up<1>(nB, lane), lane);
         } else {                                   // staged through LDS, one value per lane and array
             xch[0 * 64 + lane] = nA;
             xch[1 * 64 + lane] = nC;
             xch[2 * 64 + lane] = nB;
-            const int dn = (lane - S) & 63, up = (lane + S) & 63;
+            // ISO: wrap inside the system's own lanes (its own rows, multiplied by exact zeros)
+            const int dn = ISO ? (((lane - S) & (WS - 1)) | (lane & (64 - WS))) : ((lane - S) & 63);
+            const int up = ISO ? (((lane + S) & (WS - 1)) | (lane & (64 - WS))) : ((lane + S) & 63);
             Am = xch[0 * 64 + dn]; Cm = xch[1 * 64 + dn]; Bm = xch[2 * 64 + dn];
             Ap = xch[0 * 64 + up]; Cp = xch[1 * 64 + up]; Bp = xch[2 * 64 + up];
         }
@@ -371,12 +402,12 @@ __device__ __forceinline__ void pcr64_levels(T &A, T &D, T &C, T &Bv, int lane, 
         Bv = Bv - A * Bm - C * Bp;
         A = -A * Am;
         C = -C * Cp;
-        pcr64_levels<T, S * 2>(A, D, C, Bv, lane, xch);
+        pcr64_levels<T, S * 2, WS, ISO>(A, D, C, Bv, lane, xch);
     }
 }
 
 // one forward cyclic-reduction level with in-lane stride H (rows H, 3H, .. eliminated)
-template <typename T, int NR, int H>
+template <typename T, int NR, int H, int WS = 64, bool ISO = false>
 __device__ __forceinline__ void cr_forward(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], int lane)
 {
     if constexpr (H < NR) {
@@ -387,7 +418,9 @@ __device__ __forceinline__ void cr_forward(T (&ld)[NR], T (&d)[NR], T (&ud)[NR],
             ld[q] *= r; ud[q] *= r; B[q] *= r;
         }
         // the left neighbour of row 0 is row NR-H of lane l-1
-        const T aL0 = lane_dn<1>(ld[NR - H], lane), cL0 = lane_dn<1>(ud[NR - H], lane), bL0 = lane_dn<1>(B[NR - H], lane);
+        const T aL0 = seam_first<ISO, WS>(lane_dn<1>(ld[NR - H], lane), lane),
+                cL0 = seam_first<ISO, WS>(lane_dn<1>(ud[NR - H], lane), lane),
+                bL0 = seam_first<ISO, WS>(lane_dn<1>(B[NR - H], lane), lane);
 #pragma unroll
         for (int p = 0; p < NR; p += 2 * H) {
             const T aL = p == 0 ? aL0 : ld[p == 0 ? 0 : p - H], cL = p == 0 ? cL0 : ud[p == 0 ? 0 : p - H],
@@ -399,7 +432,7 @@ __device__ __forceinline__ void cr_forward(T (&ld)[NR], T (&d)[NR], T (&ud)[NR],
             ld[p] = -a * aL;
             ud[p] = -c * cR;
         }
-        cr_forward<T, NR, 2 * H>(ld, d, ud, B, lane);
+        cr_forward<T, NR, 2 * H, WS, ISO>(ld, d, ud, B, lane);
     }
 }
 
@@ -417,24 +450,27 @@ __device__ __forceinline__ void cr_backward(const T (&ld)[NR], const T (&ud)[NR]
     }
 }
 
-template <typename T, int NR>
+// WS lanes per system (64: one system per wave; 32: two); the final pairs sit in lanes l, l ^ (WS/2)
+template <typename T, int NR, int WS = 64, bool ISO = false>
 __device__ __forceinline__ void cr_pcr_solve(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], T (&x)[NR], int lane,
                                              T *xch)
 {
-    cr_forward<T, NR, 1>(ld, d, ud, B, lane);
+    cr_forward<T, NR, 1, WS, ISO>(ld, d, ud, B, lane);
     T A = ld[0], D = d[0], C = ud[0], Bv = B[0];
-    pcr64_levels<T, 1>(A, D, C, Bv, lane, xch);
-    const bool low = lane < 32;                    // lane^32 pairs by Cramer's rule, own unknown only
+    pcr64_levels<T, 1, WS, ISO>(A, D, C, Bv, lane, xch);
+    const bool low = (lane & (WS / 2)) == 0;       // pairs by Cramer's rule, own unknown only
     const T c_own = low ? C : A;
     T D_oth, B_oth, c_oth;
     if constexpr ((TRPL_ABLATE & 1) != 0) {
         D_oth = D * T(1.5); B_oth = -Bv; c_oth = c_own;
-    } else {
+    } else if constexpr (WS == 64) {
         D_oth = partner32(D, low); B_oth = partner32(Bv, low); c_oth = partner32(c_own, low);
+    } else {
+        D_oth = __shfl_xor(D, WS / 2, 64); B_oth = __shfl_xor(Bv, WS / 2, 64); c_oth = __shfl_xor(c_own, WS / 2, 64);
     }
     const T X = (Bv * D_oth - c_own * B_oth) * rcp_fast<T>(D * D_oth - c_own * c_oth);
     x[0] = X;
-    const T xnext = lane_up<1>(X, lane);           // lane 63 receives a wrapped value times c^ = 0
+    const T xnext = seam_last<ISO, WS>(lane_up<1>(X, lane), lane);   // a system's last lane: times c^ = 0
     cr_backward<T, NR, NR / 2>(ld, ud, B, x, xnext);
 }
 

@@ -1,0 +1,276 @@
+// FAST time-stepper for L = 128 with TWO SYSTEMS PER WAVEFRONT (same curve, adjacent samples).
+//
+// Why: the tridiagonal solve is the largest part of an inner iteration, and its in-lane
+// cyclic-reduction levels are work-efficient (O(rows)) while the cross-lane PCR levels are not
+// (O(rows log rows)).  With one L = 128 system per wave a lane holds 2 adjacent rows: 1 CR level +
+// 5 PCR levels + the pair step.  Here a lane holds 4 adjacent rows of ONE of two systems (lanes 0-31:
+// system A, lanes 32-63: system B): 2 CR levels + 4 PCR levels + the pair step for twice the nodes --
+// measured +29 % node throughput for this shape (the L = 256 kernel), at 2 waves per SIMD.
+//
+// The two systems are numerically independent: every value that crosses the seam between lanes 31 | 32
+// (or wraps 63 | 0) is multiplied by a coefficient that is exactly zero (first-row sub-diagonal,
+// last-row super-diagonal and their PCR/CR descendants), and with ISO = true it is replaced by 0
+// first, so not even a NaN/Inf of one system can reach the other.  Each system is computed by the
+// same instruction sequence whichever half it sits in: results do not depend on the pairing.
+//
+// Convergence is per system (pvSimPCR.py:213-216): a system that has converged in this time step is
+// frozen (its lanes keep their state) while its partner iterates on; a system that hits MAX is
+// flagged (:269) and parked in its equilibrium state for the rest of the run.
+// Reference for the arithmetic: see stepper_impl.hpp (assemble / PlSink are shared with it).
+#pragma once
+#include "stepper_impl.hpp"
+
+namespace trpl {
+namespace pair {
+
+constexpr int L = 128;      // nodes per system
+constexpr int NR = 4;       // adjacent rows per lane
+constexpr int WS = 32;      // lanes per system
+
+__device__ __forceinline__ double lane_value(double v, int l)      // lane l's value, wave-uniform
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                            __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// sums of v over lanes 0-31 (lo) and 32-63 (hi), wave-uniform; same association in both halves
+__device__ __forceinline__ void half_sums(double v, double &lo, double &hi)
+{
+    v = dpp_add<0x111, 0xF>(v);          // row_shr:1
+    v = dpp_add<0x112, 0xF>(v);          // row_shr:2
+    v = dpp_add<0x114, 0xF>(v);          // row_shr:4
+    v = dpp_add<0x118, 0xF>(v);          // row_shr:8   -> lane 15 of each row holds the row sum
+    v = dpp_add<0x142, 0xA>(v);          // row_bcast:15 into rows 1,3 -> lanes 31 and 63 hold the half sums
+    lo = lane_value(v, 31);
+    hi = lane_value(v, 63);
+}
+
+// norm2 (pvSimPCR.py:14-40) of both systems: ok = sum|A c - b| < TOL * sum|b|, one reduction each
+template <bool ISO>
+__device__ __forceinline__ void residual_below2(const double (&l)[NR], const double (&dg)[NR], const double (&u)[NR],
+                                                const double (&b)[NR], const double (&c)[NR], double TOL, int lane,
+                                                bool &okA, bool &okB)
+{
+    double cm[NR], cp[NR];
+    nbrB_dn<double, NR, 1>(c, cm, lane);
+    nbrB_up<double, NR, 1>(c, cp, lane);
+    cm[0] = seam_first<ISO, WS>(cm[0], lane);          // times l = 0 on a system's first row
+    cp[NR - 1] = seam_last<ISO, WS>(cp[NR - 1], lane); // times u = 0 on its last row
+    double q = 0.0;
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        const double r = fabs(l[j] * cm[j] + dg[j] * c[j] + u[j] * cp[j] - b[j]);
+        const double qj = __builtin_fma(-TOL, fabs(b[j]), r);
+        q = j == 0 ? qj : q + qj;
+    }
+    double sA, sB;
+    half_sums(q, sA, sB);
+    okA = sA < 0.0;
+    okB = sB < 0.0;
+}
+
+// field update on edges 1..L-1 (pvSimPCR.py:205-209) of the systems whose lanes have act set
+template <bool ISO>
+__device__ __forceinline__ void update_field2(const MatPar &m, double a0, const double (&Nk)[NR], const double (&Pk)[NR],
+                                              const double (&bE)[NR], double (&Ek)[NR], int lane, bool act)
+{
+    double Nm[NR], Pm[NR], A[NR], b[NR], rA[NR];
+    nbrB_dn<double, NR, 1>(Nk, Nm, lane);
+    nbrB_dn<double, NR, 1>(Pk, Pm, lane);
+    if constexpr (ISO) {     // edge 0 is never written, but its A enters a paired reciprocal: a full zero here
+        const bool first = (lane & (WS - 1)) == 0;
+        Nm[0] = first ? 0.0 : Nm[0];
+        Pm[0] = first ? 0.0 : Pm[0];
+    }
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        A[j] = (0.5 * m.Lambda) * (m.DP * (Pk[j] + Pm[j]) + m.DN * (Nk[j] + Nm[j])) + a0;
+        b[j] = m.Lambda * (m.DP * (Pk[j] - Pm[j]) - m.DN * (Nk[j] - Nm[j])) - bE[j];
+    }
+    rcp_rows<NR>(A, rA);
+    const bool act0 = act && (lane & (WS - 1)) != 0;
+    Ek[0] = act0 ? b[0] * rA[0] : Ek[0];
+#pragma unroll
+    for (int j = 1; j < NR; j++) Ek[j] = act ? b[j] * rA[j] : Ek[j];
+}
+
+template <bool ISO>
+__global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
+{
+    constexpr int LAY = 2;
+    const int lane = threadIdx.x;
+    const int ln = lane & (WS - 1);                 // lane within the system
+    const bool hi = lane >= WS;
+    const int64_t blk = blockIdx.x;
+    const int c = (int)(blk % a.C);
+    const int64_t sA = 2 * (blk / a.C);
+    const bool validB = sA + 1 < a.S;
+    const int64_t sB = validB ? sA + 1 : sA;        // an odd tail is computed twice and stored once
+    const int64_t s = hi ? sB : sA;
+    const CurveConst &cc = a.curve[c];
+
+    // ---- non-dimensional material parameters (pvSimPCR.py:327-331), per lane: two samples per wave ----
+    const double *xs = a.X + s * a.xld;
+    const double N0 = xs[0] * cc.scales[0], P0 = xs[1] * cc.scales[1], DN = xs[2] * cc.scales[2],
+                 DP = xs[3] * cc.scales[3], rate = xs[4] * cc.scales[4], sr0 = xs[5] * cc.scales[5],
+                 srL = xs[6] * cc.scales[6], CN = xs[7] * cc.scales[7], CP = xs[8] * cc.scales[8],
+                 tauN = xs[9] * cc.scales[9], tauP = xs[10] * cc.scales[10],
+                 Lambda = xs[11] * cc.scales[11];
+    const double n0p0 = N0 * P0;
+    const MatPar mp = {N0, P0, DN, DP, rate, sr0, srL, CN, CP, tauN, tauP, Lambda, n0p0};
+    const double mag = a.xld > 12 ? xs[12] : 0.0;
+    const double TOL = a.TOL;
+    const int MAX = a.MAX;
+
+    // ---- state U^t in registers; U^{t-1..t-4} of N and P in a 4-slot LDS ring (slot = t mod 4), E's in registers ----
+    constexpr int HSLOT = 2 * NR * 64;
+    constexpr int XCH = 3 * 64;
+    __shared__ __attribute__((aligned(16))) double lds[4 * HSLOT + XCH];
+    double *hist = lds;
+    double *xch = lds + 4 * HSLOT;
+    double Nk[NR], Pk[NR], Ek[NR], hE[4][NR];
+#pragma unroll
+    for (int j = 0; j < NR; j++) {                  // pvSimPCR.py:356-362
+        const double dn = a.dN[(int64_t)c * L + NR * ln + j] * cc.dx3;
+        Nk[j] = N0 + dn;
+        Pk[j] = P0 + dn;
+        Ek[j] = 0.0;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            hE[m][j] = 0.0;
+            hist[m * HSLOT + (0 * NR + j) * 64 + lane] = 0.0;
+            hist[m * HSLOT + (1 * NR + j) * 64 + lane] = 0.0;
+        }
+    }
+
+    PlSink sinkA(a, cc, c, sA, lane_value(mag, 0));
+    PlSink sinkB(a, cc, c, sB, lane_value(mag, WS));
+    const double rateA = lane_value(rate, 0), rateB = lane_value(rate, WS);
+    int statusA = 0, statusB = 0;
+    bool deadA = false, deadB = !validB;            // dead: flagged non-converged (or the odd tail's duplicate)
+    int64_t itotA = 0, itotB = 0;
+
+    for (int64_t t = 0; t <= sinkA.t_last; t++) {   // tEvol, pvSimPCR.py:237
+        if (deadA && deadB) break;
+        double a0, a1, a2, a3, a4, a5;              // :241-250
+        if (t == 0)      { a0 = 1.0; a1 = -1.0; a2 = 0.0; a3 = 0.0; a4 = 0.0; a5 = 0.0; }
+        else if (t == 1) { a0 = 1.5; a1 = -2.0; a2 = 0.5; a3 = 0.0; a4 = 0.0; a5 = 0.0; }
+        else if (t == 2) { a0 = 11.0 / 6; a1 = -3.0; a2 = 1.5; a3 = -1.0 / 3; a4 = 0.0; a5 = 0.0; }
+        else if (t == 3) { a0 = 25.0 / 12; a1 = -4.0; a2 = 3.0; a3 = -4.0 / 3; a4 = 0.25; a5 = 0.0; }
+        else             { a0 = 137.0 / 60; a1 = -5.0; a2 = 5.0; a3 = -10.0 / 3; a4 = 1.25; a5 = -0.2; }
+
+        // PL of the state at time t, pvSimPCR.py:276-281, per-node excess first (see stepper_impl.hpp)
+        double plA = 0.0, plB = 0.0;
+        const bool pl_step = (t % a.plT) == 0;
+        if (pl_step) {
+            double q = __builtin_fma(Nk[0], Pk[0], -n0p0);
+#pragma unroll
+            for (int j = 1; j < NR; j++) q += __builtin_fma(Nk[j], Pk[j], -n0p0);
+            double hA, hB;
+            half_sums(q, hA, hB);
+            plA = rateA * hA;
+            plB = rateB * hB;
+        }
+
+        // BDF right-hand sides (:128-135); U^t replaces U^{t-4} in the ring
+        double bN[NR], bP[NR], bE[NR], cE[NR];
+        {
+            const int s1 = (int)((t + 3) & 3) * HSLOT, s2 = (int)((t + 2) & 3) * HSLOT,
+                      s3 = (int)((t + 1) & 3) * HSLOT, s4 = (int)(t & 3) * HSLOT;
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                const int oN = (0 * NR + j) * 64 + lane, oP = (1 * NR + j) * 64 + lane;
+                cE[j] = Ek[j];
+                bN[j] = a1 * Nk[j] + a2 * hist[s1 + oN] + a3 * hist[s2 + oN] + a4 * hist[s3 + oN] + a5 * hist[s4 + oN];
+                bP[j] = a1 * Pk[j] + a2 * hist[s1 + oP] + a3 * hist[s2 + oP] + a4 * hist[s3 + oP] + a5 * hist[s4 + oP];
+                bE[j] = a1 * Ek[j] + a2 * hE[0][j] + a3 * hE[1][j] + a4 * hE[2][j] + a5 * hE[3][j];
+                hist[s4 + oN] = Nk[j];
+                hist[s4 + oP] = Pk[j];
+            }
+        }
+
+        // ---------------- iterate, pvSimPCR.py:93-225, both systems ----------------
+        bool doneA = deadA, doneB = deadB;
+        int itA = MAX, itB = MAX;                   // value if the loop runs to exhaustion (:225)
+        for (int iters = 0; iters < MAX; iters++) {
+            const bool act = hi ? !doneB : !doneA;  // lanes of a system that is still iterating
+            double lo_[NR], dg[NR], up[NR], bb[NR], Ep[NR], x[NR];
+            nbrB_up<double, NR, 1>(Ek, Ep, lane);   // a system's last lane reads the partner's E_0 = 0: E_L = 0
+            bool okNA, okNB, okPA, okPB;
+            // ---- electrons (:148-175) ----
+            assemble<LAY, true, NR, WS, L>(mp, a0, Nk, Pk, Ek, Ep, bN, lo_, dg, up, bb, ln);
+            residual_below2<ISO>(lo_, dg, up, bb, Nk, TOL, lane, okNA, okNB);                      // :172
+            cr_pcr_solve<double, NR, WS, ISO>(lo_, dg, up, bb, x, lane, xch);                       // :175
+#pragma unroll
+            for (int j = 0; j < NR; j++) Nk[j] = act ? x[j] : Nk[j];
+            // ---- holes, with the updated electrons (:178-202) ----
+            assemble<LAY, false, NR, WS, L>(mp, a0, Nk, Pk, Ek, Ep, bP, lo_, dg, up, bb, ln);
+            residual_below2<ISO>(lo_, dg, up, bb, Pk, TOL, lane, okPA, okPB);                      // :200
+            cr_pcr_solve<double, NR, WS, ISO>(lo_, dg, up, bb, x, lane, xch);                       // :202
+#pragma unroll
+            for (int j = 0; j < NR; j++) Pk[j] = act ? x[j] : Pk[j];
+            // ---- field on edges 1..L-1 (:205-209) ----
+            update_field2<ISO>(mp, a0, Nk, Pk, bE, Ek, lane, act);
+            if (!doneA && okNA && okPA) { doneA = true; itA = iters + 1; }                         // :213-216
+            if (!doneB && okNB && okPB) { doneB = true; itB = iters + 1; }
+            if (doneA && doneB) break;
+        }
+        bool killA = false, killB = false;
+        // :269-274 -- like the reference, converging only in iteration MAX itself counts as a failure
+        if (!deadA) { itotA += itA; if (itA >= MAX) { statusA = 1 + (int)t; killA = true; } }
+        if (!deadB) { itotB += itB; if (itB >= MAX) { statusB = 1 + (int)t; killB = true; } }
+        if (killA || killB) {
+            // park the flagged system at equilibrium (finite, converges trivially) for the rest of the run
+            const bool mine = hi ? killB : killA;
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                if (mine) {
+                    Nk[j] = N0; Pk[j] = P0; Ek[j] = 0.0; cE[j] = 0.0;
+#pragma unroll
+                    for (int m = 0; m < 4; m++) {
+                        hE[m][j] = 0.0;
+                        hist[m * HSLOT + (0 * NR + j) * 64 + lane] = N0;
+                        hist[m * HSLOT + (1 * NR + j) * 64 + lane] = P0;
+                    }
+                }
+            }
+            deadA = deadA || killA;
+            deadB = deadB || killB;
+        }
+
+        if (pl_step) {
+            if (!deadA) { if (sinkA.interp) sinkA.emit(t, plA); else sinkA.push(t, plA); }
+            if (!deadB) { if (sinkB.interp) sinkB.emit(t, plB); else sinkB.push(t, plB); }
+        }
+
+#pragma unroll
+        for (int j = 0; j < NR; j++) {              // shift the field history by one level
+#pragma unroll
+            for (int m = 3; m >= 1; m--) hE[m][j] = hE[m - 1][j];
+            hE[0][j] = cE[j];
+        }
+    }
+
+    if (!sinkA.interp) {                            // columns parked since the last full batch
+        const int64_t doneA_ = statusA ? (int64_t)(statusA - 1) : sinkA.t_last + 1;
+        const int64_t doneB_ = statusB ? (int64_t)(statusB - 1) : sinkB.t_last + 1;
+        sinkA.flush_batch((int)((doneA_ + a.plT - 1) / a.plT - sinkA.base));
+        if (validB) sinkB.flush_batch((int)((doneB_ + a.plT - 1) / a.plT - sinkB.base));
+    }
+    sinkA.finish(statusA, itotA);
+    if (validB) sinkB.finish(statusB, itotB);
+}
+
+}  // namespace pair
+
+template <bool ISO>
+hipError_t launch_stepper_pair_t(const StepArgs &a, hipStream_t stream)
+{
+    if (a.L != pair::L) return hipErrorInvalidValue;
+    const int64_t nblk = ((a.S + 1) / 2) * a.C;
+    if (nblk <= 0) return hipSuccess;
+    hipLaunchKernelGGL((pair::stepper_pair_kernel<ISO>), dim3((unsigned)nblk), dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace trpl

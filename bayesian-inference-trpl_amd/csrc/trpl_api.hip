@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <chrono>
@@ -57,6 +58,29 @@ int check_grid(int32_t L, int64_t T, int32_t plT, int32_t max_iter, double time_
     return TRPL_OK;
 }
 
+// FAST, L = 128 has two kernels: one system per wavefront (3 waves per SIMD: 12 systems per CU in
+// flight) and two systems per wavefront (2 waves per SIMD: 16 systems per CU, +21 % throughput once
+// the chip is full, but 10 % slower per wave).  A launch that does not even fill the first takes
+// the one-system kernel; anything larger the paired one.  TRPL_PAIR=0 / 1 forces never / always
+// (measurements; a system's result does not depend on its partner, but the two kernels associate
+// their node sums differently, ~1e-16 relative).
+bool use_pair_kernel(int64_t nsys)
+{
+    static const int forced = getenv("TRPL_PAIR") ? atoi(getenv("TRPL_PAIR")) : -1;
+    if (forced >= 0) return forced != 0;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        static thread_local int cached_dev = -1, cached_cus = 256;
+        if (cached_dev != dev) {
+            int n = 0;
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cached_cus = n;
+            cached_dev = dev;
+        }
+        cus = cached_cus;
+    }
+    return nsys > (int64_t)cus * 12;
+}
+
 int launch(const trpl::StepArgs &a, uint32_t flags, hipStream_t st)
 {
     if (flags & TRPL_FLAG_FP32) {
@@ -64,6 +88,11 @@ int launch(const trpl::StepArgs &a, uint32_t flags, hipStream_t st)
         if (a.L < 128) return fail(TRPL_ERR_UNSUPPORTED, "the fp32 stepper is built for L >= 128 (got %d)", a.L);
         hipError_t e32 = trpl::launch_stepper_f32(a, st);
         if (e32 != hipSuccess) return fail(TRPL_ERR_HIP, "fp32 stepper launch: %s", hipGetErrorString(e32));
+        return TRPL_OK;
+    }
+    if (!(flags & TRPL_FLAG_STRICT) && a.L == 128 && use_pair_kernel(a.S * a.C)) {
+        hipError_t ep = trpl::launch_stepper_pair(a, st);
+        if (ep != hipSuccess) return fail(TRPL_ERR_HIP, "pair stepper launch: %s", hipGetErrorString(ep));
         return TRPL_OK;
     }
     hipError_t e = (flags & TRPL_FLAG_STRICT) ? trpl::launch_stepper_strict(a, st) : trpl::launch_stepper_fast(a, st);
@@ -98,6 +127,13 @@ extern "C" {
 
 int trpl_abi_version(void) { return TRPL_ABI_VERSION; }
 const char *trpl_last_error(void) { return g_err; }
+
+int trpl_kernel_variant(int64_t nsys, int32_t L, uint32_t flags)
+{
+    if (flags & TRPL_FLAG_FP32) return TRPL_KERNEL_FP32;
+    if (flags & TRPL_FLAG_STRICT) return TRPL_KERNEL_STRICT;
+    return (L == 128 && use_pair_kernel(nsys)) ? TRPL_KERNEL_FAST_PAIR : TRPL_KERNEL_FAST;
+}
 
 int trpl_device_count(void)
 {

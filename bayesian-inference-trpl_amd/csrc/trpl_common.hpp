@@ -47,6 +47,8 @@ struct StepArgs {
 hipError_t launch_stepper_strict(const StepArgs &a, hipStream_t stream);
 hipError_t launch_stepper_fast(const StepArgs &a, hipStream_t stream);
 hipError_t launch_stepper_f32(const StepArgs &a, hipStream_t stream);   // stepper_f32.hip, L >= 128
+// stepper_pair.hip: FAST, L = 128, two systems per wavefront
+hipError_t launch_stepper_pair(const StepArgs &a, hipStream_t stream);
 
 // likelihood.hip
 hipError_t launch_log10_clamp(void *x, int elem_bytes, int64_t rows, int64_t cols, int64_t ld, double mn,

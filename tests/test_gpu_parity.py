@@ -464,8 +464,12 @@ def test_full_size_properties(gpu):
     assert abs(info_f["iters_total"].sum() / info_s["iters_total"].sum() - 1) < 1e-3
     Pf2 = gpu.loglik(X, ini, lens, Time, 128, T, obs)
     assert np.array_equal(Pf, Pf2)                                            # (iii)
-    sub = gpu.loglik(X[61000:61300], ini, lens, Time, 128, T, obs)
-    assert np.array_equal(sub, Pf[61000:61300])                               # (ii)
+    sub = gpu.loglik(X[61001:62200], ini, lens, Time, 128, T, obs)            # same kernel, other partners
+    assert np.array_equal(sub, Pf[61001:62200])                               # (ii)
+    # a launch too small to fill the chip runs the one-system-per-wavefront kernel, whose node sums
+    # associate differently: same likelihoods to rounding
+    small = gpu.loglik(X[61000:61300], ini, lens, Time, 128, T, obs)
+    assert np.allclose(small, Pf[61000:61300], rtol=1e-10, atol=1e-10)
     m = 0.25
     Xm = X.copy(); Xm[:, -1] = m
     Pm = gpu.loglik(Xm, ini, lens, Time, 128, T, obs)
@@ -501,3 +505,89 @@ def test_multi_device_entry_point_equals_single_device(trpl, gpu):
     assert np.array_equal(got, trpl.loglik(X[:2], ini, lengths, Time, 128, T, obs0))
     with pytest.raises(trpl.TrplError):
         trpl.loglik(X, ini, lengths, Time, 128, T, obs0, devices=[0, 99])
+
+
+# ---- two systems per wavefront (stepper_pair_impl.hpp): the kernel of every launch that fills the chip ----
+def _pair_batch(trpl, S):
+    lib = trpl._abi.lib()
+    if lib.trpl_kernel_variant(3 * S, 128, 0) != trpl._abi.KERNEL_FAST_PAIR:
+        pytest.skip("this device/TRPL_PAIR setting does not select the paired kernel for %d systems" % (3 * S))
+    assert lib.trpl_kernel_variant(3 * S, 128, trpl._abi.FLAG_STRICT) == trpl._abi.KERNEL_STRICT
+    X = trpl.workloads.samples(S, seed=11)
+    ini, lengths = trpl.workloads.power_scan(128)
+    return X, ini, lengths
+
+
+def test_paired_kernel_matches_strict_with_identical_iteration_counts(trpl, gpu):
+    """Parity of the paired kernel at a size where it is the one that runs (4097 samples x 3 curves, odd
+    tail included): against STRICT (bit-identical to the reference) every system takes exactly the
+    same number of inner iterations and the likelihoods agree to 1e-9."""
+    S, T, Time = 4097, 200, 5.0
+    X, ini, lengths = _pair_batch(trpl, S)
+    obs = [np.full(T + 1, 20.0) - 0.02 * np.arange(T + 1)] * 3
+    fi, si = {}, {}
+    pf = trpl.loglik(X, ini, lengths, Time, 128, T, obs, info=fi)
+    ps = trpl.loglik(X, ini, lengths, Time, 128, T, obs, info=si, strict=True)
+    assert not fi["status"].any() and not si["status"].any()
+    assert np.array_equal(fi["iters_total"], si["iters_total"])
+    assert np.max(np.abs(pf - ps) / np.abs(ps)) < 1e-9
+
+
+def test_paired_kernel_result_does_not_depend_on_the_partner(trpl, gpu):
+    """A system's result is bit-for-bit the same whichever sample shares its wavefront and whichever
+    half it sits in: drop the first sample (every pairing changes, every system changes half)."""
+    S, T, Time = 4098, 100, 2.5
+    X, ini, lengths = _pair_batch(trpl, S)
+    obs = [np.full(T + 1, 20.0)] * 3
+    a, b = {}, {}
+    pa = trpl.loglik(X, ini, lengths, Time, 128, T, obs, info=a)
+    pb = trpl.loglik(X[1:], ini, lengths, Time, 128, T, obs, info=b)
+    assert np.array_equal(pa[1:], pb)
+    assert np.array_equal(a["sse"][:, 1:], b["sse"]) and np.array_equal(a["iters_total"][:, 1:], b["iters_total"])
+    # and the PL-storing mode (pvSim): same kernel, same independence
+    pl_a = trpl.solve_pl(X[:, :12], lengths[0], Time, 128, T, ini[0])[0]     # 4098 systems: paired kernel
+    pl_b = trpl.solve_pl(X[1:, :12], lengths[0], Time, 128, T, ini[0])[0]
+    assert pl_a.shape == (S, T + 1) and np.array_equal(pl_a[1:], pl_b)
+
+
+def test_paired_kernel_isolates_a_broken_system_from_its_partner(trpl, gpu):
+    """NaN / zero-lifetime / non-converging samples are flagged (status, sse = inf) and their wavefront
+    partners come out bit-identical to a run without them."""
+    S, T, Time = 4096, 60, 1.5
+    X, ini, lengths = _pair_batch(trpl, S)
+    obs = [np.full(T + 1, 20.0)] * 3
+    clean = {}
+    pc = trpl.loglik(X, ini, lengths, Time, 128, T, obs, info=clean)
+    bad = X.copy()
+    bad[10, 9] = np.nan            # tau_n
+    bad[21, 4] = np.inf            # radiative rate
+    bad[300, 9] = 0.0              # degenerate lifetime (still solvable)
+    bad[301, 2] = -1e9             # negative diffusivity: whatever the solve does, it stays in its half
+    info = {}
+    pb = trpl.loglik(bad, ini, lengths, Time, 128, T, obs, info=info)
+    broken = np.array([10, 21, 300, 301])
+    ok = np.setdiff1d(np.arange(S), broken)
+    assert np.array_equal(pb[ok], pc[ok])
+    assert np.array_equal(info["sse"][:, ok], clean["sse"][:, ok])
+    assert np.array_equal(info["iters_total"][:, ok], clean["iters_total"][:, ok])
+    assert (info["status"][:, [10, 21]] > 0).all() and np.isinf(info["sse"][:, [10, 21]]).all()
+    assert not np.isfinite(pb[[10, 21]]).any()
+    assert np.isfinite(pb[ok]).all()
+
+
+def test_paired_kernel_mixed_convergence_matches_strict(trpl, gpu):
+    """With a small iteration cap some systems are flagged at different steps while their partners go
+    on: status (the step), iteration totals and the surviving likelihoods equal STRICT's."""
+    S, T, Time = 2048, 30, 0.75
+    X, ini, lengths = _pair_batch(trpl, S)
+    obs = [np.full(T + 1, 20.0)] * 3
+    fi, si = {}, {}
+    pf = trpl.loglik(X, ini, lengths, Time, 128, T, obs, info=fi, MAX=60)
+    ps = trpl.loglik(X, ini, lengths, Time, 128, T, obs, info=si, MAX=60, strict=True)
+    frac = (si["status"] > 0).mean()
+    assert 0.02 < frac < 0.98, frac                  # the cap must bite on some systems only
+    assert np.array_equal(fi["status"], si["status"])
+    assert np.array_equal(fi["iters_total"], si["iters_total"])
+    live = ~(si["status"] > 0).any(axis=0)
+    assert np.array_equal(np.isinf(pf), np.isinf(ps))
+    assert np.max(np.abs(pf[live] - ps[live]) / np.abs(ps[live])) < 1e-9
