@@ -352,6 +352,24 @@ __device__ __forceinline__ float partner32(float v, bool low)
 // zero, so the same lane shifts work; with ISO the values that cross a seam are replaced by 0 (and
 // the LDS indices stay inside the half) so that a non-finite value of one system can never reach
 // the other through a 0 * NaN.
+// ds_swizzle_b32 in rotate mode (offset 0xC000 | dir << 10 | n << 5; probed on gfx950 with
+// tools/swizzle_probe.hip): every group of 32 lanes is rotated by n, dir 0: lane i <- lane (i+n) & 31,
+// dir 1: lane i <- lane (i-n) & 31.  No LDS memory is touched (crossbar only) and the rotation never
+// leaves a 32-lane group: exactly the neighbour fetch of a system that owns 32 lanes.
+template <int PAT, typename T>
+__device__ __forceinline__ T swizzle(T v)
+{
+    if constexpr (sizeof(T) == 8) {
+        return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v), PAT),
+                                __builtin_amdgcn_ds_swizzle(__double2loint(v), PAT));
+    } else {
+        return __builtin_bit_cast(T, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), PAT));
+    }
+}
+template <int N, typename T> __device__ __forceinline__ T rot32_up(T v) { return swizzle<0xC000 | (N << 5)>(v); }
+template <int N, typename T> __device__ __forceinline__ T rot32_dn(T v) { return swizzle<0xC000 | (1 << 10) | (N << 5)>(v); }
+template <typename T> __device__ __forceinline__ T swap16(T v) { return swizzle<(0x10 << 10) | 0x1f>(v); }   // lane ^ 16
+
 // A voided fp64 value only has its HIGH dword cleared (one v_cndmask instead of two): what is left is
 // a denormal (|v| < 2^-1022), finite whatever the original was, and the exact-zero coefficient it
 // meets turns it into +-0.  void_value() clears both dwords where the value itself matters.
@@ -374,15 +392,21 @@ __device__ __forceinline__ T seam_last(T v, int lane)       // v arrived from la
     else return v;
 }
 
-template <typename T, int S, int WS = 64, bool ISO = false>
+// XM (32-lane systems only) moves exchanges onto ds_swizzle rotates: bit 0 the strides >= 2 and the
+// pair step, bit 1 the stride-1 PCR level, bit 2 the stride-1 fetches of the CR levels.
+template <typename T, int S, int WS = 64, bool ISO = false, int XM = 0>
 __device__ __forceinline__ void pcr64_levels(T &A, T &D, T &C, T &Bv, int lane, T *xch)
 {
+    static_assert(XM == 0 || WS == 32, "swizzle rotates work on 32-lane groups");
     if constexpr (S < WS / 2) {
         const T r = rcp_fast<T>(D);
         const T nA = A * r, nC = C * r, nB = Bv * r;
         T Am, Cm, Bm, Ap, Cp, Bp;
         if constexpr ((TRPL_ABLATE & 1) != 0 && S > 1) {
             Am = nA; Cm = nC; Bm = nB; Ap = nC; Cp = nA; Bp = -nB;
+        } else if constexpr ((S == 1 && (XM & 2) != 0) || (S > 1 && (XM & 1) != 0)) {   // rotate inside the system's 32 lanes
+            Am = rot32_dn<S>(nA); Cm = rot32_dn<S>(nC); Bm = rot32_dn<S>(nB);
+            Ap = rot32_up<S>(nA); Cp = rot32_up<S>(nC); Bp = rot32_up<S>(nB);
         } else if constexpr (S == 1 && TRPL_PCR_S1_LDS == 0) {   // DPP wave rotates
             Am = seam_first<ISO, WS>(lane_dn<1>(nA, lane), lane); Cm = seam_first<ISO, WS>(lane_dn<1>(nC, lane), lane);
             Bm = seam_first<ISO, WS>(lane_dn<1>(nB, lane), lane);
@@ -402,12 +426,12 @@ __device__ __forceinline__ void pcr64_levels(T &A, T &D, T &C, T &Bv, int lane, 
         Bv = Bv - A * Bm - C * Bp;
         A = -A * Am;
         C = -C * Cp;
-        pcr64_levels<T, S * 2, WS, ISO>(A, D, C, Bv, lane, xch);
+        pcr64_levels<T, S * 2, WS, ISO, XM>(A, D, C, Bv, lane, xch);
     }
 }
 
 // one forward cyclic-reduction level with in-lane stride H (rows H, 3H, .. eliminated)
-template <typename T, int NR, int H, int WS = 64, bool ISO = false>
+template <typename T, int NR, int H, int WS = 64, bool ISO = false, int XM = 0>
 __device__ __forceinline__ void cr_forward(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], int lane)
 {
     if constexpr (H < NR) {
@@ -418,9 +442,14 @@ __device__ __forceinline__ void cr_forward(T (&ld)[NR], T (&d)[NR], T (&ud)[NR],
             ld[q] *= r; ud[q] *= r; B[q] *= r;
         }
         // the left neighbour of row 0 is row NR-H of lane l-1
-        const T aL0 = seam_first<ISO, WS>(lane_dn<1>(ld[NR - H], lane), lane),
-                cL0 = seam_first<ISO, WS>(lane_dn<1>(ud[NR - H], lane), lane),
-                bL0 = seam_first<ISO, WS>(lane_dn<1>(B[NR - H], lane), lane);
+        T aL0, cL0, bL0;
+        if constexpr ((XM & 4) != 0) {
+            aL0 = rot32_dn<1>(ld[NR - H]); cL0 = rot32_dn<1>(ud[NR - H]); bL0 = rot32_dn<1>(B[NR - H]);
+        } else {
+            aL0 = seam_first<ISO, WS>(lane_dn<1>(ld[NR - H], lane), lane);
+            cL0 = seam_first<ISO, WS>(lane_dn<1>(ud[NR - H], lane), lane);
+            bL0 = seam_first<ISO, WS>(lane_dn<1>(B[NR - H], lane), lane);
+        }
 #pragma unroll
         for (int p = 0; p < NR; p += 2 * H) {
             const T aL = p == 0 ? aL0 : ld[p == 0 ? 0 : p - H], cL = p == 0 ? cL0 : ud[p == 0 ? 0 : p - H],
@@ -432,7 +461,7 @@ __device__ __forceinline__ void cr_forward(T (&ld)[NR], T (&d)[NR], T (&ud)[NR],
             ld[p] = -a * aL;
             ud[p] = -c * cR;
         }
-        cr_forward<T, NR, 2 * H, WS, ISO>(ld, d, ud, B, lane);
+        cr_forward<T, NR, 2 * H, WS, ISO, XM>(ld, d, ud, B, lane);
     }
 }
 
@@ -451,13 +480,13 @@ __device__ __forceinline__ void cr_backward(const T (&ld)[NR], const T (&ud)[NR]
 }
 
 // WS lanes per system (64: one system per wave; 32: two); the final pairs sit in lanes l, l ^ (WS/2)
-template <typename T, int NR, int WS = 64, bool ISO = false>
+template <typename T, int NR, int WS = 64, bool ISO = false, int XM = 0>
 __device__ __forceinline__ void cr_pcr_solve(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], T (&x)[NR], int lane,
                                              T *xch)
 {
-    cr_forward<T, NR, 1, WS, ISO>(ld, d, ud, B, lane);
+    cr_forward<T, NR, 1, WS, ISO, XM>(ld, d, ud, B, lane);
     T A = ld[0], D = d[0], C = ud[0], Bv = B[0];
-    pcr64_levels<T, 1, WS, ISO>(A, D, C, Bv, lane, xch);
+    pcr64_levels<T, 1, WS, ISO, XM>(A, D, C, Bv, lane, xch);
     const bool low = (lane & (WS / 2)) == 0;       // pairs by Cramer's rule, own unknown only
     const T c_own = low ? C : A;
     T D_oth, B_oth, c_oth;
@@ -465,12 +494,16 @@ __device__ __forceinline__ void cr_pcr_solve(T (&ld)[NR], T (&d)[NR], T (&ud)[NR
         D_oth = D * T(1.5); B_oth = -Bv; c_oth = c_own;
     } else if constexpr (WS == 64) {
         D_oth = partner32(D, low); B_oth = partner32(Bv, low); c_oth = partner32(c_own, low);
+    } else if constexpr (WS == 32 && (XM & 1) != 0) {
+        D_oth = swap16(D); B_oth = swap16(Bv); c_oth = swap16(c_own);
     } else {
         D_oth = __shfl_xor(D, WS / 2, 64); B_oth = __shfl_xor(Bv, WS / 2, 64); c_oth = __shfl_xor(c_own, WS / 2, 64);
     }
     const T X = (Bv * D_oth - c_own * B_oth) * rcp_fast<T>(D * D_oth - c_own * c_oth);
     x[0] = X;
-    const T xnext = seam_last<ISO, WS>(lane_up<1>(X, lane), lane);   // a system's last lane: times c^ = 0
+    T xnext;                                       // a system's last lane: times c^ = 0
+    if constexpr ((XM & 4) != 0) xnext = rot32_up<1>(X);
+    else xnext = seam_last<ISO, WS>(lane_up<1>(X, lane), lane);
     cr_backward<T, NR, NR / 2>(ld, ud, B, x, xnext);
 }
 

@@ -94,7 +94,7 @@ __device__ __forceinline__ void update_field2(const MatPar &m, double a0, const 
     for (int j = 1; j < NR; j++) Ek[j] = act ? b[j] * rA[j] : Ek[j];
 }
 
-template <bool ISO>
+template <bool ISO, int XM>
 __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
 {
     constexpr int LAY = 2;
@@ -124,10 +124,10 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
 
     // ---- state U^t in registers; U^{t-1..t-4} of N and P in a 4-slot LDS ring (slot = t mod 4), E's in registers ----
     constexpr int HSLOT = 2 * NR * 64;
-    constexpr int XCH = 3 * 64;
+    constexpr int XCH = (XM & 1) ? 0 : 3 * 64;      // PCR exchange buffer, only for the LDS-staged levels
     __shared__ __attribute__((aligned(16))) double lds[4 * HSLOT + XCH];
     double *hist = lds;
-    double *xch = lds + 4 * HSLOT;
+    double *xch = lds + 4 * HSLOT;                  // never dereferenced when XCH == 0
     double Nk[NR], Pk[NR], Ek[NR], hE[4][NR];
 #pragma unroll
     for (int j = 0; j < NR; j++) {                  // pvSimPCR.py:356-362
@@ -200,13 +200,13 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
             // ---- electrons (:148-175) ----
             assemble<LAY, true, NR, WS, L>(mp, a0, Nk, Pk, Ek, Ep, bN, lo_, dg, up, bb, ln);
             residual_below2<ISO>(lo_, dg, up, bb, Nk, TOL, lane, okNA, okNB);                      // :172
-            cr_pcr_solve<double, NR, WS, ISO>(lo_, dg, up, bb, x, lane, xch);                       // :175
+            cr_pcr_solve<double, NR, WS, ISO, XM>(lo_, dg, up, bb, x, lane, xch);                       // :175
 #pragma unroll
             for (int j = 0; j < NR; j++) Nk[j] = act ? x[j] : Nk[j];
             // ---- holes, with the updated electrons (:178-202) ----
             assemble<LAY, false, NR, WS, L>(mp, a0, Nk, Pk, Ek, Ep, bP, lo_, dg, up, bb, ln);
             residual_below2<ISO>(lo_, dg, up, bb, Pk, TOL, lane, okPA, okPB);                      // :200
-            cr_pcr_solve<double, NR, WS, ISO>(lo_, dg, up, bb, x, lane, xch);                       // :202
+            cr_pcr_solve<double, NR, WS, ISO, XM>(lo_, dg, up, bb, x, lane, xch);                       // :202
 #pragma unroll
             for (int j = 0; j < NR; j++) Pk[j] = act ? x[j] : Pk[j];
             // ---- field on edges 1..L-1 (:205-209) ----
@@ -263,13 +263,13 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
 
 }  // namespace pair
 
-template <bool ISO>
+template <bool ISO, int XM>
 hipError_t launch_stepper_pair_t(const StepArgs &a, hipStream_t stream)
 {
     if (a.L != pair::L) return hipErrorInvalidValue;
     const int64_t nblk = ((a.S + 1) / 2) * a.C;
     if (nblk <= 0) return hipSuccess;
-    hipLaunchKernelGGL((pair::stepper_pair_kernel<ISO>), dim3((unsigned)nblk), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL((pair::stepper_pair_kernel<ISO, XM>), dim3((unsigned)nblk), dim3(64), 0, stream, a);
     return hipGetLastError();
 }
 

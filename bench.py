@@ -175,6 +175,16 @@ def main():
     flop_launch = it_total * FLOP_PER_ITER_PER_NODE * L       # this rank's launch
     achieved_tf = flop_launch / (kern_ms * 1e-3) / 1e12
 
+    # which time-stepper this launch ran (the library picks the two-systems-per-wavefront kernel for
+    # fp64 L = 128 launches that fill the chip)
+    variant = trpl_amd._abi.lib().trpl_kernel_variant(int(args.samples_per_gpu) * C, L, flags)
+    if variant == trpl_amd._abi.KERNEL_FAST_PAIR:
+        kernel_name = "pair::stepper_pair_kernel (2 x L=128 systems per wavefront; fused time-stepper + likelihood)"
+        rocprof_name = "void trpl::pair::stepper_pair_kernel<true, 1>"
+    else:
+        kernel_name = "%sstepper_kernel<%d> (fused time-stepper + likelihood)" % ("f32::" if args.fp32 else "", L)
+        rocprof_name = ("void trpl::f32::stepper_kernel<%d>" % L) if args.fp32 else \
+            "void trpl::stepper_kernel<%d, %s>" % (L, "true" if args.strict else "false")
     out = {
         "metric": "TRPL system-timesteps/s at %d nodes (fused solve + log-likelihood)" % L,
         "value": value,
@@ -199,7 +209,7 @@ def main():
         "inner_iterations_per_s": it_all * args.steps / elapsed,
         "mean_inner_iterations_per_step": it_all / sys_steps,
         "nonconverged_systems": fail_all,
-        "roofline": {"kernel": "%sstepper_kernel<%d> (fused time-stepper + likelihood)" % ("f32::" if args.fp32 else "", L),
+        "roofline": {"kernel": kernel_name, "rocprof_name": rocprof_name,
                      "bound": "valu-fp32" if args.fp32 else "valu-fp64",
                      "achieved": achieved_tf, "peak": FP64_VECTOR_PEAK_TFLOPS * (2 if args.fp32 else 1), "unit": "TFLOP/s",
                      "frac": achieved_tf / (FP64_VECTOR_PEAK_TFLOPS * (2 if args.fp32 else 1)), "traffic": None,
@@ -234,9 +244,7 @@ def attach_traffic(out):
         return
     t = json.load(open(files[-1]))
     src = os.path.basename(files[-1])
-    if "stepper_kernel<128>" not in out["roofline"]["kernel"] or "f32" in out["roofline"]["kernel"]:
-        return                                               # the committed PMC profile is of the fp64 L=128 kernels
-    for key, obj in (("void trpl::stepper_kernel<128, false>", "roofline"),
+    for key, obj in ((out["roofline"]["rocprof_name"], "roofline"),
                      ("void trpl::pcr_batched_kernel<double, 128, false>", "roofline_hbm_pcr")):
         if key in t and obj in out and (obj == "roofline" or "double,128" in out[obj]["kernel"]):
             out[obj]["traffic"] = t[key]["hbm_bytes_per_launch"]

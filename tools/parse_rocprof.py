@@ -19,8 +19,14 @@ OURS = ("trpl::",)
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
 json.dump(bench, open(os.path.join(dst, tag + "_bench.json"), "w"), indent=1)
 
+def newest(pattern):
+    """gpurun merges every run of a tag into the same directory: keep the latest run's file only."""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
+
+
 rows = []
-for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
+for f in newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
     for r in csv.DictReader(open(f)):
         if any(k in r["Name"] for k in OURS):
             rows.append(r)
@@ -32,7 +38,7 @@ with open(os.path.join(dst, tag + "_rocprof_kernel_stats.csv"), "w") as f:
 
 traffic = {}
 for cname in ("FETCH_SIZE", "WRITE_SIZE"):
-    for f in glob.glob(os.path.join(src, "pmc_" + cname, "*", "*_counter_collection.csv")):
+    for f in newest(os.path.join(src, "pmc_" + cname, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != cname or not any(k in r["Kernel_Name"] for k in OURS):
                 continue

@@ -5,7 +5,7 @@ tag = sys.argv[1]
 res = {}
 for d in sorted(glob.glob('gpurun_out/pmc_%s_*/*/*_counter_collection.csv' % tag)):
     for r in csv.DictReader(open(d)):
-        if 'stepper_kernel<128, false>' in r['Kernel_Name']:
+        if 'stepper_kernel<128, false>' in r['Kernel_Name'] or 'stepper_pair_kernel' in r['Kernel_Name']:
             res[r['Counter_Name']] = res.get(r['Counter_Name'], 0) + float(r['Counter_Value'])
 for k, v in sorted(res.items()):
     print("   %-28s %.4g" % (k, v))
