@@ -7,7 +7,7 @@ The directory name carries hyphens, so import it through the repo-root alias `tr
 """
 from . import _abi  # noqa: F401
 from ._abi import FLAG_FP32, FLAG_NORMALIZE, FLAG_PL_F32, FLAG_STRICT, TrplError  # noqa: F401
-from . import dataio, device, dist, workloads  # noqa: F401
+from . import dataio, device, dist, posterior, workloads  # noqa: F401
 from .dataio import export, get_data, get_initpoints  # noqa: F401
 from .driver import almost_equal, bayes, bracket_times, interp_rows, is_grid_prefix, loglik, simulate  # noqa: F401
 from .likelihood import fastlog, prob  # noqa: F401

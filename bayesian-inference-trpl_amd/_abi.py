@@ -52,6 +52,13 @@ SIGNATURES = {
                           _vp, _vp, _vp, _vp, _vp, _u32, _vp, _i32, _pd],
     "trpl_shard_bounds": [_i64, _i32, _i32, _vp, _vp],
     "trpl_kernel_variant": [_i64, _i32, _u32],
+    "trpl_posterior_workspace_bytes": [_i32],
+    "trpl_posterior_weights": [_vp, _i64, _f64, _vp, _vp, _i32, _pd],
+    "trpl_posterior_weights_dev": [_vp, _i64, _f64, _vp, _vp, _vp, _i64, _vp],
+    "trpl_posterior_moments": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _pd],
+    "trpl_posterior_moments_dev": [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "trpl_posterior_hist": [_vp, _vp, _vp, _i64, _f64, _f64, _i32, _f64, _f64, _i32, _vp, _i32, _pd],
+    "trpl_posterior_hist_dev": [_vp, _vp, _vp, _i64, _f64, _f64, _i32, _f64, _f64, _i32, _vp, _vp],
     "trpl_pcr_solve_batched": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _u32, _i32, _pd],
     "trpl_pcr_solve_batched_dev": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _u32, _vp],
 }
@@ -84,7 +91,8 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(dll, name)
             fn.argtypes = argtypes
-            fn.restype = C.c_char_p if name == "trpl_last_error" else C.c_int
+            fn.restype = C.c_char_p if name == "trpl_last_error" else (
+                C.c_int64 if name == "trpl_posterior_workspace_bytes" else C.c_int)
         _lib = dll
     return _lib
 

@@ -532,6 +532,137 @@ int trpl_loglik_multi(const double *X, int64_t S, int32_t C, const double *lengt
     return rc;
 }
 
+/* ------------------------------------------------------------------ posterior core ------ */
+int64_t trpl_posterior_workspace_bytes(int32_t D) { return (int64_t)trpl::posterior_workspace_bytes(D); }
+
+int trpl_posterior_weights_dev(const double *LL, int64_t S, double tf, double *W, double *stats, void *workspace,
+                               int64_t workspace_bytes, void *stream)
+{
+    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (S == 0) return TRPL_OK;
+    if (!LL || !W || !workspace) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (!(tf > 0)) return fail(TRPL_ERR_ARG, "tf must be > 0");
+    if (workspace_bytes < (int64_t)trpl::posterior_workspace_bytes(1)) return fail(TRPL_ERR_ARG, "workspace too small");
+    hipError_t e = trpl::launch_posterior_weights(LL, S, tf, W, stats, (double *)workspace, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(TRPL_ERR_HIP, "posterior weights launch: %s", hipGetErrorString(e));
+    return TRPL_OK;
+}
+
+int trpl_posterior_weights(const double *LL, int64_t S, double tf, double *W, double *stats, int32_t device,
+                           double *seconds)
+{
+    if (seconds) *seconds = 0.0;
+    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (S == 0) return TRPL_OK;
+    if (!LL || !W) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (!(tf > 0)) return fail(TRPL_ERR_ARG, "tf must be > 0");
+    if (int rc = select_device(device)) return rc;
+    DevBuf dL, dW, dSt, ws;
+    const size_t wsb = trpl::posterior_workspace_bytes(1);
+    HIP_TRY(dL.alloc((size_t)S * 8)); HIP_TRY(dW.alloc((size_t)S * 8)); HIP_TRY(dSt.alloc(16)); HIP_TRY(ws.alloc(wsb));
+    HIP_TRY(hipMemcpy(dL.p, LL, (size_t)S * 8, hipMemcpyHostToDevice));
+    const double t0 = now_s();
+    if (int rc = trpl_posterior_weights_dev(dL.as<double>(), S, tf, dW.as<double>(), dSt.as<double>(), ws.p, (int64_t)wsb, nullptr))
+        return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (seconds) *seconds = now_s() - t0;
+    HIP_TRY(hipMemcpy(W, dW.p, (size_t)S * 8, hipMemcpyDeviceToHost));
+    if (stats) HIP_TRY(hipMemcpy(stats, dSt.p, 16, hipMemcpyDeviceToHost));
+    return TRPL_OK;
+}
+
+int trpl_posterior_moments_dev(const double *V, int64_t S, int32_t D, const double *W, const double *mean_in, double *sums,
+                               double *central, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (D < 1 || D > 16) return fail(TRPL_ERR_ARG, "D=%d must be in [1, 16]", D);
+    if (S == 0) return TRPL_OK;
+    if (!V || !W || !sums || !central || !workspace) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (workspace_bytes < (int64_t)trpl::posterior_workspace_bytes(D)) return fail(TRPL_ERR_ARG, "workspace too small");
+    hipError_t e = trpl::launch_posterior_moments(V, W, S, D, mean_in, sums, central, (double *)workspace, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(TRPL_ERR_HIP, "posterior moments launch: %s", hipGetErrorString(e));
+    return TRPL_OK;
+}
+
+int trpl_posterior_moments(const double *V, int64_t S, int32_t D, const double *W, const double *mean_in, double *sums,
+                           double *central, int32_t device, double *seconds)
+{
+    if (seconds) *seconds = 0.0;
+    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (D < 1 || D > 16) return fail(TRPL_ERR_ARG, "D=%d must be in [1, 16]", D);
+    if (!sums || !central) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    memset(sums, 0, sizeof(double) * (2 + D));
+    memset(central, 0, sizeof(double) * D * (D + 2));
+    if (S == 0) return TRPL_OK;
+    if (!V || !W) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (int rc = select_device(device)) return rc;
+    DevBuf dV, dW, dS, dC, dM, ws;
+    const size_t wsb = trpl::posterior_workspace_bytes(D);
+    if (mean_in) { HIP_TRY(dM.alloc((size_t)D * 8)); HIP_TRY(hipMemcpy(dM.p, mean_in, (size_t)D * 8, hipMemcpyHostToDevice)); }
+    HIP_TRY(dV.alloc((size_t)S * D * 8)); HIP_TRY(dW.alloc((size_t)S * 8)); HIP_TRY(dS.alloc((2 + D) * 8));
+    HIP_TRY(dC.alloc((size_t)D * (D + 2) * 8)); HIP_TRY(ws.alloc(wsb));
+    HIP_TRY(hipMemcpy(dV.p, V, (size_t)S * D * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dW.p, W, (size_t)S * 8, hipMemcpyHostToDevice));
+    const double t0 = now_s();
+    if (int rc = trpl_posterior_moments_dev(dV.as<double>(), S, D, dW.as<double>(), mean_in ? dM.as<double>() : nullptr,
+                                            dS.as<double>(), dC.as<double>(), ws.p,
+                                            (int64_t)wsb, nullptr))
+        return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (seconds) *seconds = now_s() - t0;
+    HIP_TRY(hipMemcpy(sums, dS.p, (2 + D) * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(central, dC.p, (size_t)D * (D + 2) * 8, hipMemcpyDeviceToHost));
+    return TRPL_OK;
+}
+
+static int check_hist(int64_t S, double xlo, double xhi, int32_t xb, const double *y, double ylo, double yhi, int32_t yb)
+{
+    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (xb < 1 || !(xhi > xlo)) return fail(TRPL_ERR_ARG, "x axis needs bins >= 1 and hi > lo");
+    if (y && (yb < 1 || !(yhi > ylo))) return fail(TRPL_ERR_ARG, "y axis needs bins >= 1 and hi > lo");
+    if ((int64_t)xb * (y ? yb : 1) > (1 << 24)) return fail(TRPL_ERR_ARG, "too many bins");
+    return TRPL_OK;
+}
+
+int trpl_posterior_hist_dev(const double *x, const double *y, const double *W, int64_t S, double xlo, double xhi,
+                            int32_t xbins, double ylo, double yhi, int32_t ybins, double *out, void *stream)
+{
+    if (int rc = check_hist(S, xlo, xhi, xbins, y, ylo, yhi, ybins)) return rc;
+    if (S == 0) return TRPL_OK;
+    if (!x || !out) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    hipError_t e = trpl::launch_posterior_hist(x, y, W, S, xlo, xhi, xbins, ylo, yhi, ybins, out, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(TRPL_ERR_HIP, "posterior histogram launch: %s", hipGetErrorString(e));
+    return TRPL_OK;
+}
+
+int trpl_posterior_hist(const double *x, const double *y, const double *W, int64_t S, double xlo, double xhi,
+                        int32_t xbins, double ylo, double yhi, int32_t ybins, double *out, int32_t device,
+                        double *seconds)
+{
+    if (seconds) *seconds = 0.0;
+    if (int rc = check_hist(S, xlo, xhi, xbins, y, ylo, yhi, ybins)) return rc;
+    if (!out) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    const size_t nb = (size_t)xbins * (y ? ybins : 1);
+    memset(out, 0, nb * 8);
+    if (S == 0) return TRPL_OK;
+    if (!x) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (int rc = select_device(device)) return rc;
+    DevBuf dx, dy, dW, dO;
+    HIP_TRY(dx.alloc((size_t)S * 8)); HIP_TRY(dO.alloc(nb * 8));
+    HIP_TRY(hipMemcpy(dx.p, x, (size_t)S * 8, hipMemcpyHostToDevice));
+    if (y) { HIP_TRY(dy.alloc((size_t)S * 8)); HIP_TRY(hipMemcpy(dy.p, y, (size_t)S * 8, hipMemcpyHostToDevice)); }
+    if (W) { HIP_TRY(dW.alloc((size_t)S * 8)); HIP_TRY(hipMemcpy(dW.p, W, (size_t)S * 8, hipMemcpyHostToDevice)); }
+    HIP_TRY(hipMemset(dO.p, 0, nb * 8));
+    const double t0 = now_s();
+    if (int rc = trpl_posterior_hist_dev(dx.as<double>(), y ? dy.as<double>() : nullptr, W ? dW.as<double>() : nullptr, S, xlo,
+                                         xhi, xbins, ylo, yhi, ybins, dO.as<double>(), nullptr))
+        return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (seconds) *seconds = now_s() - t0;
+    HIP_TRY(hipMemcpy(out, dO.p, nb * 8, hipMemcpyDeviceToHost));
+    return TRPL_OK;
+}
+
 /* ------------------------------------------------------------------ batched PCR --------- */
 int trpl_pcr_solve_batched_dev(const void *ld, const void *d, const void *ud, const void *b, void *x, int64_t S,
                                int32_t L, int32_t elem_bytes, uint32_t flags, void *stream)

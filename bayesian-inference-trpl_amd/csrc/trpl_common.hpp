@@ -57,6 +57,15 @@ hipError_t launch_sse_accumulate(double *P, const void *pl, int elem_bytes, int6
                                  int64_t ld, const double *values, const double *mag, hipStream_t stream);
 hipError_t launch_reduce_curves(double *P, const double *sse, int64_t S, int C, hipStream_t stream);
 
+// posterior.hip: the consumer of P[S] (weights, weighted moments, weighted histograms)
+size_t posterior_workspace_bytes(int D);
+hipError_t launch_posterior_weights(const double *LL, int64_t S, double tf, double *W, double *stats, double *ws,
+                                    hipStream_t st);
+hipError_t launch_posterior_moments(const double *V, const double *W, int64_t S, int D, const double *mean_in, double *sums,
+                                    double *central, double *ws, hipStream_t st);
+hipError_t launch_posterior_hist(const double *x, const double *y, const double *W, int64_t S, double xlo, double xhi,
+                                 int xb, double ylo, double yhi, int yb, double *out, hipStream_t st);
+
 // batched tridiagonal solve (pcr_batched_impl.hpp, instantiated in both arithmetic modes)
 hipError_t launch_pcr_batched_strict(const void *ld, const void *d, const void *ud, const void *b, void *x,
                                      int64_t S, int L, int elem_bytes, hipStream_t stream);

@@ -87,3 +87,58 @@ def pcr_solve_device(ld, d, ud, b, x, flags=0):
     _abi.check(_abi.lib().trpl_pcr_solve_batched_dev(_chk(ld, dt, "ld"), _chk(d, dt, "d"), _chk(ud, dt, "ud"),
                                                      _chk(b, dt, "b"), _chk(x, dt, "x"), S, L, d.element_size(),
                                                      int(flags), _stream()))
+
+
+# ---- posterior core, device-resident (trpl_posterior_*_dev) ----
+def posterior_workspace(D=16):
+    """A workspace tensor large enough for any posterior_*_device call with up to D columns."""
+    import torch
+    n = int(_abi.lib().trpl_posterior_workspace_bytes(int(D)))
+    return torch.empty(n // 8, dtype=torch.float64, device="cuda")
+
+
+def posterior_weights_device(LL, tf, W, workspace, stats=None):
+    """W <- normalize(LL / tf) (Visualization/utils.py:157-166); LL, W (S,) f64; stats (2,) f64 optional
+    {max, raw sum}."""
+    import torch
+    if LL.shape != W.shape or LL.dim() != 1:
+        raise ValueError("LL and W must be (S,)")
+    _abi.check(_abi.lib().trpl_posterior_weights_dev(
+        _chk(LL, torch.float64, "LL"), LL.shape[0], float(tf), _chk(W, torch.float64, "W"),
+        None if stats is None else _chk(stats, torch.float64, "stats"), _chk(workspace, torch.float64, "workspace"),
+        workspace.numel() * 8, _stream()))
+
+
+def posterior_moments_device(V, W, sums, central, workspace, mean_in=None):
+    """V (D,S), W (S,) -> sums (2+D,), central (D, D+2) as trpl_posterior_moments defines them."""
+    import torch
+    D, S = V.shape
+    if tuple(W.shape) != (S,) or tuple(sums.shape) != (2 + D,) or tuple(central.shape) != (D, D + 2):
+        raise ValueError("shape mismatch")
+    _abi.check(_abi.lib().trpl_posterior_moments_dev(
+        _chk(V, torch.float64, "V"), S, D, _chk(W, torch.float64, "W"),
+        None if mean_in is None else _chk(mean_in, torch.float64, "mean_in"), _chk(sums, torch.float64, "sums"),
+        _chk(central, torch.float64, "central"), _chk(workspace, torch.float64, "workspace"), workspace.numel() * 8,
+        _stream()))
+
+
+def posterior_hist_device(x, W, lo, hi, out, y=None, ylo=0.0, yhi=1.0):
+    """out (bins,) or (bins, ybins) += weighted counts (W None: counts); the caller zeroes out."""
+    import torch
+    xb = out.shape[0]
+    yb = out.shape[1] if y is not None else 1
+    _abi.check(_abi.lib().trpl_posterior_hist_dev(
+        _chk(x, torch.float64, "x"), None if y is None else _chk(y, torch.float64, "y"),
+        None if W is None else _chk(W, torch.float64, "W"), x.shape[0], float(lo), float(hi), int(xb), float(ylo),
+        float(yhi), int(yb), _chk(out, torch.float64, "out"), _stream()))
+
+
+def credible_interval_device(x, W, lo=0.025, hi=0.975):
+    """utils.py:185-196 on the device: sort by x, cumulate the weights, last point below `lo` and first
+    above `hi` (torch.sort / cumsum: library plumbing, no custom kernel)."""
+    import torch
+    xs, order = torch.sort(x)
+    cs = torch.cumsum(W[order], 0)
+    below = torch.nonzero(cs < lo)
+    above = torch.nonzero(cs > hi)
+    return float(xs[below[-1, 0]]), float(xs[above[0, 0]])

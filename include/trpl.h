@@ -190,6 +190,45 @@ int trpl_loglik_multi(const double *X, int64_t S, int32_t C, const double *lengt
 int trpl_shard_bounds(int64_t S, int32_t n_shards, int32_t shard, int64_t *lo, int64_t *hi);
 
 /* ---------------------------------------------------------------------------------------
+ * Posterior core -- the consumer of the likelihood vector: replaces the numpy reductions
+ * of Visualization/utils.py on *_BAYRAN_{P,X}.npy.  Streaming, HBM-bound (8 B of likelihood + 8 B per
+ * parameter column per sample); results are small arrays a multi-GPU caller can all-reduce.
+ *
+ * trpl_posterior_weights: normalize(LL / tf)  (utils.py:157-166, marginalization_visual.py:589-591):
+ *     W[i] = exp(LL[i]/tf - nanmax(LL/tf) + 1000 ln 2 - ln S) / nansum(same);  NaN stays NaN, -inf gives 0.
+ * trpl_posterior_moments: V is [D][S] (one contiguous column per parameter, D <= 16), W the weights;
+ *     sums[2+D]      = { sum w, sum w^2, sum w v_d }
+ *     central[D][D+2] = { sum w (v_d - m_d)(v_e - m_e) for e < D,  sum w (v_d - m_d)^3,  sum w (v_d - m_d)^4 }
+ *     with m = sum w v / sum w: w_mean :197-199, w_variance :202-204, covariance :222-227, w_skew :207-210,
+ *     w_kurtosis :212-215 and the weighted sample deviation :168-170 are quotients of these.
+ * trpl_posterior_hist: weighted counts (W == NULL: plain counts) of x (and y, for 2-D) in `bins` equal
+ *     bins whose edges are lo + (hi - lo) * k / bins exactly as marginalize_1D :243-244 / marginalize_2D
+ *     :270-277 build them, with numpy.histogram's rules (left-closed, last bin closed, outside and NaN
+ *     dropped); out[xbins] or out[xbins][ybins]; density normalisation is the caller's one-liner.
+ * For callers that hold a shard of the samples (one process per GPU): `stats` = { nanmax(LL/tf), nansum of
+ * the unnormalised weights } lets the shards' weights be renormalised to the global sum; `mean_in` [D]
+ * centres the second call about the all-reduced means; histograms and sums add across shards.
+ * The _dev forms take device pointers (out must be zeroed by the caller for hist) and a workspace of
+ * trpl_posterior_workspace_bytes(D) bytes (D = 1 for the weights); nothing is allocated.
+ * ------------------------------------------------------------------------------------- */
+int64_t trpl_posterior_workspace_bytes(int32_t D);
+int trpl_posterior_weights(const double *LL, int64_t S, double tf, double *W, double *stats /*nullable [2]*/,
+                           int32_t device, double *seconds);
+int trpl_posterior_weights_dev(const double *LL, int64_t S, double tf, double *W, double *stats, void *workspace,
+                               int64_t workspace_bytes, void *stream);
+int trpl_posterior_moments(const double *V, int64_t S, int32_t D, const double *W, const double *mean_in /*nullable*/,
+                           double *sums, double *central, int32_t device, double *seconds);
+int trpl_posterior_moments_dev(const double *V, int64_t S, int32_t D, const double *W, const double *mean_in,
+                               double *sums, double *central, void *workspace, int64_t workspace_bytes,
+                               void *stream);
+int trpl_posterior_hist(const double *x, const double *y /*nullable: 1-D*/, const double *W /*nullable*/,
+                        int64_t S, double xlo, double xhi, int32_t xbins, double ylo, double yhi,
+                        int32_t ybins, double *out, int32_t device, double *seconds);
+int trpl_posterior_hist_dev(const double *x, const double *y, const double *W, int64_t S, double xlo,
+                            double xhi, int32_t xbins, double ylo, double yhi, int32_t ybins, double *out,
+                            void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * trpl_pcr_solve_batched_dev -- the stand-alone batched tridiagonal solve (unit U1 of the
  * measurement plan): S independent systems  ld[i] x[i-1] + d[i] x[i] + ud[i] x[i+1] = b[i],
  * i < L, by parallel cyclic reduction with pcreduce's elimination order (pvSimPCR.py:42-81),

@@ -15,6 +15,8 @@ Reference entry points exercised (file:line):
   pvSim_fallback.pvSim_cpu_fallback :80-117 (as shipped)    -> fallback.npz
   bayes_io.get_initpoints :106-119, get_data :15-104 + bayes -> bayes_realdata.npz
   Legacy/pvSim.pvSim :129-173; Testing/PV_tester2.dydt :13-49 + odeint -> legacy_odeint.npz
+  Visualization/utils.py normalize :157-166, w_* :185-226, covariance :222-227, credible_interval :185-196,
+  marginalize_1D :239-262, marginalize_2D :264-285 (tempering: marginalization_visual.py:589-591) -> posterior.npz
 
 Usage:  python oracle/gen_golden.py [case ...]     (default: all cases)
 """
@@ -351,7 +353,60 @@ def case_legacy_odeint():
                         a_nm3=a_nm3, l_nm=l_nm, plI_legacy=plI, iters_legacy=np.array(itrs), plI_odeint=pl_ode)
 
 
-CASES = {"legacy_odeint": case_legacy_odeint, "csv_fixture": case_csv_fixture, "bayes_realdata": case_bayes_realdata, "pcr_norm": case_pcr_norm, "probs": case_probs, "sampler": case_sampler,
+def case_posterior():
+    """The numeric core of the GUI that consumes *_BAYRAN_{P,X}.npy, run as shipped (statsmodels stand-in:
+    refshim/statsmodels, only needed for the module-level import)."""
+    sys.path.insert(0, os.path.join(REF, "Visualization"))
+    import contextlib
+    import io
+    import utils as vis                                                      # (reference)
+    S = 3000
+    Xs = draw(S, seed=7)                                                     # solver units
+    X = Xs / UNIT                                                            # the GUI works on *_BAYRAN_X.npy (raw units)
+    rng = np.random.RandomState(3)
+    # a likelihood surface with the scale of a real run (sum of ~1e4 squared log errors): peaked near
+    # the marked point in (p0, B, tau_n, tau_p), long tails elsewhere, some NaN and -inf entries
+    z = np.stack([np.log10(X[:, 1] / MARK[1]), np.log10(X[:, 4] / MARK[4]), (X[:, 9] - MARK[9]) / 400.0,
+                  (X[:, 10] - MARK[10]) / 800.0, (X[:, 2] - X[:, 3]) / 60.0], axis=1)
+    LL = -2.0e4 * np.sum(z ** 2, axis=1) - 50.0 * rng.rand(S)
+    LL[rng.choice(S, 25, replace=False)] = np.nan
+    LL[rng.choice(S, 15, replace=False)] = -np.inf
+    keep = ~np.isnan(LL)                                                     # LikelihoodData.filter_nan :33-38
+    LLk, Xk = LL[keep], X[keep]
+    n_obs, c = 3 * 8000.0, 2.0
+    tf = n_obs * c                                                           # marginalization_visual.py:589
+    P = vis.normalize(LLk / tf)                                              # :590-591
+    cols = {"p0": np.log10(Xk[:, 1]), "mu_n": Xk[:, 2], "mu_p": Xk[:, 3], "B": np.log10(Xk[:, 4]),
+            "tau_n": Xk[:, 9], "tau_p": Xk[:, 10]}
+    names = list(cols)
+    mean = np.array([vis.w_mean(cols[k], P) for k in names])
+    var = np.array([vis.w_variance(cols[k], P) for k in names])
+    ws = np.sum(P ** 2)
+    sstd = np.array([vis.w_sample_var(cols[k], P, ws) for k in names])
+    skew = np.array([vis.w_skew(cols[k], P) for k in names])
+    kurt = np.array([vis.w_kurtosis(cols[k], P) for k in names])
+    cov = np.array([[vis.covariance(cols[a], cols[b], P) for b in names] for a in names])
+    with contextlib.redirect_stdout(io.StringIO()):
+        ci = np.array([vis.credible_interval(cols[k], P) for k in names])
+    limits = {"p0": (14.0, 16.0), "mu_n": (0.0, 50.0), "mu_p": (0.0, 50.0), "B": (-11.0, -9.0),
+              "tau_n": (1.0, 1000.0), "tau_p": (100.0, 1500.0)}             # tau_p: narrower than the data
+    secondary = {k: False for k in names}
+    bins = 32
+    h1 = {}
+    for k in names:                                                          # "mu" in the name -> sampling correction
+        marP, edges = vis.marginalize_1D(P, limits, bins, secondary, k, cols[k])
+        h1[k] = (marP, edges)
+    pairs = [("p0", "B"), ("tau_n", "tau_p"), ("mu_n", "p0")]
+    h2 = [vis.marginalize_2D(P, limits, bins, secondary, pr, cols[pr[0]], cols[pr[1]])[0] for pr in pairs]
+    np.savez_compressed(os.path.join(OUT, "posterior.npz"), X=X, LL=LL, tf=tf, names=np.array(names), P=P,
+                        col_index=np.array([1, 2, 3, 4, 9, 10]), col_log=np.array([1, 0, 0, 1, 0, 0]), mean=mean, var=var, ws=ws, sstd=sstd,
+                        skew=skew, kurt=kurt, cov=cov, ci=ci, bins=bins,
+                        limits=np.array([limits[k] for k in names]),
+                        h1=np.stack([h1[k][0] for k in names]), edges=np.stack([h1[k][1] for k in names]),
+                        pairs=np.array([[names.index(a), names.index(b)] for a, b in pairs]), h2=np.stack(h2))
+
+
+CASES = {"posterior": case_posterior, "legacy_odeint": case_legacy_odeint, "csv_fixture": case_csv_fixture, "bayes_realdata": case_bayes_realdata, "pcr_norm": case_pcr_norm, "probs": case_probs, "sampler": case_sampler,
          "pvsim_small": case_pvsim_small, "pvsim_power": case_pvsim_power,
          "pvsim_twothick": case_pvsim_twothick, "bayes_e2e": case_bayes_e2e,
          "fallback": case_fallback}

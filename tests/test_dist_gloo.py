@@ -69,3 +69,68 @@ def _worker_small(rank, world, port, S):
 def test_gather_with_fewer_samples_than_ranks():
     mp.spawn(_worker_small, args=(2, _free_port(), 1), nprocs=2, join=True)
     mp.spawn(_worker_small, args=(2, _free_port(), 5), nprocs=2, join=True)
+
+
+# ---- posterior core over shards (dist.posterior_*_sharded); the CPU oracle stands in for the device calls ----
+def _posterior_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import posterior as op
+    import trpl_amd
+    g = np.load(os.path.join(GOLDEN, "posterior.npz"))
+    X, LL = op.filter_nan(g["X"], g["LL"])
+    tf = float(g["tf"])
+    cols = np.stack([np.log10(X[:, i]) if lg else X[:, i] for i, lg in zip(g["col_index"], g["col_log"])])
+    lo, hi = trpl_amd.dist.shard_bounds(len(LL), world, rank)
+    if rank == 1:
+        lo = hi                                     # an empty shard must not disturb the others
+    if rank == 2:
+        lo = trpl_amd.dist.shard_bounds(len(LL), world, 1)[0]
+
+    def local_weights(ll, tf_):
+        q = ll / tf_
+        mx = np.nanmax(q)
+        w = np.exp(q - mx + 1000 * np.log(2) - np.log(q.size))
+        return w / np.nansum(w), mx, np.nansum(w)
+
+    def local_moments(V, W, mean_in):
+        sw = W.sum()
+        sums = np.concatenate([[sw, (W ** 2).sum()], V @ W])
+        m = sums[2:] / sw if mean_in is None else mean_in
+        Vc = V - m[:, None]
+        central = np.concatenate([(Vc * W) @ Vc.T, ((Vc ** 3) @ W)[:, None], ((Vc ** 4) @ W)[:, None]], axis=1)
+        return sums, central
+
+    W = trpl_amd.dist.posterior_weights_sharded(LL[lo:hi], tf, local_weights=local_weights)
+    sums, central = trpl_amd.dist.posterior_summary_sharded(cols[:, lo:hi], W, local_moments=local_moments)
+    e = op.edges(*g["limits"][0], int(g["bins"]))
+    k = op.bin_index(cols[0, lo:hi], e)
+    h = trpl_amd.dist.posterior_hist_sharded(np.bincount(k[k >= 0], weights=W[k >= 0], minlength=int(g["bins"])))
+    np.savez(os.path.join(out_dir, "post_rank%d.npz" % rank), W=W, lo=lo, hi=hi, sums=sums, central=central, h=h)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_posterior_shards_combine_to_the_single_process_result(tmp_path):
+    """3 ranks (one with an empty shard): renormalised weights, all-reduced moments and histogram equal
+    the reference's single-array results stored in the golden."""
+    world = 3
+    mp.spawn(_posterior_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g = np.load(os.path.join(GOLDEN, "posterior.npz"))
+    parts = [np.load(os.path.join(str(tmp_path), "post_rank%d.npz" % r)) for r in range(world)]
+    W = np.concatenate([p["W"] for p in parts])
+    assert W.shape == g["P"].shape and np.allclose(W, g["P"], rtol=1e-12, atol=0)
+    D = len(g["mean"])
+    for p in parts:
+        sw = p["sums"][0]
+        assert abs(sw - 1) < 1e-12
+        assert np.allclose(p["sums"][2:] / sw, g["mean"], rtol=1e-12)
+        assert np.allclose(p["central"][:, :D] / sw, g["cov"], rtol=1e-9, atol=1e-18)
+        var = np.diag(p["central"][:, :D]) / sw
+        assert np.allclose(np.sqrt(p["sums"][1] * var), g["sstd"], rtol=1e-10)
+        assert np.allclose((p["central"][:, D] / sw) / var ** 1.5, g["skew"], rtol=1e-9)
+        assert np.allclose((p["central"][:, D + 1] / sw) / var ** 2, g["kurt"], rtol=1e-9)
+        dens = p["h"] / (np.diff(g["edges"][0]) * p["h"].sum())
+        assert np.allclose(dens, g["h1"][0], rtol=1e-10, atol=1e-14)

@@ -153,3 +153,27 @@ def test_against_legacy_pvsim_and_odeint(oracle, golden):
     assert np.max(np.abs(pl / g["plI_legacy"] - 1)) < 1e-3
     assert np.max(np.abs(pl / g["plI_odeint"] - 1)) < 2e-2
     assert np.max(np.abs(pl[:, -1] / g["plI_odeint"][:, -1] - 1)) < 5e-4
+
+
+def test_posterior_core_restatement_matches_the_reference(golden):
+    """oracle/posterior.py against the outputs of the reference's own Visualization/utils.py functions
+    (normalize, w_*, covariance, credible_interval, marginalize_1D/2D; golden made by gen_golden.py)."""
+    from oracle import posterior as op
+    g = golden("posterior")
+    X, LL = op.filter_nan(g["X"], g["LL"])
+    assert len(LL) == len(g["P"]) and np.isinf(LL).any()
+    P = op.weights(LL, float(g["tf"]))
+    assert np.array_equal(P, g["P"])
+    cols = [np.log10(X[:, i]) if lg else X[:, i] for i, lg in zip(g["col_index"], g["col_log"])]
+    for k, c in enumerate(cols):
+        assert op.w_mean(c, P) == g["mean"][k] and op.w_variance(c, P) == g["var"][k]
+        assert op.w_sample_std(c, P) == g["sstd"][k]
+        assert np.isclose(op.w_skew(c, P), g["skew"][k], rtol=1e-14) and np.isclose(op.w_kurtosis(c, P), g["kurt"][k], rtol=1e-14)
+        assert op.credible_interval(c, P) == tuple(g["ci"][k])
+        dens, e = op.marginalize_1D(P, *g["limits"][k], int(g["bins"]), c, correct_sampling="mu" in str(g["names"][k]))
+        assert np.array_equal(e, g["edges"][k]) and np.allclose(dens, g["h1"][k], rtol=1e-11, atol=1e-15)
+    cov = np.array([[op.covariance(a, b, P) for b in cols] for a in cols])
+    assert np.allclose(cov, g["cov"], rtol=1e-14, atol=0)
+    for (a, b), h in zip(g["pairs"], g["h2"]):
+        assert np.allclose(op.marginalize_2D(P, g["limits"][a], g["limits"][b], int(g["bins"]), cols[a], cols[b]), h,
+                           rtol=1e-12, atol=1e-16)
