@@ -663,6 +663,48 @@ int trpl_posterior_hist(const double *x, const double *y, const double *W, int64
     return TRPL_OK;
 }
 
+/* ------------------------------------------------------------------ sampler -------------- */
+static int check_box(int64_t S, int32_t ncol, const double *lo, const double *hi, const int32_t *do_log)
+{
+    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (ncol < 1 || ncol > 16) return fail(TRPL_ERR_ARG, "ncol=%d must be in [1, 16]", ncol);
+    if (!lo || !hi || !do_log) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    for (int c = 0; c < ncol; c++) {
+        if (!(lo[c] <= hi[c])) return fail(TRPL_ERR_ARG, "column %d: lo must be <= hi", c);
+        if (do_log[c] && lo[c] != hi[c] && !(lo[c] > 0)) return fail(TRPL_ERR_ARG, "column %d: log-uniform needs lo > 0", c);
+    }
+    return TRPL_OK;
+}
+
+int trpl_sample_box_dev(uint32_t seed, int64_t S, int32_t ncol, const double *lo, const double *hi, const int32_t *do_log,
+                        uint32_t flags, double *X, void *stream)
+{
+    if (int rc = check_box(S, ncol, lo, hi, do_log)) return rc;
+    if (S == 0) return TRPL_OK;
+    if (!X) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    hipError_t e = trpl::launch_sample_box(seed, S, ncol, lo, hi, do_log, flags, X, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(TRPL_ERR_HIP, "sampler launch: %s", hipGetErrorString(e));
+    return TRPL_OK;
+}
+
+int trpl_sample_box(uint32_t seed, int64_t S, int32_t ncol, const double *lo, const double *hi, const int32_t *do_log,
+                    uint32_t flags, double *X, int32_t device, double *seconds)
+{
+    if (seconds) *seconds = 0.0;
+    if (int rc = check_box(S, ncol, lo, hi, do_log)) return rc;
+    if (S == 0) return TRPL_OK;
+    if (!X) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (int rc = select_device(device)) return rc;
+    DevBuf dX;
+    HIP_TRY(dX.alloc((size_t)S * ncol * 8));
+    const double t0 = now_s();
+    if (int rc = trpl_sample_box_dev(seed, S, ncol, lo, hi, do_log, flags, dX.as<double>(), nullptr)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (seconds) *seconds = now_s() - t0;
+    HIP_TRY(hipMemcpy(X, dX.p, (size_t)S * ncol * 8, hipMemcpyDeviceToHost));
+    return TRPL_OK;
+}
+
 /* ------------------------------------------------------------------ batched PCR --------- */
 int trpl_pcr_solve_batched_dev(const void *ld, const void *d, const void *ud, const void *b, void *x, int64_t S,
                                int32_t L, int32_t elem_bytes, uint32_t flags, void *stream)

@@ -66,6 +66,10 @@ hipError_t launch_posterior_moments(const double *V, const double *W, int64_t S,
 hipError_t launch_posterior_hist(const double *x, const double *y, const double *W, int64_t S, double xlo, double xhi,
                                  int xb, double ylo, double yhi, int yb, double *out, hipStream_t st);
 
+// sampler.hip: bayeslib.random_grid on the device (lo / hi / do_log are host arrays)
+hipError_t launch_sample_box(uint32_t seed, int64_t S, int ncol, const double *lo, const double *hi, const int32_t *do_log,
+                             uint32_t flags, double *X, hipStream_t st);
+
 // batched tridiagonal solve (pcr_batched_impl.hpp, instantiated in both arithmetic modes)
 hipError_t launch_pcr_batched_strict(const void *ld, const void *d, const void *ud, const void *b, void *x,
                                      int64_t S, int L, int elem_bytes, hipStream_t stream);

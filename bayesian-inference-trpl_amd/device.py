@@ -142,3 +142,15 @@ def credible_interval_device(x, W, lo=0.025, hi=0.975):
     below = torch.nonzero(cs < lo)
     above = torch.nonzero(cs > hi)
     return float(xs[below[-1, 0]]), float(xs[above[0, 0]])
+
+
+def sample_box_device(X, minX, maxX, do_log, seed=42, flags=0):
+    """Fill X (S, ncol) f64 in HBM with bayeslib.random_grid's draws (trpl_sample_box_dev)."""
+    import torch
+    lo = np.ascontiguousarray(minX, dtype=np.float64)
+    hi = np.ascontiguousarray(maxX, dtype=np.float64)
+    lg = np.ascontiguousarray(do_log, dtype=np.int32)
+    if X.dim() != 2 or X.shape[1] != lo.size or not (lo.shape == hi.shape == lg.shape):
+        raise ValueError("X must be (S, ncol) with ncol = len(minX) = len(maxX) = len(do_log)")
+    _abi.check(_abi.lib().trpl_sample_box_dev(int(seed) & 0xFFFFFFFF, X.shape[0], lo.size, _abi.ptr(lo), _abi.ptr(hi),
+                                              _abi.ptr(lg), int(flags), _chk(X, torch.float64, "X"), _stream()))

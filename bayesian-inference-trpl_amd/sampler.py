@@ -52,3 +52,27 @@ def default_box(seed=42, num_points=4):
     rng = np.random.RandomState(seed)
     return random_grid(DEFAULT_MINX * UNIT_CONVERSIONS, DEFAULT_MAXX * UNIT_CONVERSIONS, DEFAULT_DO_LOG,
                        num_points, rng=rng)
+
+
+def random_grid_device(minX, maxX, do_log, num_points, seed=42, sim_flags=None, device=0):
+    """random_grid (+ make_grid's overrides when sim_flags is given) drawn ON THE GPU by
+    trpl_sample_box: the reference's MT19937 stream after numpy.random.seed(seed).  Linear columns are
+    bit-identical to random_grid's, log-uniform columns agree to the last ulp or two of pow().  Returns
+    the (num_points, len(minX)) array (host copy; trpl_amd.device.sample_box_device keeps it in HBM)."""
+    from . import _abi
+    lo = np.ascontiguousarray(minX, dtype=np.float64)
+    hi = np.ascontiguousarray(maxX, dtype=np.float64)
+    lg = np.ascontiguousarray(do_log, dtype=np.int32)
+    if not (lo.shape == hi.shape == lg.shape and lo.ndim == 1):
+        raise ValueError("minX, maxX and do_log must be one-dimensional and of equal length")
+    X = np.empty((int(num_points), lo.size))
+    _abi.check(_abi.lib().trpl_sample_box(int(seed) & 0xFFFFFFFF, int(num_points), lo.size, _abi.ptr(lo), _abi.ptr(hi),
+                                          _abi.ptr(lg), box_flags(sim_flags), _abi.ptr(X), int(device), None))
+    return X
+
+
+def box_flags(sim_flags):
+    """TRPL_BOX_* bits of make_grid's three overrides (bayeslib.py:36-38)."""
+    f = sim_flags or {}
+    return (1 if f.get("override_equal_mu") else 0) | (2 if f.get("override_equal_s") else 0) \
+        | (4 if f.get("override_equal_auger") else 0)

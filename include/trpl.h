@@ -190,6 +190,25 @@ int trpl_loglik_multi(const double *X, int64_t S, int32_t C, const double *lengt
 int trpl_shard_bounds(int64_t S, int32_t n_shards, int32_t shard, int64_t *lo, int64_t *hi);
 
 /* ---------------------------------------------------------------------------------------
+ * trpl_sample_box -- replaces bayeslib.random_grid(minX, maxX, do_log, num_points) after
+ * numpy.random.seed(seed) (bayeslib.py:18-32, parallel_bayes_gpu.py:35) and the make_grid overrides
+ * (bayeslib.py:67-75), generating X[S][ncol] in device memory: the same MT19937 stream, the same draw
+ * order (column after column, fixed columns draw nothing), the same 53-bit doubles.  Linear columns are
+ * bit-identical to the reference's; log-uniform columns go through the device's pow() (<= 1 ulp from
+ * the host's).  lo / hi / do_log are HOST arrays [ncol] (bounds already unit-converted, as the reference
+ * passes them).  flags: 1 = equal mobilities (X[:,2] = X[:,3]), 2 = equal surface velocities
+ * (X[:,6] = X[:,5]), 4 = equal Auger coefficients (X[:,8] = X[:,7]).
+ * ------------------------------------------------------------------------------------- */
+#define TRPL_BOX_EQUAL_MU 0x1
+#define TRPL_BOX_EQUAL_S 0x2
+#define TRPL_BOX_EQUAL_AUGER 0x4
+int trpl_sample_box(uint32_t seed, int64_t S, int32_t ncol, const double *lo, const double *hi,
+                    const int32_t *do_log, uint32_t flags, double *X, int32_t device, double *seconds);
+int trpl_sample_box_dev(uint32_t seed, int64_t S, int32_t ncol, const double *lo /*host*/,
+                        const double *hi /*host*/, const int32_t *do_log /*host*/, uint32_t flags,
+                        double *X /*device*/, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Posterior core -- the consumer of the likelihood vector: replaces the numpy reductions
  * of Visualization/utils.py on *_BAYRAN_{P,X}.npy.  Streaming, HBM-bound (8 B of likelihood + 8 B per
  * parameter column per sample); results are small arrays a multi-GPU caller can all-reduce.

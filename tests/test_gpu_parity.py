@@ -668,3 +668,35 @@ def test_posterior_core_at_scale_and_edges(trpl, gpu, oracle):
     with pytest.raises(trpl.TrplError):
         po.hist(x, w, 1.0, 1.0, bins)
     assert po.weights(np.zeros(0)).shape == (0,)
+
+
+# ---- device sampler (csrc/sampler.hip) against the reference's own draws ----
+def test_device_sampler_draws_the_reference_stream(trpl, gpu, golden):
+    """trpl_sample_box vs the reference's random_grid after numpy.random.seed(42) (sampler.npz holds its
+    output): fixed and linear columns bit-identical, log-uniform columns to 2 ulp (device pow vs host pow);
+    sizes that end inside / exactly on a 624-word block; the make_grid overrides."""
+    sm = trpl.sampler
+    lo, hi, lg = sm.DEFAULT_MINX * sm.UNIT_CONVERSIONS, sm.DEFAULT_MAXX * sm.UNIT_CONVERSIONS, sm.DEFAULT_DO_LOG
+    g = golden("sampler")
+    lin = np.array([not l for l in lg])
+    for key in ("X4", "X64"):
+        want = g[key]
+        got = sm.random_grid_device(g["minX"] * g["unit"], g["maxX"] * g["unit"], g["do_log"], len(want), seed=42)
+        assert np.array_equal(got[:, lin], want[:, lin]), key
+        assert np.allclose(got[:, ~lin], want[:, ~lin], rtol=5e-16, atol=0), key
+    for S in (1, 311, 312, 313, 624, 5000):                     # 312 doubles per regenerated block
+        want = sm.default_box(42, S)
+        got = sm.random_grid_device(lo, hi, lg, S, seed=42)
+        assert np.array_equal(got[:, lin], want[:, lin]) and np.allclose(got, want, rtol=5e-16, atol=0), S
+    want = sm.default_box(7, 1000)
+    flags = {"override_equal_mu": True, "override_equal_s": True, "override_equal_auger": True}
+    got = sm.random_grid_device(lo, hi, lg, 1000, seed=7, sim_flags=flags)
+    assert np.array_equal(got[:, 2], want[:, 3]) and np.array_equal(got[:, 3], want[:, 3])
+    assert np.allclose(got[:, 6], want[:, 5], rtol=5e-16) and np.allclose(got[:, 8], want[:, 7], rtol=5e-16)
+    # the samples it produces drive the solver like the host-drawn ones
+    import torch
+    X = torch.empty((4096, 13), dtype=torch.float64, device="cuda")
+    trpl.device.sample_box_device(X, lo, hi, lg, seed=42)
+    assert np.allclose(X.cpu().numpy(), sm.default_box(42, 4096), rtol=5e-16, atol=0)
+    with pytest.raises(trpl.TrplError):
+        sm.random_grid_device(hi, lo, lg, 4)
