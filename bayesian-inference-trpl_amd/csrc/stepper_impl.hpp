@@ -249,12 +249,13 @@ struct PlSink {
 // the 12 non-dimensional material parameters of one system (wave-uniform) + N0*P0
 struct MatPar {
     double N0, P0, DN, DP, rate, sr0, srL, CN, CP, tauN, tauP, Lambda, n0p0;
+    double mfirst = 0.0, mlast = 0.0;   // SURF_FMA only: 1.0 on the lane that owns node 0 / node L-1, else 0.0
 };
 
 // Assemble the electron (IS_N) or hole tridiagonal system of one Newton/Picard iteration:
 // pvSimPCR.py:148-170 (electrons) / :178-198 (holes).  lo = A2 (sub-diagonal), dg = A1,
 // up = A0 (super-diagonal), bb = right-hand side.  Ep[j] = E at node i+1.
-template <int LAY, bool IS_N, int NR, int W, int L>
+template <int LAY, bool IS_N, int NR, int W, int L, bool SURF_FMA = false>
 __device__ __forceinline__ void assemble(const MatPar &m, double a0, const double (&Nk)[NR], const double (&Pk)[NR],
                                          const double (&Ek)[NR], const double (&Ep)[NR], const double (&bU)[NR],
                                          double (&lo)[NR], double (&dg)[NR], double (&up)[NR], double (&bb)[NR],
@@ -327,8 +328,17 @@ __device__ __forceinline__ void assemble(const MatPar &m, double a0, const doubl
         const double inv = LAY == 2 ? rcp_nr1(Ns + Ps) : rcp_nr(Ns + Ps);
         const double dss = -sr * (Vs * Vs + m.n0p0) * (inv * inv);
         const double fs = sr * (Ns * Ps - m.n0p0) * inv + dss * Us;
-        if (ln == 0) { dg[0] -= dss; bb[0] -= fs; }
-        if (ln == W - 1) { dg[NR - 1] -= dss; bb[NR - 1] -= fs; }
+        if constexpr (SURF_FMA) {
+            // branch-free: the two lane-conditional updates as four fmas with 0/1 lane masks, so that the
+            // iteration body stays one basic block (the paired kernel: every wave holds surface lanes)
+            dg[0] = __builtin_fma(-m.mfirst, dss, dg[0]);
+            bb[0] = __builtin_fma(-m.mfirst, fs, bb[0]);
+            dg[NR - 1] = __builtin_fma(-m.mlast, dss, dg[NR - 1]);
+            bb[NR - 1] = __builtin_fma(-m.mlast, fs, bb[NR - 1]);
+        } else {
+            if (ln == 0) { dg[0] -= dss; bb[0] -= fs; }
+            if (ln == W - 1) { dg[NR - 1] -= dss; bb[NR - 1] -= fs; }
+        }
     }
 }
 

@@ -117,7 +117,8 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
                  tauN = xs[9] * cc.scales[9], tauP = xs[10] * cc.scales[10],
                  Lambda = xs[11] * cc.scales[11];
     const double n0p0 = N0 * P0;
-    const MatPar mp = {N0, P0, DN, DP, rate, sr0, srL, CN, CP, tauN, tauP, Lambda, n0p0};
+    const MatPar mp = {N0, P0, DN, DP, rate, sr0, srL, CN, CP, tauN, tauP, Lambda, n0p0,
+                       ln == 0 ? 1.0 : 0.0, ln == WS - 1 ? 1.0 : 0.0};
     const double mag = a.xld > 12 ? xs[12] : 0.0;
     const double TOL = a.TOL;
     const int MAX = a.MAX;
@@ -198,13 +199,13 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
             nbrB_up<double, NR, 1>(Ek, Ep, lane);   // a system's last lane reads the partner's E_0 = 0: E_L = 0
             bool okNA, okNB, okPA, okPB;
             // ---- electrons (:148-175) ----
-            assemble<LAY, true, NR, WS, L>(mp, a0, Nk, Pk, Ek, Ep, bN, lo_, dg, up, bb, ln);
+            assemble<LAY, true, NR, WS, L, true>(mp, a0, Nk, Pk, Ek, Ep, bN, lo_, dg, up, bb, ln);
             residual_below2<ISO>(lo_, dg, up, bb, Nk, TOL, lane, okNA, okNB);                      // :172
             cr_pcr_solve<double, NR, WS, ISO, XM>(lo_, dg, up, bb, x, lane, xch);                       // :175
 #pragma unroll
             for (int j = 0; j < NR; j++) Nk[j] = act ? x[j] : Nk[j];
             // ---- holes, with the updated electrons (:178-202) ----
-            assemble<LAY, false, NR, WS, L>(mp, a0, Nk, Pk, Ek, Ep, bP, lo_, dg, up, bb, ln);
+            assemble<LAY, false, NR, WS, L, true>(mp, a0, Nk, Pk, Ek, Ep, bP, lo_, dg, up, bb, ln);
             residual_below2<ISO>(lo_, dg, up, bb, Pk, TOL, lane, okPA, okPB);                      // :200
             cr_pcr_solve<double, NR, WS, ISO, XM>(lo_, dg, up, bb, x, lane, xch);                       // :202
 #pragma unroll
