@@ -62,14 +62,17 @@ __global__ void __launch_bounds__(kThreads) nanmax_partial(const double *LL, int
     m = block_reduce<true>(m, sm);
     if (threadIdx.x == 0) part[blockIdx.x] = m;
 }
-__global__ void __launch_bounds__(kThreads) final_reduce(double *part, int nb, int ncol, bool is_max, double *out)
+// part is [gridDim.y][nb][ncol]; block (c, y) reduces column c of slab y over the nb block partials:
+// thread t takes b = t, t + 256, ... in order, then the fixed block tree -- deterministic
+__global__ void __launch_bounds__(kThreads) final_reduce(const double *part, int nb, int ncol, bool is_max, double *out)
 {
-    // part is [nb][ncol]; column c is reduced by thread c in block order (deterministic)
-    const int c = threadIdx.x;
-    if (c >= ncol) return;
+    __shared__ double sm[kThreads / 64];
+    const int c = blockIdx.x;
+    const double *p = part + (int64_t)blockIdx.y * nb * ncol;
     double r = is_max ? -INFINITY : 0.0;
-    for (int b = 0; b < nb; b++) r = is_max ? fmax(r, part[(int64_t)b * ncol + c]) : r + part[(int64_t)b * ncol + c];
-    out[c] = r;
+    for (int b = threadIdx.x; b < nb; b += kThreads) r = is_max ? fmax(r, p[(int64_t)b * ncol + c]) : r + p[(int64_t)b * ncol + c];
+    r = is_max ? block_reduce<true>(r, sm) : block_reduce<false>(r, sm);
+    if (threadIdx.x == 0) out[(int64_t)blockIdx.y * ncol + c] = r;
 }
 __global__ void __launch_bounds__(kThreads) weights_partial(const double *LL, int64_t S, double tf, const double *mx,
                                                             double c_up, double c_size, double *W, double *part)
@@ -121,57 +124,81 @@ __global__ void __launch_bounds__(kThreads) moments1_partial(const double *V, co
         }
     }
 }
-// ---- moments pass 2, one parameter d per blockIdx.y: sum w (v_d - m_d)(v_e - m_e) for all e, and the
-//      third and fourth central sums of v_d; sums[0] = sum w, sums[2 + d] = sum w v_d from pass 1 ----
+// ---- moments pass 2, a tile of kTile parameters d per blockIdx.y (the columns are read once per tile):
+//      sum w (v_d - m_d)(v_e - m_e) for all e, and the third and fourth central sums of v_d;
+//      sums[0] = sum w, sums[2 + d] = sum w v_d from pass 1 ----
+constexpr int kTile = 4;
 __global__ void __launch_bounds__(kThreads) moments2_partial(const double *V, const double *W, int64_t S, int D,
                                                              const double *sums, const double *mean_in, double *part)
 {
     __shared__ double sm[kThreads / 64];
-    const int d = blockIdx.y;
+    const int d0 = blockIdx.y * kTile;
     const double sw = sums[0];
     double mean[kMaxDim];
 #pragma unroll
     for (int e = 0; e < kMaxDim; e++) mean[e] = e < D ? (mean_in ? mean_in[e] : sums[2 + e] / sw) : 0.0;      // np.average
-    double md = 0.0;
+    double c[kTile][kMaxDim], m3[kTile], m4[kTile];
 #pragma unroll
-    for (int e = 0; e < kMaxDim; e++) md = e == d ? mean[e] : md;
-    double c[kMaxDim], m3 = 0.0, m4 = 0.0;
+    for (int t = 0; t < kTile; t++) {
+        m3[t] = 0.0; m4[t] = 0.0;
 #pragma unroll
-    for (int e = 0; e < kMaxDim; e++) c[e] = 0.0;
+        for (int e = 0; e < kMaxDim; e++) c[t][e] = 0.0;
+    }
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < S; i += (int64_t)gridDim.x * kThreads) {
         const double w = W[i];
-        const double xd = V[(int64_t)d * S + i] - md;
+        double xc[kMaxDim];
 #pragma unroll
-        for (int e = 0; e < kMaxDim; e++)
-            if (e < D) c[e] += (xd * (V[(int64_t)e * S + i] - mean[e])) * w;
-        const double x2 = xd * xd;
-        m3 += (x2 * xd) * w;
-        m4 += (x2 * x2) * w;
-    }
-    double *row = part + ((int64_t)d * gridDim.x + blockIdx.x) * (D + 2);
+        for (int e = 0; e < kMaxDim; e++) xc[e] = e < D ? V[(int64_t)e * S + i] - mean[e] : 0.0;
 #pragma unroll
-    for (int e = 0; e < kMaxDim; e++) {
-        if (e < D) {
-            const double r = block_reduce<false>(c[e], sm);
-            if (threadIdx.x == 0) row[e] = r;
+        for (int t = 0; t < kTile; t++) {
+            double xd = 0.0;
+#pragma unroll
+            for (int e = 0; e < kMaxDim; e++) xd = e == d0 + t ? xc[e] : xd;
+#pragma unroll
+            for (int e = 0; e < kMaxDim; e++)
+                if (e < D) c[t][e] += (xd * xc[e]) * w;
+            const double x2 = xd * xd;
+            m3[t] += (x2 * xd) * w;
+            m4[t] += (x2 * x2) * w;
         }
     }
-    double r = block_reduce<false>(m3, sm);
-    if (threadIdx.x == 0) row[D] = r;
-    r = block_reduce<false>(m4, sm);
-    if (threadIdx.x == 0) row[D + 1] = r;
+#pragma unroll
+    for (int t = 0; t < kTile; t++) {
+        const int d = d0 + t;
+        if (d >= D) break;                                       // wave-uniform
+        double *row = part + ((int64_t)d * gridDim.x + blockIdx.x) * (D + 2);
+#pragma unroll
+        for (int e = 0; e < kMaxDim; e++) {
+            if (e < D) {
+                const double r = block_reduce<false>(c[t][e], sm);
+                if (threadIdx.x == 0) row[e] = r;
+            }
+        }
+        double r = block_reduce<false>(m3[t], sm);
+        if (threadIdx.x == 0) row[D] = r;
+        r = block_reduce<false>(m4[t], sm);
+        if (threadIdx.x == 0) row[D + 1] = r;
+    }
 }
 
 // ---- histograms ----
 __device__ __forceinline__ double edge(double lo, double hi, int k, int bins) { return lo + ((hi - lo) * k) / bins; }
-// numpy's bin of x against edges e_0..e_bins (e_k as the reference builds them, utils.py:243-244): -1 = dropped
-__device__ __forceinline__ int bin_of(double x, double lo, double hi, int bins)
+// numpy's bin of x against edges e_0..e_bins (e_k as the reference builds them, utils.py:243-244): -1 = dropped.
+// tab (LDS, bins + 1 entries) holds those edges when the axis is small enough, `scale` = bins / (hi - lo):
+// a multiply finds the candidate bin, comparisons against the exact edges settle it.
+constexpr int kMaxAxisTab = 1024;
+__device__ __forceinline__ int bin_of(double x, double lo, double hi, int bins, double scale, const double *tab)
 {
     if (!(x >= lo && x <= hi)) return -1;                       // also drops NaN
-    int k = (int)(((x - lo) / (hi - lo)) * bins);
+    int k = (int)((x - lo) * scale);
     k = k < 0 ? 0 : (k > bins - 1 ? bins - 1 : k);
-    while (k > 0 && x < edge(lo, hi, k, bins)) k--;
-    while (k < bins - 1 && x >= edge(lo, hi, k + 1, bins)) k++;
+    if (tab) {
+        while (k > 0 && x < tab[k]) k--;
+        while (k < bins - 1 && x >= tab[k + 1]) k++;
+    } else {
+        while (k > 0 && x < edge(lo, hi, k, bins)) k--;
+        while (k < bins - 1 && x >= edge(lo, hi, k + 1, bins)) k++;
+    }
     return k;
 }
 __global__ void __launch_bounds__(kThreads) hist_kernel(const double *x, const double *y, const double *W, int64_t S,
@@ -179,27 +206,40 @@ __global__ void __launch_bounds__(kThreads) hist_kernel(const double *x, const d
                                                         double *out)
 {
     __shared__ double bins[kLdsBins];
+    __shared__ double xtab[kMaxAxisTab + 1], ytab[kMaxAxisTab + 1];
+    const double *xt = xb <= kMaxAxisTab ? xtab : nullptr, *yt = (y && yb <= kMaxAxisTab) ? ytab : nullptr;
+    if (xt) for (int k = threadIdx.x; k <= xb; k += kThreads) xtab[k] = edge(xlo, xhi, k, xb);
+    if (yt) for (int k = threadIdx.x; k <= yb; k += kThreads) ytab[k] = edge(ylo, yhi, k, yb);
+    const double xs = xb / (xhi - xlo), ys = y ? yb / (yhi - ylo) : 0.0;
+    __syncthreads();
     const int nb = y ? xb * yb : xb;
     const bool use_lds = nb <= kLdsBins;
+    // few bins mean many lanes adding to the same LDS word: keep up to 16 replicas, one per lane group
+    int rep = 1;
+    while (rep < 16 && 2 * rep * nb <= kLdsBins) rep *= 2;
+    const int my = (threadIdx.x & (rep - 1)) * nb;
     if (use_lds) {
-        for (int k = threadIdx.x; k < nb; k += kThreads) bins[k] = 0.0;
+        for (int k = threadIdx.x; k < rep * nb; k += kThreads) bins[k] = 0.0;
         __syncthreads();
     }
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < S; i += (int64_t)gridDim.x * kThreads) {
-        int k = bin_of(x[i], xlo, xhi, xb);
+        int k = bin_of(x[i], xlo, xhi, xb, xs, xt);
         if (k >= 0 && y) {
-            const int ky = bin_of(y[i], ylo, yhi, yb);
+            const int ky = bin_of(y[i], ylo, yhi, yb, ys, yt);
             k = ky < 0 ? -1 : k * yb + ky;                      // [x bin][y bin], like np.histogram2d
         }
         if (k < 0) continue;
         const double w = W ? W[i] : 1.0;
-        if (use_lds) atomicAdd(&bins[k], w);
+        if (use_lds) atomicAdd(&bins[my + k], w);
         else atomicAdd(&out[k], w);
     }
     if (use_lds) {
         __syncthreads();
-        for (int k = threadIdx.x; k < nb; k += kThreads)
-            if (bins[k] != 0.0) atomicAdd(&out[k], bins[k]);
+        for (int k = threadIdx.x; k < nb; k += kThreads) {
+            double t = 0.0;
+            for (int r = 0; r < rep; r++) t += bins[r * nb + k];
+            if (t != 0.0) atomicAdd(&out[k], t);
+        }
     }
 }
 
@@ -227,9 +267,9 @@ hipError_t launch_posterior_weights(const double *LL, int64_t S, double tf, doub
     double *part = ws, *mx = ws + kMaxBlocks, *sum = mx + 1;
     const double c_up = 1000.0 * log(2.0), c_size = log((double)S);                   // utils.py:164
     hipLaunchKernelGGL(nanmax_partial, dim3(nb), dim3(kThreads), 0, st, LL, S, tf, part);
-    hipLaunchKernelGGL(final_reduce, dim3(1), dim3(kThreads), 0, st, part, nb, 1, true, mx);
+    hipLaunchKernelGGL(final_reduce, dim3(1, 1), dim3(kThreads), 0, st, part, nb, 1, true, mx);
     hipLaunchKernelGGL(weights_partial, dim3(nb), dim3(kThreads), 0, st, LL, S, tf, mx, c_up, c_size, W, part);
-    hipLaunchKernelGGL(final_reduce, dim3(1), dim3(kThreads), 0, st, part, nb, 1, false, sum);
+    hipLaunchKernelGGL(final_reduce, dim3(1, 1), dim3(kThreads), 0, st, part, nb, 1, false, sum);
     hipLaunchKernelGGL(scale_kernel, dim3(nb), dim3(kThreads), 0, st, W, S, sum);
     if (stats) hipLaunchKernelGGL(copy2_kernel, dim3(1), dim3(1), 0, st, mx, sum, stats);
     return hipGetLastError();
@@ -247,11 +287,9 @@ hipError_t launch_posterior_moments(const double *V, const double *W, int64_t S,
     if (S <= 0) return hipSuccess;
     const int nb = grid_for(S);
     hipLaunchKernelGGL(moments1_partial, dim3(nb), dim3(kThreads), 0, st, V, W, S, D, ws);
-    hipLaunchKernelGGL(final_reduce, dim3(1), dim3(kThreads), 0, st, ws, nb, 2 + D, false, sums);
-    hipLaunchKernelGGL(moments2_partial, dim3(nb, D), dim3(kThreads), 0, st, V, W, S, D, sums, mean_in, ws);
-    for (int d = 0; d < D; d++)
-        hipLaunchKernelGGL(final_reduce, dim3(1), dim3(kThreads), 0, st, ws + (int64_t)d * nb * (D + 2), nb, D + 2, false,
-                           central + (int64_t)d * (D + 2));
+    hipLaunchKernelGGL(final_reduce, dim3(2 + D, 1), dim3(kThreads), 0, st, ws, nb, 2 + D, false, sums);
+    hipLaunchKernelGGL(moments2_partial, dim3(nb, (D + kTile - 1) / kTile), dim3(kThreads), 0, st, V, W, S, D, sums, mean_in, ws);
+    hipLaunchKernelGGL(final_reduce, dim3(D + 2, D), dim3(kThreads), 0, st, ws, nb, D + 2, false, central);
     return hipGetLastError();
 }
 
@@ -262,7 +300,7 @@ hipError_t launch_posterior_hist(const double *x, const double *y, const double 
     using namespace post;
     if (S <= 0) return hipSuccess;
     int nb = grid_for(S);
-    if (nb > 256) nb = 256;                 // fewer, longer blocks: fewer flushes of the LDS bins
+    if (nb > 768) nb = 768;                 // 3 blocks per CU (48 KB of LDS each): enough loads in flight, few bin flushes
     hipLaunchKernelGGL(hist_kernel, dim3(nb), dim3(kThreads), 0, st, x, y, W, S, xlo, xhi, xb, ylo, yhi, yb, out);
     return hipGetLastError();
 }
