@@ -505,6 +505,11 @@ def test_multi_device_entry_point_equals_single_device(trpl, gpu):
     assert np.array_equal(got, trpl.loglik(X[:2], ini, lengths, Time, 128, T, obs0))
     with pytest.raises(trpl.TrplError):
         trpl.loglik(X, ini, lengths, Time, 128, T, obs0, devices=[0, 99])
+    # shards large enough for the two-systems-per-wavefront kernel: other partners, same bits
+    Xb = trpl.workloads.samples(5001, seed=6)
+    obs2 = [np.full(41, 20.0)] * 3
+    one = trpl.loglik(Xb, ini, lengths, 1.0, 128, 40, obs2)
+    assert np.array_equal(trpl.loglik(Xb, ini, lengths, 1.0, 128, 40, obs2, devices=[0, 0]), one)
 
 
 # ---- two systems per wavefront (stepper_pair_impl.hpp): the kernel of every launch that fills the chip ----
