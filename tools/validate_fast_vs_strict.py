@@ -1,5 +1,5 @@
 """Offline validation at benchmark scale: FAST vs STRICT (bit-identical-to-reference arithmetic) likelihoods and
-iteration counts over the whole sampled parameter box.  python tools/validate_fast_vs_strict.py [S] [T]"""
+iteration counts over the whole sampled parameter box.  python tools/validate_fast_vs_strict.py [S] [T] [power_scan|twothick]"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np, torch, trpl_amd
@@ -7,7 +7,7 @@ from trpl_amd import device as tdev, workloads as wl
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 dev = torch.device("cuda", 0); L = 128; Time = T * 0.025
-ini, lens = wl.power_scan(L); C = 3
+ini, lens = (wl.twothick(L) if len(sys.argv) > 3 and sys.argv[3] == "twothick" else wl.power_scan(L)); C = len(lens)
 X = torch.from_numpy(wl.samples(S)).to(dev); ini_d = torch.from_numpy(ini).to(dev)
 mark = torch.from_numpy((wl.MARKED_POINT * trpl_amd.UNIT_CONVERSIONS)[None, :-1].copy()).to(dev)
 obs = torch.empty((C, T + 1), dtype=torch.float64, device=dev)
