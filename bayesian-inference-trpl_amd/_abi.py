@@ -51,7 +51,7 @@ SIGNATURES = {
     "trpl_loglik_multi": [_vp, _i64, _i32, _vp, _f64, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64,
                           _vp, _vp, _vp, _vp, _vp, _u32, _vp, _i32, _pd],
     "trpl_shard_bounds": [_i64, _i32, _i32, _vp, _vp],
-    "trpl_kernel_variant": [_i64, _i32, _u32],
+    "trpl_kernel_variant": [_i64, _i32, _i64, _u32],
     "trpl_sample_box": [_u32, _i64, _i32, _vp, _vp, _vp, _u32, _vp, _i32, _pd],
     "trpl_sample_box_dev": [_u32, _i64, _i32, _vp, _vp, _vp, _u32, _vp, _vp],
     "trpl_posterior_workspace_bytes": [_i32],

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <vector>
 
@@ -59,12 +60,15 @@ int check_grid(int32_t L, int64_t T, int32_t plT, int32_t max_iter, double time_
 }
 
 // FAST, L = 128 has two kernels: one system per wavefront (3 waves per SIMD: 12 systems per CU in
-// flight) and two systems per wavefront (2 waves per SIMD: 16 systems per CU, +21 % throughput once
-// the chip is full, but 10 % slower per wave).  A launch that does not even fill the first takes
-// the one-system kernel; anything larger the paired one.  TRPL_PAIR=0 / 1 forces never / always
-// (measurements; a system's result does not depend on its partner, but the two kernels associate
-// their node sums differently, ~1e-16 relative).
-bool use_pair_kernel(int64_t nsys)
+// flight) and two systems per wavefront (2 waves per SIMD: 16 systems per CU, +25..37 % throughput once
+// the chip is kept full, but ~10 % slower per wave).  A launch's duration is set by its slowest chain of
+// systems, so the paired kernel only pays when the chip stays full for most of the launch: more systems
+// than the one-system kernel holds at once, and -- for short windows, where the first time steps' 20-900
+// inner iterations make the work per system very uneven -- at least five such fills.  Measured crossover
+// (MI355X, Power_scan): `steps` = 8000: paired wins from 4 098 systems (+9 %); 1000: from ~15 000.
+// TRPL_PAIR=0 / 1 forces never / always (measurements; a system's result does not depend on its
+// partner, but the two kernels associate their node sums differently, ~1e-16 relative).
+bool use_pair_kernel(int64_t nsys, int64_t steps)
 {
     static const int forced = getenv("TRPL_PAIR") ? atoi(getenv("TRPL_PAIR")) : -1;
     if (forced >= 0) return forced != 0;
@@ -78,10 +82,12 @@ bool use_pair_kernel(int64_t nsys)
         }
         cus = cached_cus;
     }
-    return nsys > (int64_t)cus * 12;
+    const int64_t fill = (int64_t)cus * 12;
+    return nsys > fill && (steps >= 4000 || nsys >= 5 * fill);
 }
 
-int launch(const trpl::StepArgs &a, uint32_t flags, hipStream_t st)
+// steps: how many time steps the launch will take (T, or up to the last observation in likelihood mode)
+int launch(const trpl::StepArgs &a, uint32_t flags, hipStream_t st, int64_t steps)
 {
     if (flags & TRPL_FLAG_FP32) {
         if (flags & TRPL_FLAG_STRICT) return fail(TRPL_ERR_ARG, "TRPL_FLAG_FP32 and TRPL_FLAG_STRICT exclude each other");
@@ -90,7 +96,7 @@ int launch(const trpl::StepArgs &a, uint32_t flags, hipStream_t st)
         if (e32 != hipSuccess) return fail(TRPL_ERR_HIP, "fp32 stepper launch: %s", hipGetErrorString(e32));
         return TRPL_OK;
     }
-    if (!(flags & TRPL_FLAG_STRICT) && a.L == 128 && use_pair_kernel(a.S * a.C)) {
+    if (!(flags & TRPL_FLAG_STRICT) && a.L == 128 && use_pair_kernel(a.S * a.C, steps)) {
         hipError_t ep = trpl::launch_stepper_pair(a, st);
         if (ep != hipSuccess) return fail(TRPL_ERR_HIP, "pair stepper launch: %s", hipGetErrorString(ep));
         return TRPL_OK;
@@ -128,11 +134,11 @@ extern "C" {
 int trpl_abi_version(void) { return TRPL_ABI_VERSION; }
 const char *trpl_last_error(void) { return g_err; }
 
-int trpl_kernel_variant(int64_t nsys, int32_t L, uint32_t flags)
+int trpl_kernel_variant(int64_t nsys, int32_t L, int64_t steps, uint32_t flags)
 {
     if (flags & TRPL_FLAG_FP32) return TRPL_KERNEL_FP32;
     if (flags & TRPL_FLAG_STRICT) return TRPL_KERNEL_STRICT;
-    return (L == 128 && use_pair_kernel(nsys)) ? TRPL_KERNEL_FAST_PAIR : TRPL_KERNEL_FAST;
+    return (L == 128 && use_pair_kernel(nsys, steps)) ? TRPL_KERNEL_FAST_PAIR : TRPL_KERNEL_FAST;
 }
 
 int trpl_device_count(void)
@@ -163,7 +169,7 @@ int trpl_solve_pl_dev(const double *matpar, int64_t S, double length_nm, double 
     a.S = S; a.C = 1; a.L = L; a.T = T; a.plT = plT; a.MAX = max_iter; a.flags = flags;
     a.TOL = pow(10.0, -(double)tol_exp);                        /* pvSimPCR.py:112 */
     curve_const(length_nm, time_ns, L, T, a.curve[0]);
-    return launch(a, flags, (hipStream_t)stream);
+    return launch(a, flags, (hipStream_t)stream, T);
 }
 
 int trpl_solve_pl(const double *matpar, int64_t S, double length_nm, double time_ns, int32_t L, int64_t T,
@@ -313,7 +319,12 @@ static int loglik_dev_impl(const double *X, int64_t S, int32_t C, const double *
         curve_const(lengths_nm[c], time_ns, L, T, a.curve[c]);
         a.curve[c].n_obs = n_obs[c];
     }
-    if (int rc = launch(a, flags, (hipStream_t)stream)) return rc;
+    int64_t steps = T;                              // the kernel stops at the last observation (PlSink::t_last)
+    if (!interp) {
+        steps = 0;
+        for (int c = 0; c < C; c++) steps = std::max<int64_t>(steps, (n_obs[c] - 1) * (int64_t)plT);
+    }
+    if (int rc = launch(a, flags, (hipStream_t)stream, steps)) return rc;
     hipError_t e = trpl::launch_reduce_curves(P, sse, S, C, (hipStream_t)stream);
     if (e != hipSuccess) return fail(TRPL_ERR_HIP, "reduce_curves launch: %s", hipGetErrorString(e));
     return TRPL_OK;

@@ -181,7 +181,7 @@ def main():
 
     # which time-stepper this launch ran (the library picks the two-systems-per-wavefront kernel for
     # fp64 L = 128 launches that fill the chip)
-    variant = trpl_amd._abi.lib().trpl_kernel_variant(int(args.samples_per_gpu) * C, L, flags)
+    variant = trpl_amd._abi.lib().trpl_kernel_variant(int(args.samples_per_gpu) * C, L, T, flags)
     if variant == trpl_amd._abi.KERNEL_FAST_PAIR:
         kernel_name = "pair::stepper_pair_kernel (2 x L=128 systems per wavefront; fused time-stepper + likelihood)"
         rocprof_name = "void trpl::pair::stepper_pair_kernel<true, 1>"

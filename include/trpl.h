@@ -56,13 +56,14 @@ extern "C" {
                                      tol_exp 4-5 (fp32's residual floor is ~1e-7).  No reference exists for
                                      this mode (the reference is fp64 only) */
 
-/* which time-stepper kernel a launch of nsys = S * C systems on L nodes with these flags runs on the
- * current device (the choice never changes a system's result beyond the rounding of its node sums) */
+/* which time-stepper kernel a launch of nsys = S * C systems on L nodes taking `steps` time steps (T, or up
+ * to the last observation in likelihood mode) with these flags runs on the current device (the choice
+ * never changes a system's result beyond the rounding of its node sums) */
 #define TRPL_KERNEL_FAST 0        /* one system per wavefront */
-#define TRPL_KERNEL_FAST_PAIR 1   /* two systems per wavefront: L = 128, launches that more than fill the chip */
+#define TRPL_KERNEL_FAST_PAIR 1   /* two systems per wavefront: L = 128, launches that keep the chip full */
 #define TRPL_KERNEL_STRICT 2
 #define TRPL_KERNEL_FP32 3
-int trpl_kernel_variant(int64_t nsys, int32_t L, uint32_t flags);
+int trpl_kernel_variant(int64_t nsys, int32_t L, int64_t steps, uint32_t flags);
 
 int trpl_abi_version(void);
 const char *trpl_last_error(void);

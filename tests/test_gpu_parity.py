@@ -464,9 +464,9 @@ def test_full_size_properties(gpu):
     assert abs(info_f["iters_total"].sum() / info_s["iters_total"].sum() - 1) < 1e-3
     Pf2 = gpu.loglik(X, ini, lens, Time, 128, T, obs)
     assert np.array_equal(Pf, Pf2)                                            # (iii)
-    sub = gpu.loglik(X[61001:62200], ini, lens, Time, 128, T, obs)            # same kernel, other partners
-    assert np.array_equal(sub, Pf[61001:62200])                               # (ii)
-    # a launch too small to fill the chip runs the one-system-per-wavefront kernel, whose node sums
+    sub = gpu.loglik(X[60001:65300], ini, lens, Time, 128, T, obs)            # same kernel, other partners
+    assert np.array_equal(sub, Pf[60001:65300])                               # (ii)
+    # a launch that cannot keep the chip full runs the one-system-per-wavefront kernel, whose node sums
     # associate differently: same likelihoods to rounding
     small = gpu.loglik(X[61000:61300], ini, lens, Time, 128, T, obs)
     assert np.allclose(small, Pf[61000:61300], rtol=1e-10, atol=1e-10)
@@ -506,29 +506,29 @@ def test_multi_device_entry_point_equals_single_device(trpl, gpu):
     with pytest.raises(trpl.TrplError):
         trpl.loglik(X, ini, lengths, Time, 128, T, obs0, devices=[0, 99])
     # shards large enough for the two-systems-per-wavefront kernel: other partners, same bits
-    Xb = trpl.workloads.samples(5001, seed=6)
+    Xb = trpl.workloads.samples(10243, seed=6)
     obs2 = [np.full(41, 20.0)] * 3
     one = trpl.loglik(Xb, ini, lengths, 1.0, 128, 40, obs2)
     assert np.array_equal(trpl.loglik(Xb, ini, lengths, 1.0, 128, 40, obs2, devices=[0, 0]), one)
 
 
 # ---- two systems per wavefront (stepper_pair_impl.hpp): the kernel of every launch that fills the chip ----
-def _pair_batch(trpl, S):
+def _pair_batch(trpl, S, T):
     lib = trpl._abi.lib()
-    if lib.trpl_kernel_variant(3 * S, 128, 0) != trpl._abi.KERNEL_FAST_PAIR:
+    if lib.trpl_kernel_variant(3 * S, 128, T, 0) != trpl._abi.KERNEL_FAST_PAIR:
         pytest.skip("this device/TRPL_PAIR setting does not select the paired kernel for %d systems" % (3 * S))
-    assert lib.trpl_kernel_variant(3 * S, 128, trpl._abi.FLAG_STRICT) == trpl._abi.KERNEL_STRICT
+    assert lib.trpl_kernel_variant(3 * S, 128, T, trpl._abi.FLAG_STRICT) == trpl._abi.KERNEL_STRICT
     X = trpl.workloads.samples(S, seed=11)
     ini, lengths = trpl.workloads.power_scan(128)
     return X, ini, lengths
 
 
 def test_paired_kernel_matches_strict_with_identical_iteration_counts(trpl, gpu):
-    """Parity of the paired kernel at a size where it is the one that runs (4097 samples x 3 curves, odd
+    """Parity of the paired kernel at a size where it is the one that runs (5123 samples x 3 curves, odd
     tail included): against STRICT (bit-identical to the reference) every system takes exactly the
     same number of inner iterations and the likelihoods agree to 1e-9."""
-    S, T, Time = 4097, 200, 5.0
-    X, ini, lengths = _pair_batch(trpl, S)
+    S, T, Time = 5123, 200, 5.0
+    X, ini, lengths = _pair_batch(trpl, S, T)
     obs = [np.full(T + 1, 20.0) - 0.02 * np.arange(T + 1)] * 3
     fi, si = {}, {}
     pf = trpl.loglik(X, ini, lengths, Time, 128, T, obs, info=fi)
@@ -541,8 +541,8 @@ def test_paired_kernel_matches_strict_with_identical_iteration_counts(trpl, gpu)
 def test_paired_kernel_result_does_not_depend_on_the_partner(trpl, gpu):
     """A system's result is bit-for-bit the same whichever sample shares its wavefront and whichever
     half it sits in: drop the first sample (every pairing changes, every system changes half)."""
-    S, T, Time = 4098, 100, 2.5
-    X, ini, lengths = _pair_batch(trpl, S)
+    S, T, Time = 5122, 100, 2.5
+    X, ini, lengths = _pair_batch(trpl, S, T)
     obs = [np.full(T + 1, 20.0)] * 3
     a, b = {}, {}
     pa = trpl.loglik(X, ini, lengths, Time, 128, T, obs, info=a)
@@ -550,16 +550,19 @@ def test_paired_kernel_result_does_not_depend_on_the_partner(trpl, gpu):
     assert np.array_equal(pa[1:], pb)
     assert np.array_equal(a["sse"][:, 1:], b["sse"]) and np.array_equal(a["iters_total"][:, 1:], b["iters_total"])
     # and the PL-storing mode (pvSim): same kernel, same independence
-    pl_a = trpl.solve_pl(X[:, :12], lengths[0], Time, 128, T, ini[0])[0]     # 4098 systems: paired kernel
-    pl_b = trpl.solve_pl(X[1:, :12], lengths[0], Time, 128, T, ini[0])[0]
-    assert pl_a.shape == (S, T + 1) and np.array_equal(pl_a[1:], pl_b)
+    Xp = np.concatenate([X, X, X])[:, :12]                                   # one curve per call: 15 366 systems
+    assert trpl._abi.lib().trpl_kernel_variant(len(Xp) - 1, 128, T, 0) == trpl._abi.KERNEL_FAST_PAIR
+    pl_a = trpl.solve_pl(Xp, lengths[0], Time, 128, T, ini[0])[0]
+    pl_b = trpl.solve_pl(Xp[1:], lengths[0], Time, 128, T, ini[0])[0]
+    assert pl_a.shape == (3 * S, T + 1) and np.array_equal(pl_a[1:], pl_b)
+    assert np.array_equal(pl_a[:S], pl_a[S:2 * S])                           # same sample, other partner and half
 
 
 def test_paired_kernel_isolates_a_broken_system_from_its_partner(trpl, gpu):
     """NaN / zero-lifetime / non-converging samples are flagged (status, sse = inf) and their wavefront
     partners come out bit-identical to a run without them."""
-    S, T, Time = 4096, 60, 1.5
-    X, ini, lengths = _pair_batch(trpl, S)
+    S, T, Time = 5120, 60, 1.5
+    X, ini, lengths = _pair_batch(trpl, S, T)
     obs = [np.full(T + 1, 20.0)] * 3
     clean = {}
     pc = trpl.loglik(X, ini, lengths, Time, 128, T, obs, info=clean)
@@ -583,8 +586,8 @@ def test_paired_kernel_isolates_a_broken_system_from_its_partner(trpl, gpu):
 def test_paired_kernel_mixed_convergence_matches_strict(trpl, gpu):
     """With a small iteration cap some systems are flagged at different steps while their partners go
     on: status (the step), iteration totals and the surviving likelihoods equal STRICT's."""
-    S, T, Time = 2048, 30, 0.75
-    X, ini, lengths = _pair_batch(trpl, S)
+    S, T, Time = 5120, 30, 0.75
+    X, ini, lengths = _pair_batch(trpl, S, T)
     obs = [np.full(T + 1, 20.0)] * 3
     fi, si = {}, {}
     pf = trpl.loglik(X, ini, lengths, Time, 128, T, obs, info=fi, MAX=60)
