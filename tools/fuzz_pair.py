@@ -16,8 +16,9 @@ if sys.argv[1] == "run":
     ini, lens = wl.twothick(128)
     obs = [np.full(T + 1, 18.0) - 0.01 * np.arange(T + 1)] * len(lens)
     info = {}
-    P = trpl_amd.loglik(X, ini, lens, T * 0.025, 128, T, obs, info=info, MAX=2000)
-    v = trpl_amd._abi.lib().trpl_kernel_variant(S * len(lens), 128, T, 0)
+    strict = len(sys.argv) > 3 and sys.argv[3] == "strict"        # the reference's arithmetic as the third leg
+    P = trpl_amd.loglik(X, ini, lens, T * 0.025, 128, T, obs, info=info, MAX=2000, strict=strict)
+    v = trpl_amd._abi.lib().trpl_kernel_variant(S * len(lens), 128, T, trpl_amd.FLAG_STRICT if strict else 0)
     np.savez(sys.argv[2], P=P, variant=v, **{k: info[k] for k in ("sse", "status", "iters_total")})
     print("variant", v, "non-converged", int((info["status"] != 0).sum()), "of", info["status"].size,
           "iterations", int(info["iters_total"].sum()), "seconds", info["seconds"])
