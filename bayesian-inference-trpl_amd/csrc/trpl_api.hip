@@ -485,7 +485,7 @@ int trpl_loglik_multi(const double *X, int64_t S, int32_t C, const double *lengt
     const size_t nobs = (size_t)C * obs_ld;
     const double t0 = now_s();
     int rc = TRPL_OK;
-    // enqueue everything on every device before waiting for any of them
+    // stage and launch on every device before waiting for any of them
     for (int r = 0; r < n_devices && rc == TRPL_OK; r++) {
         Shard &q = sh[r];
         q.dev = devices ? devices[r] : r;
@@ -515,6 +515,18 @@ int trpl_loglik_multi(const double *X, int64_t S, int32_t C, const double *lengt
                                         obs_ld, n_obs, q.P.as<double>(), q.sse.as<double>(), q.status.as<int32_t>(),
                                         q.iters.as<int64_t>(), flags, q.st))
                 return e;
+            return TRPL_OK;
+        }();
+    }
+    // only now the copies back: a device-to-host copy into pageable memory blocks the calling thread until
+    // the shard's kernel has finished, so issuing it inside the loop above would run the devices one
+    // after the other
+    for (int r = 0; r < n_devices && rc == TRPL_OK; r++) {
+        Shard &q = sh[r];
+        const int64_t n = q.hi - q.lo;
+        if (n == 0 || !q.st) continue;
+        rc = [&]() -> int {
+            HIP_TRY(hipSetDevice(q.dev));
             HIP_TRY(hipMemcpyAsync(P + q.lo, q.P.p, (size_t)n * 8, hipMemcpyDeviceToHost, q.st));
             // per-curve outputs are [C][S] on the host and [C][n] on the device: one strided copy each
             if (sse)
