@@ -183,4 +183,88 @@ hipError_t launch_reduce_curves(double *P, const double *sse, int64_t S, int C, 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Likelihood of PL rows that are already in HBM (the output of trpl_solve_pl_dev) against one set of
+// observations, in ONE pass: re-dimensionalised PL -> optional self-normalisation -> clamp -> log10
+// (bayeslib.py:150-157) -> observations on the grid or linearly interpolated between the bracketing
+// grid points (bayeslib.py:184-191) -> squared error (probs.py:29-44).  This is what lets one solve
+// serve several experiments (the reference's loop order curves -> blocks -> experiments) without the
+// PL matrix ever crossing PCIe.  One 256-thread block per row (the reference's 1024-row blocks would
+// otherwise leave most of the chip idle behind the fp64 log10), threads stride over the observations,
+// fixed-order block reduction at the end: the sum is associated differently from probs.prob's serial loop (~1e-16);
+// trpl_log10_clamp + trpl_sse_accumulate remain the bit-exact pair.  HBM-bound: n_obs (or 2 n_obs,
+// off-grid) PL elements per row.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ double log_pl(T v, T v0, bool normalize, bool f32_staging)
+{
+    if (f32_staging) {                       // the reference's float32 plI buffer (bayeslib.py:137)
+        float f = (float)v;
+        if (normalize) f = f / (float)v0;
+        if ((double)f < DBL_MIN) f = (float)DBL_MIN;
+        return (double)(float)log10((double)f);
+    }
+    double d = (double)v;
+    if (normalize) d = d / (double)v0;
+    if (d < DBL_MIN) d = DBL_MIN;
+    return log10(d);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) pl_loglik_kernel(const T *pl, int64_t rows, int64_t ld, const double *obs,
+                                                        const int32_t *obs_hi, const double *obs_dx, const double *obs_h,
+                                                        int64_t n_obs, const double *mag, const int32_t *status,
+                                                        double *P, double *sse_out, uint32_t flags)
+{
+    __shared__ double part[4];
+    const int lane = threadIdx.x & 63;
+    const int64_t row = blockIdx.x;
+    const T *r = pl + row * ld;
+    const bool normalize = (flags & 0x4u) != 0, f32 = (flags & 0x2u) != 0 || sizeof(T) == 4;
+    const T v0 = r[0];
+    const double m = mag[row];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n_obs; i += 256) {
+        double y;
+        if (obs_hi) {
+            const int64_t hi = obs_hi[i];
+            const double lg_hi = log_pl<T>(r[hi], v0, normalize, f32), lg_lo = log_pl<T>(r[hi - 1], v0, normalize, f32);
+            const double dy = f32 ? (double)((float)lg_hi - (float)lg_lo) : lg_hi - lg_lo;
+            y = (dy / obs_h[i]) * obs_dx[i] + lg_lo;            // scipy interp1d: slope * (x - x_lo) + y_lo
+        } else {
+            y = log_pl<T>(r[i], v0, normalize, f32);
+        }
+        double err = y + m;
+        err -= obs[i];
+        acc += err * err;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        acc = ((part[0] + part[1]) + part[2]) + part[3];
+        // a system flagged non-converged (its PL is NaN from that step on) scores +inf, like the fused path
+        if ((status && status[row] != 0) || !(acc == acc)) acc = INFINITY;
+        if (sse_out) sse_out[row] = acc;
+        if (P) P[row] -= acc;                                   // probs.py:44,:60
+    }
+}
+
+hipError_t launch_pl_loglik(const void *pl, int elem_bytes, int64_t rows, int64_t ld, const double *obs,
+                            const int32_t *obs_hi, const double *obs_dx, const double *obs_h, int64_t n_obs,
+                            const double *mag, const int32_t *status, double *P, double *sse_out, uint32_t flags,
+                            hipStream_t stream)
+{
+    if (rows <= 0) return hipSuccess;
+    const dim3 grid((unsigned)rows), block(256);
+    if (elem_bytes == 4)
+        hipLaunchKernelGGL(pl_loglik_kernel<float>, grid, block, 0, stream, (const float *)pl, rows, ld, obs, obs_hi, obs_dx,
+                           obs_h, n_obs, mag, status, P, sse_out, flags);
+    else
+        hipLaunchKernelGGL(pl_loglik_kernel<double>, grid, block, 0, stream, (const double *)pl, rows, ld, obs, obs_hi, obs_dx,
+                           obs_h, n_obs, mag, status, P, sse_out, flags);
+    return hipGetLastError();
+}
+
 }  // namespace trpl

@@ -287,6 +287,26 @@ int trpl_sse_accumulate(double *P, const void *plI, int32_t elem_bytes, int64_t 
     return TRPL_OK;
 }
 
+/* ------------------------------------------------------------------ loglik from stored PL */
+int trpl_loglik_from_pl_dev(const void *plI, int32_t elem_bytes, int64_t rows, int64_t ncol, int64_t ld,
+                            const double *obs, const int32_t *obs_hi, const double *obs_dx, const double *obs_h,
+                            int64_t n_obs, const double *mag, const int32_t *status, double *P, double *sse,
+                            uint32_t flags, void *stream)
+{
+    if (elem_bytes != 4 && elem_bytes != 8) return fail(TRPL_ERR_ARG, "elem_bytes must be 4 or 8");
+    if (rows < 0 || ncol < 1 || ld < ncol || n_obs < 0) return fail(TRPL_ERR_ARG, "bad shape");
+    const bool interp = obs_hi || obs_dx || obs_h;
+    if (interp && !(obs_hi && obs_dx && obs_h)) return fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h go together");
+    if (!interp && n_obs > ncol) return fail(TRPL_ERR_ARG, "n_obs=%lld exceeds the %lld PL columns", (long long)n_obs, (long long)ncol);
+    if (rows > 0x7fffffffLL) return fail(TRPL_ERR_ARG, "too many rows for one launch");
+    if (rows == 0) return TRPL_OK;
+    if (!plI || !mag || (n_obs && !obs) || (!P && !sse)) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    hipError_t e = trpl::launch_pl_loglik(plI, elem_bytes, rows, ld, obs, obs_hi, obs_dx, obs_h, n_obs, mag, status, P, sse, flags,
+                                          (hipStream_t)stream);
+    if (e != hipSuccess) return fail(TRPL_ERR_HIP, "pl_loglik launch: %s", hipGetErrorString(e));
+    return TRPL_OK;
+}
+
 /* ------------------------------------------------------------------ fused loglik -------- */
 static int loglik_dev_impl(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns, int32_t L,
                            int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN,

@@ -56,6 +56,10 @@ hipError_t launch_log10_clamp(void *x, int elem_bytes, int64_t rows, int64_t col
 hipError_t launch_sse_accumulate(double *P, const void *pl, int elem_bytes, int64_t rows, int64_t n_obs,
                                  int64_t ld, const double *values, const double *mag, hipStream_t stream);
 hipError_t launch_reduce_curves(double *P, const double *sse, int64_t S, int C, hipStream_t stream);
+hipError_t launch_pl_loglik(const void *pl, int elem_bytes, int64_t rows, int64_t ld, const double *obs,
+                            const int32_t *obs_hi, const double *obs_dx, const double *obs_h, int64_t n_obs,
+                            const double *mag, const int32_t *status, double *P, double *sse_out, uint32_t flags,
+                            hipStream_t stream);
 
 // posterior.hip: the consumer of P[S] (weights, weighted moments, weighted histograms)
 size_t posterior_workspace_bytes(int D);

@@ -154,3 +154,24 @@ def sample_box_device(X, minX, maxX, do_log, seed=42, flags=0):
         raise ValueError("X must be (S, ncol) with ncol = len(minX) = len(maxX) = len(do_log)")
     _abi.check(_abi.lib().trpl_sample_box_dev(int(seed) & 0xFFFFFFFF, X.shape[0], lo.size, _abi.ptr(lo), _abi.ptr(hi),
                                               _abi.ptr(lg), int(flags), _chk(X, torch.float64, "X"), _stream()))
+
+
+def loglik_from_pl_device(pl, obs, mag, P=None, sse=None, obs_hi=None, obs_dx=None, obs_h=None, ncol=None, flags=0,
+                          status=None):
+    """trpl_loglik_from_pl_dev: likelihood of PL rows resident in HBM (pl (rows, ld) f32/f64, as written by
+    solve_pl_device) against one observation set obs (n_obs,) f64 -- on the grid, or off-grid with the
+    bracketing arrays obs_hi (int32), obs_dx, obs_h of driver.bracket_times.  mag (rows,) f64 log offsets;
+    P (rows,) is decremented in place and/or sse (rows,) receives the squared-error sums; status (rows,)
+    int32 from solve_pl_device makes flagged systems score +inf."""
+    import torch
+    if pl.dim() != 2 or pl.dtype not in (torch.float32, torch.float64):
+        raise ValueError("pl must be a 2-D float32/float64 tensor")
+    rows, ld = pl.shape
+    interp = obs_hi is not None
+    _abi.check(_abi.lib().trpl_loglik_from_pl_dev(
+        _chk(pl, pl.dtype, "pl"), pl.element_size(), rows, int(ld if ncol is None else ncol), ld,
+        _chk(obs, torch.float64, "obs"), _chk(obs_hi, torch.int32, "obs_hi") if interp else None,
+        _chk(obs_dx, torch.float64, "obs_dx") if interp else None, _chk(obs_h, torch.float64, "obs_h") if interp else None,
+        obs.shape[0], _chk(mag, torch.float64, "mag"), None if status is None else _chk(status, torch.int32, "status"),
+        None if P is None else _chk(P, torch.float64, "P"),
+        None if sse is None else _chk(sse, torch.float64, "sse"), int(flags), _stream()))

@@ -154,6 +154,64 @@ def loglik(X, init_params, lengths, Time, L, T, obs, tol=7, MAX=10000, plT=1, P=
     return P
 
 
+def _simulate_resident(e_data, P, X, num_curves, thicknesses, sim_params, init_params, normalize, pl_dtype, group,
+                       num_gpus, gpu_id, device, solver_time, err_sq_time, sim_t):
+    """Several experiments, fused option on: the reference's own loop order -- curves -> sample blocks ->
+    experiments (bayeslib.py:117-171) -- with the block's PL matrix kept in HBM: one solve per (curve, block)
+    (trpl_solve_pl_dev), then one pass over it per experiment (trpl_loglik_from_pl_dev: normalise, clamp,
+    log10, time interpolation, squared error).  Only X goes in and P comes out."""
+    import time
+
+    import torch
+
+    from . import device as tdev
+    dev = torch.device("cuda", device)
+    Time, L, T = sim_params[1], sim_params[2], sim_params[3]
+    tdt = torch.float32 if pl_dtype == np.float32 else torch.float64
+    flags = _abi.FLAG_NORMALIZE if normalize else 0
+    with torch.cuda.device(dev):
+        ini_d = torch.from_numpy(np.ascontiguousarray(init_params, dtype=np.float64)).to(dev)
+        # per (experiment, curve): observations and, off the grid, their brackets -- staged once
+        staged = []
+        for exp in e_data:
+            per_curve = []
+            for c in range(num_curves):
+                t = np.asarray(exp[0][c], dtype=float)
+                o = np.asarray(exp[1][c], dtype=float)
+                if almost_equal(sim_t, t):                                    # bayeslib.py:182-183
+                    per_curve.append((torch.from_numpy(np.ascontiguousarray(o)).to(dev), None))
+                else:
+                    order = np.argsort(t, kind="stable")
+                    hi, dx, h = bracket_times(sim_t, t[order])
+                    per_curve.append((torch.from_numpy(np.ascontiguousarray(o[order])).to(dev),
+                                      tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (hi, dx, h))))
+            staged.append(per_curve)
+        for blk in range(gpu_id * group, len(X), num_gpus * group):           # :131
+            size = min(group, len(X) - blk)
+            X_d = torch.from_numpy(np.ascontiguousarray(X[blk:blk + size], dtype=np.float64)).to(dev)
+            mat_d, mag_d = X_d[:, :12].contiguous(), X_d[:, 12].contiguous()   # :144,:195
+            P_d = torch.from_numpy(np.ascontiguousarray(P[:, blk:blk + size])).to(dev)
+            pl_d = torch.empty((size, T // sim_params[4] + 1), dtype=tdt, device=dev)     # :137
+            st_d = torch.empty(size, dtype=torch.int32, device=dev)
+            for c in range(num_curves):                                       # :117
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                tdev.solve_pl_device(mat_d, thicknesses[c], Time, L, T, ini_d[c].contiguous(), pl_d, status=st_d,
+                                     tol=sim_params[6], MAX=sim_params[7], plT=sim_params[4])
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for e, per_curve in enumerate(staged):                        # :171
+                    o_d, br = per_curve[c]
+                    tdev.loglik_from_pl_device(pl_d, o_d, mag_d, P=P_d[e], flags=flags, status=st_d,
+                                               obs_hi=None if br is None else br[0],
+                                               obs_dx=None if br is None else br[1],
+                                               obs_h=None if br is None else br[2])
+                torch.cuda.synchronize(dev)
+                solver_time[gpu_id] += t1 - t0
+                err_sq_time[gpu_id] += time.perf_counter() - t1
+            P[:, blk:blk + size] = P_d.cpu().numpy()
+
+
 def simulate(model, e_data, P, X, plI, plI_int, num_curves, sim_params, init_params, sim_flags, gpu_info, gpu_id,
              solver_time, err_sq_time, misc_time, logger=None):
     """bayeslib.simulate (bayeslib.py:83-205), GPU branch, same arguments and in-place effects.
@@ -185,6 +243,10 @@ def simulate(model, e_data, P, X, plI, plI_int, num_curves, sim_params, init_par
 
     fused = bool(gpu_info.get("fused", False)) and LOG_PL and sim_params[4] == 1 and all(
         in_range(exp[0][c]) for exp in e_data for c in range(num_curves))
+    if fused and len(e_data) > 1 and gpu_info.get("devices") is None:
+        _simulate_resident(e_data, P, X, num_curves, thicknesses, sim_params, init_params, NORMALIZE, pl_dtype,
+                           group, num_gpus, gpu_id, device, solver_time, err_sq_time, sim_t)
+        return
     if fused:
         # an experiment sampled exactly on the full simulation grid is compared point by point
         # (the reference's bypass, bayeslib.py:182-183); anything else is interpolated (:184-191)

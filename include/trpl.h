@@ -119,6 +119,26 @@ int trpl_sse_accumulate_dev(double *P, const void *plI, int32_t elem_bytes, int6
                             void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * trpl_loglik_from_pl_dev -- log-likelihood of PL rows that are ALREADY in device memory (the output of
+ * trpl_solve_pl_dev) against one observation set, in one pass: replaces, for one experiment,
+ * bayeslib.simulate's normalise / fastlog / griddata / prob sequence (bayeslib.py:150-157, :173-201) on a
+ * resident PL block, so that one solve serves every experiment (the reference's loop order
+ * curves -> blocks -> experiments, bayeslib.py:117-171) without the PL matrix crossing PCIe.
+ *   plI [rows][ld] fp32/fp64 PL as written by trpl_solve_pl_dev (ncol = T/plT + 1 valid columns)
+ *   obs [n_obs] log10 observations; obs_hi/obs_dx/obs_h all NULL: observation i sits on grid column i;
+ *   all non-NULL: off-grid times bracketed like trpl_loglik_obs (obs_hi in [1, ncol-1], plT = 1)
+ *   mag [rows] log offsets (X[:, 12]);  P [rows] (nullable): P[j] -= sse_j;  sse [rows] (nullable) out
+ *   status [rows] (nullable) as written by trpl_solve_pl_dev: a flagged system scores +inf, like trpl_loglik
+ *   flags: TRPL_FLAG_PL_F32 (implied by a 4-byte buffer), TRPL_FLAG_NORMALIZE
+ * The squared errors are summed by a wave reduction (trpl_log10_clamp + trpl_sse_accumulate stay the pair
+ * that is bit-identical to probs.prob's serial sum).  Device pointers only; nothing is allocated.
+ * ------------------------------------------------------------------------------------- */
+int trpl_loglik_from_pl_dev(const void *plI, int32_t elem_bytes, int64_t rows, int64_t ncol, int64_t ld,
+                            const double *obs, const int32_t *obs_hi, const double *obs_dx,
+                            const double *obs_h, int64_t n_obs, const double *mag, const int32_t *status,
+                            double *P, double *sse, uint32_t flags, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * trpl_loglik -- the fused path: replaces the body of bayeslib.simulate (bayeslib.py:117-201)
  * for one experiment whose observation times are the first n_obs[c] points of the simulation
  * grid: for every sample s and curve c it time-steps the system, and accumulates

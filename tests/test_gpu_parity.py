@@ -708,3 +708,56 @@ def test_device_sampler_draws_the_reference_stream(trpl, gpu, golden):
     assert np.allclose(X.cpu().numpy(), sm.default_box(42, 4096), rtol=5e-16, atol=0)
     with pytest.raises(trpl.TrplError):
         sm.random_grid_device(hi, lo, lg, 4)
+
+
+# ---- likelihood of PL rows resident in HBM (trpl_loglik_from_pl_dev): one solve, several experiments ----
+def test_loglik_from_resident_pl_equals_the_fused_kernel(trpl, gpu):
+    """solve_pl_device into an HBM buffer + loglik_from_pl_device per observation set == the fused kernel
+    (same PL, same log10 / staging / interpolation rules; the squared errors are summed in another order):
+    fp64 and float32 staging, self-normalisation, on- and off-grid times, a flagged system, two experiments
+    on one solve."""
+    import torch
+    tdev = trpl.device
+    S, T, Time, L = 300, 160, 4.0, 128
+    X = trpl.workloads.samples(S, seed=9)
+    X[:, 12] = np.linspace(-0.3, 0.4, S)                                   # non-trivial log offsets
+    ini, lengths = trpl.workloads.power_scan(L)
+    dev = torch.device("cuda", 0)
+    X_d = torch.from_numpy(X).to(dev)
+    mat_d, mag_d = X_d[:, :12].contiguous(), X_d[:, 12].contiguous()
+    ini_d = torch.from_numpy(ini).to(dev)
+    rng = np.random.default_rng(3)
+    sim_t = np.linspace(0, Time, T + 1)
+    obs_on = [19.0 - 0.02 * np.arange(100), 19.5 - 0.01 * np.arange(T + 1), 20.0 - 0.03 * np.arange(7)]
+    t_off = [np.sort(rng.uniform(0, Time, n)) for n in (50, 1, 33)]
+    obs_off = [19.0 + 0.1 * rng.standard_normal(len(t)) for t in t_off]
+    for pl_dtype, f32 in ((torch.float64, False), (torch.float32, True)):
+        for normalize in (False, True):
+            flags = trpl._abi.FLAG_NORMALIZE if normalize else 0
+            want_on = trpl.loglik(X, ini, lengths, Time, L, T, obs_on, pl_f32=f32, normalize=normalize)
+            want_off = trpl.loglik(X, ini, lengths, Time, L, T, obs_off, times=t_off, pl_f32=f32, normalize=normalize)
+            P_on = torch.zeros(S, dtype=torch.float64, device=dev)
+            P_off = torch.zeros(S, dtype=torch.float64, device=dev)
+            pl = torch.empty((S, T + 1), dtype=pl_dtype, device=dev)
+            st = torch.empty(S, dtype=torch.int32, device=dev)
+            for c in range(3):                                               # ONE solve per curve, two experiments on it
+                tdev.solve_pl_device(mat_d, lengths[c], Time, L, T, ini_d[c].contiguous(), pl, status=st)
+                tdev.loglik_from_pl_device(pl, torch.from_numpy(obs_on[c]).to(dev), mag_d, P=P_on, flags=flags, status=st)
+                hi, dx, h = trpl.bracket_times(sim_t, t_off[c])
+                tdev.loglik_from_pl_device(pl, torch.from_numpy(obs_off[c]).to(dev), mag_d, P=P_off, flags=flags, status=st,
+                                           obs_hi=torch.from_numpy(hi).to(dev), obs_dx=torch.from_numpy(dx).to(dev),
+                                           obs_h=torch.from_numpy(h).to(dev))
+            tol = 2e-6 if f32 else 1e-12          # float32 staging: (float)(pl/norm) here vs (float)pl/(float)norm fused
+            assert np.allclose(P_on.cpu().numpy(), want_on, rtol=tol, atol=0), (pl_dtype, normalize)
+            assert np.allclose(P_off.cpu().numpy(), want_off, rtol=tol, atol=0), (pl_dtype, normalize)
+    # a flagged system scores -inf, its neighbours are untouched
+    pl = torch.empty((S, T + 1), dtype=torch.float64, device=dev)
+    st = torch.empty(S, dtype=torch.int32, device=dev)
+    tdev.solve_pl_device(mat_d, lengths[2], Time, L, T, ini_d[2].contiguous(), pl, status=st, MAX=25)
+    assert 0 < int((st != 0).sum()) < S
+    sse = torch.empty(S, dtype=torch.float64, device=dev)
+    tdev.loglik_from_pl_device(pl, torch.from_numpy(obs_on[1]).to(dev), mag_d, sse=sse, status=st)
+    bad = (st != 0).cpu().numpy()
+    assert np.isinf(sse.cpu().numpy()[bad]).all() and np.isfinite(sse.cpu().numpy()[~bad]).all()
+    with pytest.raises(trpl.TrplError):
+        tdev.loglik_from_pl_device(pl, torch.zeros(T + 5, dtype=torch.float64, device=dev), mag_d, sse=sse)
