@@ -190,7 +190,8 @@ def main():
         rocprof_name = ("void trpl::f32::stepper_kernel<%d>" % L) if args.fp32 else \
             "void trpl::stepper_kernel<%d, %s>" % (L, "true" if args.strict else "false")
     out = {
-        "metric": "TRPL system-timesteps/s at %d nodes (fused solve + log-likelihood)" % L,
+        "metric": "TRPL timesteps/sec at %d nodes (system = parameter sample x excitation; fused solve + "
+                  "log-likelihood; parameter-sample likelihoods/sec in likelihoods_per_s_*)" % L,
         "value": value,
         "unit": "system-timesteps/s",
         "n_gpus": world,
