@@ -761,3 +761,34 @@ def test_loglik_from_resident_pl_equals_the_fused_kernel(trpl, gpu):
     assert np.isinf(sse.cpu().numpy()[bad]).all() and np.isfinite(sse.cpu().numpy()[~bad]).all()
     with pytest.raises(trpl.TrplError):
         tdev.loglik_from_pl_device(pl, torch.zeros(T + 5, dtype=torch.float64, device=dev), mag_d, sse=sse)
+
+
+def test_fused_call_limits_sixteen_curves_and_strided_pl(trpl, gpu):
+    """Edge sizes of one fused call: the maximum of 16 curves (ragged observation counts) equals sixteen
+    one-curve calls accumulated in curve order; 17 is refused; plT > 1 in a launch large enough for the
+    two-systems-per-wavefront kernel equals STRICT."""
+    S, T, Time, L = 40, 50, 1.25, 128
+    X = trpl.workloads.samples(S, seed=21)
+    base, lens3 = trpl.workloads.power_scan(L)
+    ini = np.stack([base[c % 3] * (1.0 + 0.05 * c) for c in range(16)])
+    lengths = np.array([2000.0 if c % 2 else 311.0 for c in range(16)])
+    obs = [np.full(1 + (7 * c) % (T + 1), 19.0 + 0.1 * c) for c in range(16)]
+    info = {}
+    P16 = trpl.loglik(X, ini, lengths, Time, L, T, obs, info=info)
+    Pacc = np.zeros(S)
+    for c in range(16):
+        one = {}
+        trpl.loglik(X, ini[c:c + 1], lengths[c:c + 1], Time, L, T, [obs[c]], P=Pacc, info=one)
+        assert np.array_equal(one["sse"][0], info["sse"][c]) and np.array_equal(one["iters_total"][0], info["iters_total"][c])
+    assert np.array_equal(P16, Pacc)
+    with pytest.raises(trpl.TrplError):
+        trpl.loglik(X, np.concatenate([ini, ini[:1]]), np.append(lengths, 311.0), Time, L, T, obs + [obs[0]])
+    # plT = 4 at paired-kernel size
+    S2, T2 = 5200, 64
+    if trpl._abi.lib().trpl_kernel_variant(3 * S2, 128, T2, 0) == trpl._abi.KERNEL_FAST_PAIR:
+        X2 = trpl.workloads.samples(S2, seed=22)
+        obs4 = [np.full(T2 // 4 + 1, 19.5)] * 3
+        fi, si = {}, {}
+        pf = trpl.loglik(X2, base, lens3, T2 * 0.025, L, T2, obs4, plT=4, info=fi)
+        ps = trpl.loglik(X2, base, lens3, T2 * 0.025, L, T2, obs4, plT=4, info=si, strict=True)
+        assert np.array_equal(fi["iters_total"], si["iters_total"]) and np.allclose(pf, ps, rtol=1e-9, atol=0)
