@@ -106,10 +106,27 @@ int launch(const trpl::StepArgs &a, uint32_t flags, hipStream_t st, int64_t step
     return TRPL_OK;
 }
 
+// Every host-buffer call works on a private non-blocking stream with stream-ordered allocations, so
+// that calls issued from different host threads (or for different devices) overlap on the GPU: nothing
+// here synchronises the whole device.  Declare the CallScope before the DevBufs of a call: the buffers
+// are released (hipFreeAsync) first, then the scope drains and destroys the stream.
+struct CallScope {
+    hipStream_t st = nullptr;
+    hipError_t open() { return hipStreamCreateWithFlags(&st, hipStreamNonBlocking); }
+    ~CallScope()
+    {
+        if (st) {
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamDestroy(st);
+        }
+    }
+};
 struct DevBuf {                      // RAII device allocation for the host-buffer calls
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+    hipStream_t st = nullptr;
+    void release() { if (p) (void)hipFreeAsync(p, st); p = nullptr; }
+    ~DevBuf() { release(); }
+    hipError_t alloc(size_t n, hipStream_t s) { st = s; return hipMallocAsync(&p, n ? n : 1, s); }
     template <typename T> T *as() { return (T *)p; }
 };
 
@@ -186,25 +203,28 @@ int trpl_solve_pl(const double *matpar, int64_t S, double length_nm, double time
     const int64_t ncol = T / plT + 1;
     if (pl_ld < ncol) return fail(TRPL_ERR_ARG, "pl_ld=%lld < T/plT+1", (long long)pl_ld);
     if (int rc = select_device(device)) return rc;
+    CallScope cs;
+    HIP_TRY(cs.open());
     DevBuf dm, dn, dp, ds, di;
-    HIP_TRY(dm.alloc((size_t)S * 12 * 8));
-    HIP_TRY(dn.alloc((size_t)L * 8));
-    HIP_TRY(dp.alloc((size_t)S * ncol * pl_elem_bytes));
-    HIP_TRY(ds.alloc((size_t)S * 4));
-    HIP_TRY(di.alloc((size_t)S * 8));
-    HIP_TRY(hipMemcpy(dm.p, matpar, (size_t)S * 12 * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dn.p, dN, (size_t)L * 8, hipMemcpyHostToDevice));
+    HIP_TRY(dm.alloc((size_t)S * 12 * 8, cs.st));
+    HIP_TRY(dn.alloc((size_t)L * 8, cs.st));
+    HIP_TRY(dp.alloc((size_t)S * ncol * pl_elem_bytes, cs.st));
+    HIP_TRY(ds.alloc((size_t)S * 4, cs.st));
+    HIP_TRY(di.alloc((size_t)S * 8, cs.st));
+    HIP_TRY(hipMemcpyAsync(dm.p, matpar, (size_t)S * 12 * 8, hipMemcpyHostToDevice, cs.st));
+    HIP_TRY(hipMemcpyAsync(dn.p, dN, (size_t)L * 8, hipMemcpyHostToDevice, cs.st));
     const double t0 = now_s();
     if (int rc = trpl_solve_pl_dev(dm.as<double>(), S, length_nm, time_ns, L, T, plT, tol_exp, max_iter,
                                    dn.as<double>(), dp.p, pl_elem_bytes, ncol, ds.as<int32_t>(),
-                                   di.as<int64_t>(), flags, nullptr))
+                                   di.as<int64_t>(), flags, cs.st))
         return rc;
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(cs.st));
     if (seconds) *seconds = now_s() - t0;                       /* pvSimPCR.py:378-381 */
-    HIP_TRY(hipMemcpy2D(plI, (size_t)pl_ld * pl_elem_bytes, dp.p, (size_t)ncol * pl_elem_bytes,
-                        (size_t)ncol * pl_elem_bytes, (size_t)S, hipMemcpyDeviceToHost));
-    if (status) HIP_TRY(hipMemcpy(status, ds.p, (size_t)S * 4, hipMemcpyDeviceToHost));
-    if (iters_total) HIP_TRY(hipMemcpy(iters_total, di.p, (size_t)S * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy2DAsync(plI, (size_t)pl_ld * pl_elem_bytes, dp.p, (size_t)ncol * pl_elem_bytes,
+                        (size_t)ncol * pl_elem_bytes, (size_t)S, hipMemcpyDeviceToHost, cs.st));
+    if (status) HIP_TRY(hipMemcpyAsync(status, ds.p, (size_t)S * 4, hipMemcpyDeviceToHost, cs.st));
+    if (iters_total) HIP_TRY(hipMemcpyAsync(iters_total, di.p, (size_t)S * 8, hipMemcpyDeviceToHost, cs.st));
+    HIP_TRY(hipStreamSynchronize(cs.st));        // the copies back have landed (and their errors surface here)
     return TRPL_OK;
 }
 
@@ -231,15 +251,18 @@ int trpl_log10_clamp(void *x, int32_t elem_bytes, int64_t rows, int64_t cols, in
     if (rows == 0 || cols == 0) return TRPL_OK;
     if (!x) return fail(TRPL_ERR_ARG, "x must not be NULL");
     if (int rc = select_device(device)) return rc;
+    CallScope cs;
+    HIP_TRY(cs.open());
     const double t0 = now_s();                                   /* probs.py:79: includes the copies */
     DevBuf dx;
     const size_t rowb = (size_t)cols * elem_bytes;
-    HIP_TRY(dx.alloc(rowb * rows));
-    HIP_TRY(hipMemcpy2D(dx.p, rowb, x, (size_t)ld * elem_bytes, rowb, (size_t)rows, hipMemcpyHostToDevice));
-    if (int rc = trpl_log10_clamp_dev(dx.p, elem_bytes, rows, cols, cols, min, nullptr)) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy2D(x, (size_t)ld * elem_bytes, dx.p, rowb, rowb, (size_t)rows, hipMemcpyDeviceToHost));
+    HIP_TRY(dx.alloc(rowb * rows, cs.st));
+    HIP_TRY(hipMemcpy2DAsync(dx.p, rowb, x, (size_t)ld * elem_bytes, rowb, (size_t)rows, hipMemcpyHostToDevice, cs.st));
+    if (int rc = trpl_log10_clamp_dev(dx.p, elem_bytes, rows, cols, cols, min, cs.st)) return rc;
+    HIP_TRY(hipStreamSynchronize(cs.st));
+    HIP_TRY(hipMemcpy2DAsync(x, (size_t)ld * elem_bytes, dx.p, rowb, rowb, (size_t)rows, hipMemcpyDeviceToHost, cs.st));
     if (seconds) *seconds = now_s() - t0;
+    HIP_TRY(hipStreamSynchronize(cs.st));        // the copies back have landed (and their errors surface here)
     return TRPL_OK;
 }
 
@@ -265,25 +288,28 @@ int trpl_sse_accumulate(double *P, const void *plI, int32_t elem_bytes, int64_t 
     if (rows == 0) return TRPL_OK;
     if (!P || !mag || (n_obs && (!plI || !values))) return fail(TRPL_ERR_ARG, "NULL pointer argument");
     if (int rc = select_device(device)) return rc;
+    CallScope cs;
+    HIP_TRY(cs.open());
     const double t0 = now_s();                                   /* probs.py:51 */
     DevBuf dP, dpl, dv, dm;
     const size_t rowb = (size_t)n_obs * elem_bytes;
-    HIP_TRY(dP.alloc((size_t)rows * 8));
-    HIP_TRY(dpl.alloc(rowb * rows));
-    HIP_TRY(dv.alloc((size_t)n_obs * 8));
-    HIP_TRY(dm.alloc((size_t)rows * 8));
-    HIP_TRY(hipMemcpy(dP.p, P, (size_t)rows * 8, hipMemcpyHostToDevice));
+    HIP_TRY(dP.alloc((size_t)rows * 8, cs.st));
+    HIP_TRY(dpl.alloc(rowb * rows, cs.st));
+    HIP_TRY(dv.alloc((size_t)n_obs * 8, cs.st));
+    HIP_TRY(dm.alloc((size_t)rows * 8, cs.st));
+    HIP_TRY(hipMemcpyAsync(dP.p, P, (size_t)rows * 8, hipMemcpyHostToDevice, cs.st));
     if (n_obs) {
-        HIP_TRY(hipMemcpy2D(dpl.p, rowb, plI, (size_t)ld * elem_bytes, rowb, (size_t)rows, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(dv.p, values, (size_t)n_obs * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy2DAsync(dpl.p, rowb, plI, (size_t)ld * elem_bytes, rowb, (size_t)rows, hipMemcpyHostToDevice, cs.st));
+        HIP_TRY(hipMemcpyAsync(dv.p, values, (size_t)n_obs * 8, hipMemcpyHostToDevice, cs.st));
     }
-    HIP_TRY(hipMemcpy(dm.p, mag, (size_t)rows * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(dm.p, mag, (size_t)rows * 8, hipMemcpyHostToDevice, cs.st));
     if (int rc = trpl_sse_accumulate_dev(dP.as<double>(), dpl.p, elem_bytes, rows, n_obs, n_obs, dv.as<double>(),
-                                         dm.as<double>(), nullptr))
+                                         dm.as<double>(), cs.st))
         return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(P, dP.p, (size_t)rows * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipStreamSynchronize(cs.st));
+    HIP_TRY(hipMemcpyAsync(P, dP.p, (size_t)rows * 8, hipMemcpyDeviceToHost, cs.st));
     if (seconds) *seconds = now_s() - t0;
+    HIP_TRY(hipStreamSynchronize(cs.st));        // the copies back have landed (and their errors surface here)
     return TRPL_OK;
 }
 
@@ -384,6 +410,8 @@ static int loglik_host_impl(const double *X, int64_t S, int32_t C, const double 
     if (!X || !lengths_nm || !dN || !obs || !n_obs || !P) return fail(TRPL_ERR_ARG, "NULL pointer argument");
     if (obs_ld < 1) return fail(TRPL_ERR_ARG, "obs_ld must be >= 1");
     if (int rc = select_device(device)) return rc;
+    CallScope cs;
+    HIP_TRY(cs.open());
     const bool interp = obs_hi != nullptr;
     if (interp) {                                    // the brackets are host data here: validate them
         for (int c = 0; c < C; c++)
@@ -395,36 +423,37 @@ static int loglik_host_impl(const double *X, int64_t S, int32_t C, const double 
     }
     DevBuf dX, ddN, dobs, dhi, ddx, dh, dP, dsse, dst, dit;
     const size_t nsys = (size_t)S * C, nobs = (size_t)C * obs_ld;
-    HIP_TRY(dX.alloc((size_t)S * 13 * 8));
-    HIP_TRY(ddN.alloc((size_t)C * L * 8));
-    HIP_TRY(dobs.alloc(nobs * 8));
-    HIP_TRY(dP.alloc((size_t)S * 8));
-    HIP_TRY(dsse.alloc(nsys * 8));
-    HIP_TRY(dst.alloc(nsys * 4));
-    HIP_TRY(dit.alloc(nsys * 8));
-    HIP_TRY(hipMemcpy(dX.p, X, (size_t)S * 13 * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ddN.p, dN, (size_t)C * L * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dobs.p, obs, nobs * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dP.p, P, (size_t)S * 8, hipMemcpyHostToDevice));
+    HIP_TRY(dX.alloc((size_t)S * 13 * 8, cs.st));
+    HIP_TRY(ddN.alloc((size_t)C * L * 8, cs.st));
+    HIP_TRY(dobs.alloc(nobs * 8, cs.st));
+    HIP_TRY(dP.alloc((size_t)S * 8, cs.st));
+    HIP_TRY(dsse.alloc(nsys * 8, cs.st));
+    HIP_TRY(dst.alloc(nsys * 4, cs.st));
+    HIP_TRY(dit.alloc(nsys * 8, cs.st));
+    HIP_TRY(hipMemcpyAsync(dX.p, X, (size_t)S * 13 * 8, hipMemcpyHostToDevice, cs.st));
+    HIP_TRY(hipMemcpyAsync(ddN.p, dN, (size_t)C * L * 8, hipMemcpyHostToDevice, cs.st));
+    HIP_TRY(hipMemcpyAsync(dobs.p, obs, nobs * 8, hipMemcpyHostToDevice, cs.st));
+    HIP_TRY(hipMemcpyAsync(dP.p, P, (size_t)S * 8, hipMemcpyHostToDevice, cs.st));
     if (interp) {
-        HIP_TRY(dhi.alloc(nobs * 4)); HIP_TRY(ddx.alloc(nobs * 8)); HIP_TRY(dh.alloc(nobs * 8));
-        HIP_TRY(hipMemcpy(dhi.p, obs_hi, nobs * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(ddx.p, obs_dx, nobs * 8, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(dh.p, obs_h, nobs * 8, hipMemcpyHostToDevice));
+        HIP_TRY(dhi.alloc(nobs * 4, cs.st)); HIP_TRY(ddx.alloc(nobs * 8, cs.st)); HIP_TRY(dh.alloc(nobs * 8, cs.st));
+        HIP_TRY(hipMemcpyAsync(dhi.p, obs_hi, nobs * 4, hipMemcpyHostToDevice, cs.st));
+        HIP_TRY(hipMemcpyAsync(ddx.p, obs_dx, nobs * 8, hipMemcpyHostToDevice, cs.st));
+        HIP_TRY(hipMemcpyAsync(dh.p, obs_h, nobs * 8, hipMemcpyHostToDevice, cs.st));
     }
     const double t0 = now_s();
     if (int rc = loglik_dev_impl(dX.as<double>(), S, C, lengths_nm, time_ns, L, T, plT, tol_exp, max_iter,
                                  ddN.as<double>(), dobs.as<double>(), interp ? dhi.as<int32_t>() : nullptr,
                                  interp ? ddx.as<double>() : nullptr, interp ? dh.as<double>() : nullptr, obs_ld, n_obs,
                                  dP.as<double>(), dsse.as<double>(), dst.as<int32_t>(), dit.as<int64_t>(), flags,
-                                 nullptr))
+                                 cs.st))
         return rc;
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(cs.st));
     if (seconds) *seconds = now_s() - t0;
-    HIP_TRY(hipMemcpy(P, dP.p, (size_t)S * 8, hipMemcpyDeviceToHost));
-    if (sse) HIP_TRY(hipMemcpy(sse, dsse.p, nsys * 8, hipMemcpyDeviceToHost));
-    if (status) HIP_TRY(hipMemcpy(status, dst.p, nsys * 4, hipMemcpyDeviceToHost));
-    if (iters_total) HIP_TRY(hipMemcpy(iters_total, dit.p, nsys * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(P, dP.p, (size_t)S * 8, hipMemcpyDeviceToHost, cs.st));
+    if (sse) HIP_TRY(hipMemcpyAsync(sse, dsse.p, nsys * 8, hipMemcpyDeviceToHost, cs.st));
+    if (status) HIP_TRY(hipMemcpyAsync(status, dst.p, nsys * 4, hipMemcpyDeviceToHost, cs.st));
+    if (iters_total) HIP_TRY(hipMemcpyAsync(iters_total, dit.p, nsys * 8, hipMemcpyDeviceToHost, cs.st));
+    HIP_TRY(hipStreamSynchronize(cs.st));        // the copies back have landed (and their errors surface here)
     return TRPL_OK;
 }
 
@@ -468,7 +497,11 @@ struct Shard {                       // one device's share of the samples; relea
     ~Shard()
     {
         (void)hipSetDevice(dev);
-        if (st) (void)hipStreamDestroy(st);
+        for (DevBuf *b : {&X, &dN, &obs, &ohi, &odx, &oh, &P, &sse, &status, &iters}) b->release();   // stream-ordered frees
+        if (st) {
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamDestroy(st);
+        }
     }
 };
 }  // namespace
@@ -516,15 +549,15 @@ int trpl_loglik_multi(const double *X, int64_t S, int32_t C, const double *lengt
         rc = [&]() -> int {
             HIP_TRY(hipSetDevice(q.dev));
             HIP_TRY(hipStreamCreateWithFlags(&q.st, hipStreamNonBlocking));
-            HIP_TRY(q.X.alloc((size_t)n * 13 * 8)); HIP_TRY(q.dN.alloc((size_t)C * L * 8)); HIP_TRY(q.obs.alloc(nobs * 8));
-            HIP_TRY(q.P.alloc((size_t)n * 8)); HIP_TRY(q.sse.alloc(nsys * 8)); HIP_TRY(q.status.alloc(nsys * 4));
-            HIP_TRY(q.iters.alloc(nsys * 8));
+            HIP_TRY(q.X.alloc((size_t)n * 13 * 8, q.st)); HIP_TRY(q.dN.alloc((size_t)C * L * 8, q.st)); HIP_TRY(q.obs.alloc(nobs * 8, q.st));
+            HIP_TRY(q.P.alloc((size_t)n * 8, q.st)); HIP_TRY(q.sse.alloc(nsys * 8, q.st)); HIP_TRY(q.status.alloc(nsys * 4, q.st));
+            HIP_TRY(q.iters.alloc(nsys * 8, q.st));
             HIP_TRY(hipMemcpyAsync(q.X.p, X + q.lo * 13, (size_t)n * 13 * 8, hipMemcpyHostToDevice, q.st));
             HIP_TRY(hipMemcpyAsync(q.dN.p, dN, (size_t)C * L * 8, hipMemcpyHostToDevice, q.st));
             HIP_TRY(hipMemcpyAsync(q.obs.p, obs, nobs * 8, hipMemcpyHostToDevice, q.st));
             HIP_TRY(hipMemcpyAsync(q.P.p, P + q.lo, (size_t)n * 8, hipMemcpyHostToDevice, q.st));
             if (interp) {
-                HIP_TRY(q.ohi.alloc(nobs * 4)); HIP_TRY(q.odx.alloc(nobs * 8)); HIP_TRY(q.oh.alloc(nobs * 8));
+                HIP_TRY(q.ohi.alloc(nobs * 4, q.st)); HIP_TRY(q.odx.alloc(nobs * 8, q.st)); HIP_TRY(q.oh.alloc(nobs * 8, q.st));
                 HIP_TRY(hipMemcpyAsync(q.ohi.p, obs_hi, nobs * 4, hipMemcpyHostToDevice, q.st));
                 HIP_TRY(hipMemcpyAsync(q.odx.p, obs_dx, nobs * 8, hipMemcpyHostToDevice, q.st));
                 HIP_TRY(hipMemcpyAsync(q.oh.p, obs_h, nobs * 8, hipMemcpyHostToDevice, q.st));
@@ -600,17 +633,20 @@ int trpl_posterior_weights(const double *LL, int64_t S, double tf, double *W, do
     if (!LL || !W) return fail(TRPL_ERR_ARG, "NULL pointer argument");
     if (!(tf > 0)) return fail(TRPL_ERR_ARG, "tf must be > 0");
     if (int rc = select_device(device)) return rc;
+    CallScope cs;
+    HIP_TRY(cs.open());
     DevBuf dL, dW, dSt, ws;
     const size_t wsb = trpl::posterior_workspace_bytes(1);
-    HIP_TRY(dL.alloc((size_t)S * 8)); HIP_TRY(dW.alloc((size_t)S * 8)); HIP_TRY(dSt.alloc(16)); HIP_TRY(ws.alloc(wsb));
-    HIP_TRY(hipMemcpy(dL.p, LL, (size_t)S * 8, hipMemcpyHostToDevice));
+    HIP_TRY(dL.alloc((size_t)S * 8, cs.st)); HIP_TRY(dW.alloc((size_t)S * 8, cs.st)); HIP_TRY(dSt.alloc(16, cs.st)); HIP_TRY(ws.alloc(wsb, cs.st));
+    HIP_TRY(hipMemcpyAsync(dL.p, LL, (size_t)S * 8, hipMemcpyHostToDevice, cs.st));
     const double t0 = now_s();
-    if (int rc = trpl_posterior_weights_dev(dL.as<double>(), S, tf, dW.as<double>(), dSt.as<double>(), ws.p, (int64_t)wsb, nullptr))
+    if (int rc = trpl_posterior_weights_dev(dL.as<double>(), S, tf, dW.as<double>(), dSt.as<double>(), ws.p, (int64_t)wsb, cs.st))
         return rc;
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(cs.st));
     if (seconds) *seconds = now_s() - t0;
-    HIP_TRY(hipMemcpy(W, dW.p, (size_t)S * 8, hipMemcpyDeviceToHost));
-    if (stats) HIP_TRY(hipMemcpy(stats, dSt.p, 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(W, dW.p, (size_t)S * 8, hipMemcpyDeviceToHost, cs.st));
+    if (stats) HIP_TRY(hipMemcpyAsync(stats, dSt.p, 16, hipMemcpyDeviceToHost, cs.st));
+    HIP_TRY(hipStreamSynchronize(cs.st));        // the copies back have landed (and their errors surface here)
     return TRPL_OK;
 }
 
@@ -639,22 +675,25 @@ int trpl_posterior_moments(const double *V, int64_t S, int32_t D, const double *
     if (S == 0) return TRPL_OK;
     if (!V || !W) return fail(TRPL_ERR_ARG, "NULL pointer argument");
     if (int rc = select_device(device)) return rc;
+    CallScope cs;
+    HIP_TRY(cs.open());
     DevBuf dV, dW, dS, dC, dM, ws;
     const size_t wsb = trpl::posterior_workspace_bytes(D);
-    if (mean_in) { HIP_TRY(dM.alloc((size_t)D * 8)); HIP_TRY(hipMemcpy(dM.p, mean_in, (size_t)D * 8, hipMemcpyHostToDevice)); }
-    HIP_TRY(dV.alloc((size_t)S * D * 8)); HIP_TRY(dW.alloc((size_t)S * 8)); HIP_TRY(dS.alloc((2 + D) * 8));
-    HIP_TRY(dC.alloc((size_t)D * (D + 2) * 8)); HIP_TRY(ws.alloc(wsb));
-    HIP_TRY(hipMemcpy(dV.p, V, (size_t)S * D * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dW.p, W, (size_t)S * 8, hipMemcpyHostToDevice));
+    if (mean_in) { HIP_TRY(dM.alloc((size_t)D * 8, cs.st)); HIP_TRY(hipMemcpyAsync(dM.p, mean_in, (size_t)D * 8, hipMemcpyHostToDevice, cs.st)); }
+    HIP_TRY(dV.alloc((size_t)S * D * 8, cs.st)); HIP_TRY(dW.alloc((size_t)S * 8, cs.st)); HIP_TRY(dS.alloc((2 + D) * 8, cs.st));
+    HIP_TRY(dC.alloc((size_t)D * (D + 2) * 8, cs.st)); HIP_TRY(ws.alloc(wsb, cs.st));
+    HIP_TRY(hipMemcpyAsync(dV.p, V, (size_t)S * D * 8, hipMemcpyHostToDevice, cs.st));
+    HIP_TRY(hipMemcpyAsync(dW.p, W, (size_t)S * 8, hipMemcpyHostToDevice, cs.st));
     const double t0 = now_s();
     if (int rc = trpl_posterior_moments_dev(dV.as<double>(), S, D, dW.as<double>(), mean_in ? dM.as<double>() : nullptr,
                                             dS.as<double>(), dC.as<double>(), ws.p,
-                                            (int64_t)wsb, nullptr))
+                                            (int64_t)wsb, cs.st))
         return rc;
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(cs.st));
     if (seconds) *seconds = now_s() - t0;
-    HIP_TRY(hipMemcpy(sums, dS.p, (2 + D) * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(central, dC.p, (size_t)D * (D + 2) * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(sums, dS.p, (2 + D) * 8, hipMemcpyDeviceToHost, cs.st));
+    HIP_TRY(hipMemcpyAsync(central, dC.p, (size_t)D * (D + 2) * 8, hipMemcpyDeviceToHost, cs.st));
+    HIP_TRY(hipStreamSynchronize(cs.st));        // the copies back have landed (and their errors surface here)
     return TRPL_OK;
 }
 
@@ -690,19 +729,22 @@ int trpl_posterior_hist(const double *x, const double *y, const double *W, int64
     if (S == 0) return TRPL_OK;
     if (!x) return fail(TRPL_ERR_ARG, "NULL pointer argument");
     if (int rc = select_device(device)) return rc;
+    CallScope cs;
+    HIP_TRY(cs.open());
     DevBuf dx, dy, dW, dO;
-    HIP_TRY(dx.alloc((size_t)S * 8)); HIP_TRY(dO.alloc(nb * 8));
-    HIP_TRY(hipMemcpy(dx.p, x, (size_t)S * 8, hipMemcpyHostToDevice));
-    if (y) { HIP_TRY(dy.alloc((size_t)S * 8)); HIP_TRY(hipMemcpy(dy.p, y, (size_t)S * 8, hipMemcpyHostToDevice)); }
-    if (W) { HIP_TRY(dW.alloc((size_t)S * 8)); HIP_TRY(hipMemcpy(dW.p, W, (size_t)S * 8, hipMemcpyHostToDevice)); }
-    HIP_TRY(hipMemset(dO.p, 0, nb * 8));
+    HIP_TRY(dx.alloc((size_t)S * 8, cs.st)); HIP_TRY(dO.alloc(nb * 8, cs.st));
+    HIP_TRY(hipMemcpyAsync(dx.p, x, (size_t)S * 8, hipMemcpyHostToDevice, cs.st));
+    if (y) { HIP_TRY(dy.alloc((size_t)S * 8, cs.st)); HIP_TRY(hipMemcpyAsync(dy.p, y, (size_t)S * 8, hipMemcpyHostToDevice, cs.st)); }
+    if (W) { HIP_TRY(dW.alloc((size_t)S * 8, cs.st)); HIP_TRY(hipMemcpyAsync(dW.p, W, (size_t)S * 8, hipMemcpyHostToDevice, cs.st)); }
+    HIP_TRY(hipMemsetAsync(dO.p, 0, nb * 8, cs.st));
     const double t0 = now_s();
     if (int rc = trpl_posterior_hist_dev(dx.as<double>(), y ? dy.as<double>() : nullptr, W ? dW.as<double>() : nullptr, S, xlo,
-                                         xhi, xbins, ylo, yhi, ybins, dO.as<double>(), nullptr))
+                                         xhi, xbins, ylo, yhi, ybins, dO.as<double>(), cs.st))
         return rc;
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(cs.st));
     if (seconds) *seconds = now_s() - t0;
-    HIP_TRY(hipMemcpy(out, dO.p, nb * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(out, dO.p, nb * 8, hipMemcpyDeviceToHost, cs.st));
+    HIP_TRY(hipStreamSynchronize(cs.st));        // the copies back have landed (and their errors surface here)
     return TRPL_OK;
 }
 
@@ -738,13 +780,16 @@ int trpl_sample_box(uint32_t seed, int64_t S, int32_t ncol, const double *lo, co
     if (S == 0) return TRPL_OK;
     if (!X) return fail(TRPL_ERR_ARG, "NULL pointer argument");
     if (int rc = select_device(device)) return rc;
+    CallScope cs;
+    HIP_TRY(cs.open());
     DevBuf dX;
-    HIP_TRY(dX.alloc((size_t)S * ncol * 8));
+    HIP_TRY(dX.alloc((size_t)S * ncol * 8, cs.st));
     const double t0 = now_s();
-    if (int rc = trpl_sample_box_dev(seed, S, ncol, lo, hi, do_log, flags, dX.as<double>(), nullptr)) return rc;
-    HIP_TRY(hipDeviceSynchronize());
+    if (int rc = trpl_sample_box_dev(seed, S, ncol, lo, hi, do_log, flags, dX.as<double>(), cs.st)) return rc;
+    HIP_TRY(hipStreamSynchronize(cs.st));
     if (seconds) *seconds = now_s() - t0;
-    HIP_TRY(hipMemcpy(X, dX.p, (size_t)S * ncol * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(X, dX.p, (size_t)S * ncol * 8, hipMemcpyDeviceToHost, cs.st));
+    HIP_TRY(hipStreamSynchronize(cs.st));        // the copies back have landed (and their errors surface here)
     return TRPL_OK;
 }
 
@@ -774,18 +819,21 @@ int trpl_pcr_solve_batched(const void *ld, const void *d, const void *ud, const 
     if (S == 0) return TRPL_OK;
     if (!ld || !d || !ud || !b || !x) return fail(TRPL_ERR_ARG, "NULL pointer argument");
     if (int rc = select_device(device)) return rc;
+    CallScope cs;
+    HIP_TRY(cs.open());
     const size_t n = (size_t)S * L * elem_bytes;
     DevBuf bl, bd, bu, bb, bx;
-    HIP_TRY(bl.alloc(n)); HIP_TRY(bd.alloc(n)); HIP_TRY(bu.alloc(n)); HIP_TRY(bb.alloc(n)); HIP_TRY(bx.alloc(n));
-    HIP_TRY(hipMemcpy(bl.p, ld, n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(bd.p, d, n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(bu.p, ud, n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(bb.p, b, n, hipMemcpyHostToDevice));
+    HIP_TRY(bl.alloc(n, cs.st)); HIP_TRY(bd.alloc(n, cs.st)); HIP_TRY(bu.alloc(n, cs.st)); HIP_TRY(bb.alloc(n, cs.st)); HIP_TRY(bx.alloc(n, cs.st));
+    HIP_TRY(hipMemcpyAsync(bl.p, ld, n, hipMemcpyHostToDevice, cs.st));
+    HIP_TRY(hipMemcpyAsync(bd.p, d, n, hipMemcpyHostToDevice, cs.st));
+    HIP_TRY(hipMemcpyAsync(bu.p, ud, n, hipMemcpyHostToDevice, cs.st));
+    HIP_TRY(hipMemcpyAsync(bb.p, b, n, hipMemcpyHostToDevice, cs.st));
     const double t0 = now_s();
-    if (int rc = trpl_pcr_solve_batched_dev(bl.p, bd.p, bu.p, bb.p, bx.p, S, L, elem_bytes, flags, nullptr)) return rc;
-    HIP_TRY(hipDeviceSynchronize());
+    if (int rc = trpl_pcr_solve_batched_dev(bl.p, bd.p, bu.p, bb.p, bx.p, S, L, elem_bytes, flags, cs.st)) return rc;
+    HIP_TRY(hipStreamSynchronize(cs.st));
     if (seconds) *seconds = now_s() - t0;
-    HIP_TRY(hipMemcpy(x, bx.p, n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(x, bx.p, n, hipMemcpyDeviceToHost, cs.st));
+    HIP_TRY(hipStreamSynchronize(cs.st));        // the copies back have landed (and their errors surface here)
     return TRPL_OK;
 }
 

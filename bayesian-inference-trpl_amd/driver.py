@@ -263,29 +263,53 @@ def simulate(model, e_data, P, X, plI, plI_int, num_curves, sim_params, init_par
                 solver_time[gpu_id] += info["seconds"]
         return
 
-    for ic_num in range(num_curves):
-        sim_params[0] = thicknesses[ic_num]                               # :119
+    # The reference walks curves -> blocks (:117,:131).  A sample only ever meets its own block, and every
+    # P[e, j] receives its curves in the same order either way, so the loops can be swapped: blocks outside,
+    # and -- when the model is this package's own (re-entrant: every call runs on a private stream) -- the
+    # block's curves solved concurrently from a few host threads, which is what fills the chip when the
+    # blocks are as small as the reference's default 1024 samples.
+    overlap = model is pvSim and bool(gpu_info.get("overlap_curves", True)) and num_curves > 1
+    ncol = T // sim_params[4] + 1
+
+    def solve_curve(ic_num, blk, size):
+        par = list(sim_params)
+        par[0] = thicknesses[ic_num]                                      # :119
+        buf = np.empty((size, ncol), dtype=pl_dtype)                      # :137
+        sec = model(buf, None, None, None, X[blk:blk + size, :-1], par, init_params[ic_num], None, None, 1,
+                    init_mode="points")
+        return buf, sec
+
+    pool = None
+    if overlap:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=min(num_curves, 8))
+    try:
         for blk in range(gpu_id * group, len(X), num_gpus * group):       # :131
-            if logger is not None:
-                logger.info("Curve #{}: Calculating {} of {}".format(ic_num, blk, len(X)))
             size = min(group, len(X) - blk)
-            plI[gpu_id] = np.empty((size, T // sim_params[4] + 1), dtype=pl_dtype)      # :137
-            solver_time[gpu_id] += model(plI[gpu_id], None, None, None, X[blk:blk + size, :-1], sim_params,
-                                         init_params[ic_num], None, None, 1, init_mode="points")
-            if NORMALIZE:                                                 # :150-154
-                plI[gpu_id] /= plI[gpu_id][:, :1].copy()
-            if LOG_PL:                                                    # :155-157
-                misc_time[gpu_id] += fastlog(plI[gpu_id], sys.float_info.min, device=device)
-            for e, exp in enumerate(e_data):                              # :168
-                times, values = np.asarray(exp[0][ic_num], dtype=float), exp[1][ic_num]
-                if almost_equal(sim_t, times):                            # :173,:182-183
-                    plI_int[gpu_id] = plI[gpu_id]
-                else:                                                     # :184-191
-                    clock0 = time.perf_counter()
-                    plI_int[gpu_id] = interp_rows(sim_t, plI[gpu_id], times)
-                    misc_time[gpu_id] += time.perf_counter() - clock0
-                err_sq_time[gpu_id] += prob(P[e, blk:blk + size], plI_int[gpu_id], values, None,
-                                            np.ascontiguousarray(X[blk:blk + size, -1]), device=device)
+            if logger is not None:
+                logger.info("Calculating {} of {}".format(blk, len(X)))
+            pending = [pool.submit(solve_curve, c, blk, size) for c in range(num_curves)] if overlap else None
+            for ic_num in range(num_curves):                              # :117
+                sim_params[0] = thicknesses[ic_num]                       # :119 (the caller's list is mutated, as there)
+                plI[gpu_id], sec = pending[ic_num].result() if overlap else solve_curve(ic_num, blk, size)
+                solver_time[gpu_id] += sec
+                if NORMALIZE:                                             # :150-154
+                    plI[gpu_id] /= plI[gpu_id][:, :1].copy()
+                if LOG_PL:                                                # :155-157
+                    misc_time[gpu_id] += fastlog(plI[gpu_id], sys.float_info.min, device=device)
+                for e, exp in enumerate(e_data):                          # :168
+                    times, values = np.asarray(exp[0][ic_num], dtype=float), exp[1][ic_num]
+                    if almost_equal(sim_t, times):                        # :173,:182-183
+                        plI_int[gpu_id] = plI[gpu_id]
+                    else:                                                 # :184-191
+                        clock0 = time.perf_counter()
+                        plI_int[gpu_id] = interp_rows(sim_t, plI[gpu_id], times)
+                        misc_time[gpu_id] += time.perf_counter() - clock0
+                    err_sq_time[gpu_id] += prob(P[e, blk:blk + size], plI_int[gpu_id], values, None,
+                                                np.ascontiguousarray(X[blk:blk + size, -1]), device=device)
+    finally:
+        if pool is not None:
+            pool.shutdown(wait=True)
 
 
 def bayes(model, N, P, minX, maxX, do_log, init_params, sim_params, e_data, sim_flags, gpu_info, logger=None,

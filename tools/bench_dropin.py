@@ -15,11 +15,12 @@ mark = (wl.MARKED_POINT * tp.UNIT_CONVERSIONS)[None, :-1]
 obs = [np.log10(tp.solve_pl(mark, lens[c], Time, L, T, ini[c], strict=True)[0][0][:n_obs]) for c in range(3)]
 e_data = [([sim_t[:n_obs]] * 3, obs, [None] * 3)]
 flags = {"load_PL_from_file": False, "log_pl": True, "self_normalize": False}
-for fused in (False, True):
+for name, fused, overlap in (("unfused, one curve at a time", False, False), ("unfused, curves overlapped ", False, True),
+                             ("fused                      ", True, True)):
     P = np.zeros((1, S)); st, et, mt = np.zeros(1), np.zeros(1), np.zeros(1)
     t0 = time.perf_counter()
     tp.simulate(tp.pvSim, e_data, P, X, [None], [None], 3, [2000.0, Time, L, T, 1, (0,), 7, 10000], ini, flags,
-                {"sims_per_gpu": 1024, "num_gpus": 1, "fused": fused}, 0, st, et, mt)
+                {"sims_per_gpu": 1024, "num_gpus": 1, "fused": fused, "overlap_curves": overlap}, 0, st, et, mt)
     dt = time.perf_counter() - t0
-    print(f"{'fused  ' if fused else 'unfused'} T={T}: wall {dt:.3f} s  (solver {st[0]:.3f} s, fastlog+interp {mt[0]:.3f} s, prob {et[0]:.3f} s)"
+    print(f"{name} T={T}: wall {dt:.3f} s  (solver {st[0]:.3f} s, fastlog+interp {mt[0]:.3f} s, prob {et[0]:.3f} s)"
           f"  -> {S * 3 * (T + 1) / dt:.3e} system-timesteps/s incl. PCIe and host work;  P[0]={P[0,0]:.6f}")
