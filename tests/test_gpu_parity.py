@@ -792,3 +792,36 @@ def test_fused_call_limits_sixteen_curves_and_strided_pl(trpl, gpu):
         pf = trpl.loglik(X2, base, lens3, T2 * 0.025, L, T2, obs4, plT=4, info=fi)
         ps = trpl.loglik(X2, base, lens3, T2 * 0.025, L, T2, obs4, plT=4, info=si, strict=True)
         assert np.array_equal(fi["iters_total"], si["iters_total"]) and np.allclose(pf, ps, rtol=1e-9, atol=0)
+
+
+def test_host_calls_from_several_threads_overlap_and_agree(trpl, gpu):
+    """Host-buffer entry points are re-entrant (private stream, stream-ordered allocations, thread-local
+    error string): eight threads solving different curves / sample sets at once return exactly what
+    the same calls return one after the other, and an error in one thread stays in that thread."""
+    from concurrent.futures import ThreadPoolExecutor
+    ini, lengths = trpl.workloads.power_scan(128)
+    jobs = [(trpl.workloads.samples(200 + 17 * k, seed=30 + k)[:, :12], k % 3) for k in range(8)]
+
+    def run(job):
+        X, c = job
+        pl, st, it, _ = trpl.solve_pl(X, lengths[c], 2.0, 128, 80, ini[c])
+        lp = np.log10(np.maximum(pl, 1e-300))
+        trpl.fastlog(pl, 1e-300)
+        return pl, lp, st, it
+
+    serial = [run(j) for j in jobs]
+    with ThreadPoolExecutor(max_workers=8) as pool:
+        threaded = list(pool.map(run, jobs))
+    for a, b in zip(serial, threaded):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+        assert np.allclose(a[0], a[1], rtol=1e-15, atol=0)
+
+    def bad(_):
+        try:
+            trpl.solve_pl(jobs[0][0], lengths[0], 2.0, 100, 80, ini[0][:100])       # L not a power of two
+        except trpl.TrplError as e:
+            return str(e)
+        return None
+    with ThreadPoolExecutor(max_workers=2) as pool:
+        msgs = list(pool.map(bad, range(4))) + [r[0].shape for r in pool.map(run, jobs[:2])]
+    assert all(isinstance(m, str) and "power of two" in m for m in msgs[:4])
