@@ -33,7 +33,7 @@
 #define TRPL_PCR_S1_LDS 0         // stride-1 level of the 64-unknown PCR: 0 = DPP rotates, 1 = staged through LDS
 #endif
 #ifndef TRPL_PCR_SETPRIO
-#define TRPL_PCR_SETPRIO 2        // s_setprio level inside the cross-lane PCR levels of the paired kernel (0 = off)
+#define TRPL_PCR_SETPRIO 2        // s_setprio level inside the cross-lane PCR levels (0 = off)
 #endif
 #ifndef TRPL_RCP_PAIR
 #define TRPL_RCP_PAIR 1       // pair reciprocals (rcp_rows); 0 only for A/B measurements

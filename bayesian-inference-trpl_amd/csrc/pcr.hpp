@@ -488,8 +488,9 @@ __device__ __forceinline__ void cr_pcr_solve(T (&ld)[NR], T (&d)[NR], T (&ud)[NR
     T A = ld[0], D = d[0], C = ud[0], Bv = B[0];
     // the cross-lane levels are one long dependent chain (reciprocal -> normalise -> exchange -> eliminate):
     // a wave inside it is issued ahead of its SIMD neighbour, which then fills the gaps with its assembly
-    // (+0.6..0.8 % on the paired kernel, same-box A/B; priority over the whole solve: +0.1 %)
-    if constexpr (TRPL_PCR_SETPRIO > 0 && WS == 32) __builtin_amdgcn_s_setprio(TRPL_PCR_SETPRIO);
+    // (+0.6..0.8 % on the paired kernel, +1.2 % on the one-system kernel, same-box A/B; priority over the
+    // whole solve: +0.1 %)
+    if constexpr (TRPL_PCR_SETPRIO > 0) __builtin_amdgcn_s_setprio(TRPL_PCR_SETPRIO);
     pcr64_levels<T, 1, WS, ISO, XM>(A, D, C, Bv, lane, xch);
     const bool low = (lane & (WS / 2)) == 0;       // pairs by Cramer's rule, own unknown only
     const T c_own = low ? C : A;
@@ -505,7 +506,7 @@ __device__ __forceinline__ void cr_pcr_solve(T (&ld)[NR], T (&d)[NR], T (&ud)[NR
     }
     const T X = (Bv * D_oth - c_own * B_oth) * rcp_fast<T>(D * D_oth - c_own * c_oth);
     x[0] = X;
-    if constexpr (TRPL_PCR_SETPRIO > 0 && WS == 32) __builtin_amdgcn_s_setprio(0);
+    if constexpr (TRPL_PCR_SETPRIO > 0) __builtin_amdgcn_s_setprio(0);
     T xnext;                                       // a system's last lane: times c^ = 0
     if constexpr ((XM & 4) != 0) xnext = rot32_up<1>(X);
     else xnext = seam_last<ISO, WS>(lane_up<1>(X, lane), lane);
