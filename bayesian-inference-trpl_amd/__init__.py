@@ -6,7 +6,9 @@ The directory name carries hyphens, so import it through the repo-root alias `tr
 (include/trpl.h); there is no CPU fallback.
 """
 from . import _abi  # noqa: F401
-from ._abi import FLAG_FP32, FLAG_NORMALIZE, FLAG_PL_F32, FLAG_STRICT, TrplError  # noqa: F401
+_abi.ensure_built()            # a fresh checkout builds here, before this process can have touched the GPU
+from ._abi import (FLAG_FP32, FLAG_KERNEL_PAIR, FLAG_KERNEL_SINGLE, FLAG_NORMALIZE, FLAG_PL_F32, FLAG_STRICT,  # noqa: F401
+                   TrplError)
 from . import dataio, device, dist, posterior, workloads  # noqa: F401
 from .dataio import export, get_data, get_initpoints  # noqa: F401
 from .driver import almost_equal, bayes, bracket_times, interp_rows, is_grid_prefix, loglik, simulate  # noqa: F401

@@ -15,7 +15,10 @@ LIB_PATH = os.environ.get("TRPL_LIBRARY", os.path.join(_HERE, "libtrpl_hip.so"))
 # status codes / flags (include/trpl.h)
 OK, ERR_ARG, ERR_HIP, ERR_NODEVICE, ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 FLAG_STRICT, FLAG_PL_F32, FLAG_NORMALIZE, FLAG_FP32 = 0x1, 0x2, 0x4, 0x8
+FLAG_KERNEL_PAIR, FLAG_KERNEL_SINGLE = 0x10, 0x20
 KERNEL_FAST, KERNEL_FAST_PAIR, KERNEL_STRICT, KERNEL_FP32 = 0, 1, 2, 3
+ABI_VERSION = 2
+MAX_SNAPS = 16
 
 
 class TrplError(RuntimeError):
@@ -36,6 +39,10 @@ SIGNATURES = {
                       _i32, _pd],
     "trpl_solve_pl_dev": [_vp, _i64, _f64, _f64, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _i64, _vp, _vp,
                           _u32, _vp],
+    "trpl_solve_pl_snap": [_vp, _i64, _f64, _f64, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _i64, _vp, _vp, _vp,
+                           _i32, _vp, _vp, _vp, _u32, _i32, _pd],
+    "trpl_solve_pl_snap_dev": [_vp, _i64, _f64, _f64, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _i64, _vp, _vp,
+                               _vp, _i32, _vp, _vp, _vp, _u32, _vp],
     "trpl_log10_clamp": [_vp, _i32, _i64, _i64, _i64, _f64, _i32, _pd],
     "trpl_log10_clamp_dev": [_vp, _i32, _i64, _i64, _i64, _f64, _vp],
     "trpl_sse_accumulate": [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _vp, _i32, _pd],
@@ -51,7 +58,14 @@ SIGNATURES = {
     "trpl_loglik_from_pl_dev": [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _u32, _vp],
     "trpl_loglik_multi": [_vp, _i64, _i32, _vp, _f64, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64,
                           _vp, _vp, _vp, _vp, _vp, _u32, _vp, _i32, _pd],
+    "trpl_multi_create": [_vp, _i32, _vp],
+    "trpl_multi_destroy": [_vp],
+    "trpl_multi_device_count": [_vp],
+    "trpl_multi_synchronize": [_vp],
+    "trpl_loglik_multi_dev": [_vp, _vp, _i64, _i32, _vp, _f64, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp,
+                              _i64, _vp, _vp, _vp, _vp, _vp, _u32],
     "trpl_shard_bounds": [_i64, _i32, _i32, _vp, _vp],
+    "trpl_shard_of": [_i64, _i32, _i64],
     "trpl_kernel_variant": [_i64, _i32, _i64, _u32],
     "trpl_sample_box": [_u32, _i64, _i32, _vp, _vp, _vp, _u32, _vp, _i32, _pd],
     "trpl_sample_box_dev": [_u32, _i64, _i32, _vp, _vp, _vp, _u32, _vp, _vp],
@@ -72,13 +86,31 @@ _lib = None
 def _build_if_missing():
     """A fresh checkout has no shared object (it is git-ignored): build the HIP library in-tree with
     the package Makefile when hipcc is present.  This is a build step, not a fallback -- the result
-    is the same gfx950 library; set TRPL_AUTOBUILD=0 to forbid it."""
+    is the same gfx950 library; set TRPL_AUTOBUILD=0 to forbid it.
+
+    Under torch.distributed.run every rank of a fresh checkout arrives here at once: the build is
+    serialised with an exclusive lock file and re-checked under the lock, and the Makefile links under
+    a temporary name and renames, so no rank ever loads a half-written library."""
+    import fcntl
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if os.path.isfile("/opt/rocm/bin/hipcc") else None)
     if os.environ.get("TRPL_AUTOBUILD", "1") == "0" or hipcc is None or "TRPL_LIBRARY" in os.environ:
         return
-    subprocess.check_call(["make", "-s", "-j4", "-C", _HERE, "libtrpl_hip.so", "HIPCC=" + hipcc])
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not os.path.isfile(LIB_PATH):                       # another process may have built it meanwhile
+                subprocess.check_call(["make", "-s", "-j4", "-C", _HERE, "libtrpl_hip.so", "HIPCC=" + hipcc])
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def ensure_built():
+    """Build the library if it is missing (called when the package is imported, i.e. before anything in
+    this process has touched the GPU)."""
+    if not os.path.isfile(LIB_PATH):
+        _build_if_missing()
 
 
 def lib():
@@ -91,11 +123,15 @@ def lib():
             raise ImportError("%s not found: build it with `make -C %s` (hipcc, gfx950); "
                               "there is no CPU fallback" % (LIB_PATH, _HERE))
         dll = C.CDLL(LIB_PATH)
+        dll.trpl_abi_version.restype = C.c_int
+        if dll.trpl_abi_version() != ABI_VERSION:
+            raise ImportError("%s has ABI version %d, this binding needs %d: rebuild it (`make -C %s`)"
+                              % (LIB_PATH, dll.trpl_abi_version(), ABI_VERSION, _HERE))
         for name, argtypes in SIGNATURES.items():
             fn = getattr(dll, name)
             fn.argtypes = argtypes
             fn.restype = C.c_char_p if name == "trpl_last_error" else (
-                C.c_int64 if name == "trpl_posterior_workspace_bytes" else C.c_int)
+                C.c_int64 if name in ("trpl_posterior_workspace_bytes", "trpl_shard_of") else C.c_int)
         _lib = dll
     return _lib
 
@@ -105,10 +141,32 @@ def check(rc):
         raise TrplError(rc, lib().trpl_last_error().decode("utf-8", "replace"))
 
 
+def kernel_flag(kernel):
+    """TRPL_FLAG_KERNEL_* bit for kernel = None (library's choice) | "pair" | "single"."""
+    if kernel is None:
+        return 0
+    try:
+        return {"pair": FLAG_KERNEL_PAIR, "single": FLAG_KERNEL_SINGLE}[kernel]
+    except KeyError:
+        raise ValueError("kernel must be None, 'pair' or 'single', got %r" % (kernel,))
+
+
+def pin_variant(flags, nsys_total, L, steps):
+    """`flags` with the stepper variant of a LOGICAL batch of nsys_total systems pinned, for callers that cut
+    the batch into several launches (sample shards over ranks, blocks): every launch then runs the kernel the
+    whole batch would, and a sample's bits do not depend on the cut (include/trpl.h, TRPL_FLAG_KERNEL_*)."""
+    if flags & (FLAG_KERNEL_PAIR | FLAG_KERNEL_SINGLE):
+        return flags
+    v = lib().trpl_kernel_variant(int(nsys_total), int(L), int(steps), int(flags))
+    return flags | {KERNEL_FAST_PAIR: FLAG_KERNEL_PAIR, KERNEL_FAST: FLAG_KERNEL_SINGLE}.get(v, 0)
+
+
 def ptr(a):
     """Address of a numpy array / int device pointer / None."""
     if a is None:
         return None
     if isinstance(a, np.ndarray):
         return a.ctypes.data
+    if isinstance(a, C.Array):
+        return C.addressof(a)
     return int(a)

@@ -246,6 +246,55 @@ struct PlSink {
     }
 };
 
+// State snapshots (the reference's debug outputs plN / plP / plE: pvSimPCR.py:283-288 (disabled
+// there), working form Legacy/pvSim.py:121-126): the state of time step snap_t[i] -- level k, the state
+// PL(t) is computed from -- goes to slot snap_slot[i], re-dimensionalised like Legacy/pvSim.py:169-171
+// (N, P / dx^3, E / dx; E on the L + 1 edges, E_0 = E_L = 0).  One system's lanes call take(); `row` and
+// `live` may differ between the halves of a wavefront that holds two systems.
+struct SnapSink {
+    const StepArgs &a;
+    const CurveConst &cc;
+    int next = 0;
+    __device__ SnapSink(const StepArgs &a_, const CurveConst &cc_) : a(a_), cc(cc_) {}
+    __device__ __forceinline__ bool due(int64_t t) const { return next < a.n_snap && t == (int64_t)a.snap_t[next]; }
+
+    // node(j) = node index of this lane's row j
+    template <int NR, int L, typename NodeOf>
+    __device__ __forceinline__ void take(const double (&N)[NR], const double (&P)[NR], const double (&E)[NR],
+                                         int64_t row, bool live, NodeOf node)
+    {
+        const int64_t at = row * a.snap_ld + a.snap_slot[next];
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                const int i = node(j);
+                if (a.snapN) a.snapN[at * L + i] = N[j] / cc.dx3;
+                if (a.snapP) a.snapP[at * L + i] = P[j] / cc.dx3;
+                if (a.snapE) {
+                    a.snapE[at * (L + 1) + i] = E[j] / cc.dx;
+                    if (i == L - 1) a.snapE[at * (L + 1) + L] = 0.0;            // E_L is never written (:205)
+                }
+            }
+        }
+        next++;
+    }
+
+    // a system flagged at step status-1 (pvSimPCR.py:269): its snapshots from that step on are NaN, like its PL
+    template <int L>
+    __device__ __forceinline__ void fail_fill(int64_t row, int status, int lane_in_sys, int lanes)
+    {
+        for (int i = 0; i < a.n_snap; i++) {
+            if ((int64_t)a.snap_t[i] < (int64_t)status - 1) continue;
+            const int64_t at = row * a.snap_ld + a.snap_slot[i];
+            for (int n = lane_in_sys; n <= L; n += lanes) {
+                if (n < L && a.snapN) a.snapN[at * L + n] = __builtin_nan("");
+                if (n < L && a.snapP) a.snapP[at * L + n] = __builtin_nan("");
+                if (a.snapE) a.snapE[at * (L + 1) + n] = __builtin_nan("");
+            }
+        }
+    }
+};
+
 // the 12 non-dimensional material parameters of one system (wave-uniform) + N0*P0
 struct MatPar {
     double N0, P0, DN, DP, rate, sr0, srL, CN, CP, tauN, tauP, Lambda, n0p0;
@@ -381,7 +430,7 @@ __device__ __forceinline__ void update_field(const MatPar &m, double a0, const d
     }
 }
 
-template <int L, bool STRICT>
+template <int L, bool STRICT, bool SNAP = false>
 __global__ void __launch_bounds__(64, (STRICT || L > 128) ? (L > 256 ? 1 : 2) : TRPL_FAST_WAVES) stepper_kernel(const StepArgs a)
 {
     constexpr int W = L < 64 ? L : 64;
@@ -435,10 +484,16 @@ __global__ void __launch_bounds__(64, (STRICT || L > 128) ? (L > 256 ? 1 : 2) : 
     }
 
     PlSink sink(a, cc, c, s, mag);
+    SnapSink snap(a, cc);
     int status = 0;
     int64_t itot = 0;
 
     for (int64_t t = 0; t <= sink.t_last; t++) {   // tEvol, pvSimPCR.py:237
+        if constexpr (SNAP) {                      // the state at time t, before it is stepped (:283-288)
+            if (snap.due(t))
+                snap.template take<NR, L>(Nk, Pk, Ek, sink.orow, (int)threadIdx.x < W,
+                                          [&](int j) { return node_of<LAY, NR, W>(ln, j); });
+        }
         double a0, a1, a2, a3, a4, a5;             // :241-250
         if (t == 0)      { a0 = 1.0; a1 = -1.0; a2 = 0.0; a3 = 0.0; a4 = 0.0; a5 = 0.0; }
         else if (t == 1) { a0 = 1.5; a1 = -2.0; a2 = 0.5; a3 = 0.0; a4 = 0.0; a5 = 0.0; }
@@ -538,6 +593,9 @@ __global__ void __launch_bounds__(64, (STRICT || L > 128) ? (L > 256 ? 1 : 2) : 
         const int64_t done = status ? (int64_t)(status - 1) : sink.t_last + 1;      // steps whose PL was emitted
         sink.flush_batch((int)((done + a.plT - 1) / a.plT - sink.base));
     }
+    if constexpr (SNAP) {
+        if (status) snap.template fail_fill<L>(sink.orow, status, threadIdx.x, 64);
+    }
     sink.finish(status, itot);
 }
 
@@ -549,9 +607,13 @@ hipError_t launch_stepper(const StepArgs &a, hipStream_t stream)
     dim3 grid((unsigned)nsys), block(64);
     // development knob: extra dynamic LDS per workgroup lowers the number of resident waves
     static const unsigned lds_pad = getenv("TRPL_LDS_PAD") ? (unsigned)atoi(getenv("TRPL_LDS_PAD")) : 0u;
+    const bool snap = a.n_snap > 0;                // the snapshot code only exists in its own instantiation
     switch (a.L) {
 #define TRPL_CASE(LL) \
-    case LL: hipLaunchKernelGGL((stepper_kernel<LL, STRICT>), grid, block, lds_pad, stream, a); break;
+    case LL: \
+        if (snap) hipLaunchKernelGGL((stepper_kernel<LL, STRICT, true>), grid, block, lds_pad, stream, a); \
+        else      hipLaunchKernelGGL((stepper_kernel<LL, STRICT, false>), grid, block, lds_pad, stream, a); \
+        break;
         TRPL_CASE(4) TRPL_CASE(8) TRPL_CASE(16) TRPL_CASE(32) TRPL_CASE(64) TRPL_CASE(128)
         TRPL_CASE(256) TRPL_CASE(512)
 #undef TRPL_CASE

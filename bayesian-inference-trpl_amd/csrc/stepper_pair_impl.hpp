@@ -94,7 +94,7 @@ __device__ __forceinline__ void update_field2(const MatPar &m, double a0, const 
     for (int j = 1; j < NR; j++) Ek[j] = act ? b[j] * rA[j] : Ek[j];
 }
 
-template <bool ISO, int XM>
+template <bool ISO, int XM, bool SNAP = false>
 __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
 {
     constexpr int LAY = 2;
@@ -150,9 +150,15 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
     int statusA = 0, statusB = 0;
     bool deadA = false, deadB = !validB;            // dead: flagged non-converged (or the odd tail's duplicate)
     int64_t itotA = 0, itotB = 0;
+    SnapSink snap(a, cc);
 
     for (int64_t t = 0; t <= sinkA.t_last; t++) {   // tEvol, pvSimPCR.py:237
         if (deadA && deadB) break;
+        if constexpr (SNAP) {                       // the state at time t, before it is stepped (:283-288)
+            if (snap.due(t))
+                snap.template take<NR, L>(Nk, Pk, Ek, hi ? sinkB.orow : sinkA.orow, hi ? !deadB : !deadA,
+                                          [&](int j) { return NR * ln + j; });
+        }
         double a0, a1, a2, a3, a4, a5;              // :241-250
         if (t == 0)      { a0 = 1.0; a1 = -1.0; a2 = 0.0; a3 = 0.0; a4 = 0.0; a5 = 0.0; }
         else if (t == 1) { a0 = 1.5; a1 = -2.0; a2 = 0.5; a3 = 0.0; a4 = 0.0; a5 = 0.0; }
@@ -258,6 +264,10 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
         sinkA.flush_batch((int)((doneA_ + a.plT - 1) / a.plT - sinkA.base));
         if (validB) sinkB.flush_batch((int)((doneB_ + a.plT - 1) / a.plT - sinkB.base));
     }
+    if constexpr (SNAP) {
+        if (statusA && !hi) snap.template fail_fill<L>(sinkA.orow, statusA, ln, WS);
+        if (statusB && hi && validB) snap.template fail_fill<L>(sinkB.orow, statusB, ln, WS);
+    }
     sinkA.finish(statusA, itotA);
     if (validB) sinkB.finish(statusB, itotB);
 }
@@ -270,7 +280,8 @@ hipError_t launch_stepper_pair_t(const StepArgs &a, hipStream_t stream)
     if (a.L != pair::L) return hipErrorInvalidValue;
     const int64_t nblk = ((a.S + 1) / 2) * a.C;
     if (nblk <= 0) return hipSuccess;
-    hipLaunchKernelGGL((pair::stepper_pair_kernel<ISO, XM>), dim3((unsigned)nblk), dim3(64), 0, stream, a);
+    if (a.n_snap > 0) hipLaunchKernelGGL((pair::stepper_pair_kernel<ISO, XM, true>), dim3((unsigned)nblk), dim3(64), 0, stream, a);
+    else              hipLaunchKernelGGL((pair::stepper_pair_kernel<ISO, XM, false>), dim3((unsigned)nblk), dim3(64), 0, stream, a);
     return hipGetLastError();
 }
 

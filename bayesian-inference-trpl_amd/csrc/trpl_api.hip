@@ -12,14 +12,13 @@
 #include <chrono>
 #include <vector>
 
-#include "../../include/trpl.h"
-#include "trpl_common.hpp"
+#include "api_util.hpp"
 
-namespace {
+namespace trpl {
 
-thread_local char g_err[512] = "";
+namespace { thread_local char g_err[512] = ""; }
 
-int fail(int code, const char *fmt, ...)
+int api_fail(int code, const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
@@ -28,13 +27,42 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess) return fail(TRPL_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));   \
-    } while (0)
+int check_grid(int32_t L, int64_t T, int32_t plT, int32_t max_iter, double time_ns)
+{
+    if (!pow2(L) || L < 4 || L > 512) return api_fail(TRPL_ERR_ARG, "L=%d must be a power of two in [4, 512]", L);
+    if (T < 1) return api_fail(TRPL_ERR_ARG, "T=%lld must be >= 1", (long long)T);
+    if (T > 0x7ffffff0LL) return api_fail(TRPL_ERR_ARG, "T=%lld is too large", (long long)T);
+    if (plT < 1) return api_fail(TRPL_ERR_ARG, "plT=%d must be >= 1", plT);
+    if (max_iter < 1) return api_fail(TRPL_ERR_ARG, "max_iter=%d must be >= 1", max_iter);
+    if (!(time_ns > 0)) return api_fail(TRPL_ERR_ARG, "time_ns must be > 0");
+    return TRPL_OK;
+}
 
-bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+int check_brackets(const int32_t *obs_hi, const double *obs_dx, const double *obs_h, int32_t C, int64_t obs_ld,
+                   const int64_t *n_obs, int64_t T)
+{
+    for (int c = 0; c < C; c++)
+        for (int64_t i = 0; i < n_obs[c] && i < obs_ld; i++) {
+            const int64_t at = (int64_t)c * obs_ld + i;
+            const int32_t h = obs_hi[at];
+            if (h < 1 || h > T || (i && h < obs_hi[at - 1]))
+                return api_fail(TRPL_ERR_ARG, "obs_hi[%d][%lld]=%d must be sorted and in [1, T]", c, (long long)i, h);
+            if (!(obs_h[at] > 0) || !(obs_dx[at] >= 0) || !(obs_dx[at] <= obs_h[at]))
+                return api_fail(TRPL_ERR_ARG, "observation %lld of curve %d: need 0 <= obs_dx <= obs_h and obs_h > 0",
+                                (long long)i, c);
+        }
+    return TRPL_OK;
+}
+
+int64_t loglik_steps(bool interp, int32_t C, const int64_t *n_obs, int32_t plT, int64_t T)
+{
+    if (interp) return T;                            // the kernel stops at the last observation (PlSink::t_last)
+    int64_t steps = 0;
+    for (int c = 0; c < C; c++) steps = std::max<int64_t>(steps, (n_obs[c] - 1) * (int64_t)plT);
+    return steps;
+}
+
+namespace {
 
 // pvSim's non-dimensionalisation (pvSimPCR.py:314-331, :393).  Python's float `**` is C pow().
 void curve_const(double length, double time_ns, int L, int64_t T, trpl::CurveConst &cc)
@@ -46,17 +74,8 @@ void curve_const(double length, double time_ns, int L, int64_t T, trpl::CurveCon
     memcpy(cc.scales, s, sizeof s);
     cc.dx3 = dx3;
     cc.plnorm = pow(dx, 2.0) * dt;
+    cc.dx = dx;
     cc.n_obs = 0;
-}
-
-int check_grid(int32_t L, int64_t T, int32_t plT, int32_t max_iter, double time_ns)
-{
-    if (!pow2(L) || L < 4 || L > 512) return fail(TRPL_ERR_ARG, "L=%d must be a power of two in [4, 512]", L);
-    if (T < 1) return fail(TRPL_ERR_ARG, "T=%lld must be >= 1", (long long)T);
-    if (plT < 1) return fail(TRPL_ERR_ARG, "plT=%d must be >= 1", plT);
-    if (max_iter < 1) return fail(TRPL_ERR_ARG, "max_iter=%d must be >= 1", max_iter);
-    if (!(time_ns > 0)) return fail(TRPL_ERR_ARG, "time_ns must be > 0");
-    return TRPL_OK;
 }
 
 // FAST, L = 128 has two kernels: one system per wavefront (3 waves per SIMD: 12 systems per CU in
@@ -66,8 +85,8 @@ int check_grid(int32_t L, int64_t T, int32_t plT, int32_t max_iter, double time_
 // than the one-system kernel holds at once, and -- for short windows, where the first time steps' 20-900
 // inner iterations make the work per system very uneven -- at least five such fills.  Measured crossover
 // (MI355X, Power_scan): `steps` = 8000: paired wins from 4 098 systems (+9 %); 1000: from ~15 000.
-// TRPL_PAIR=0 / 1 forces never / always (measurements; a system's result does not depend on its
-// partner, but the two kernels associate their node sums differently, ~1e-16 relative).
+// TRPL_FLAG_KERNEL_PAIR / _SINGLE force the choice per call; the environment variable TRPL_PAIR=0 / 1
+// forces it for a whole process (measurements only; the flags win).
 bool use_pair_kernel(int64_t nsys, int64_t steps)
 {
     static const int forced = getenv("TRPL_PAIR") ? atoi(getenv("TRPL_PAIR")) : -1;
@@ -86,17 +105,62 @@ bool use_pair_kernel(int64_t nsys, int64_t steps)
     return nsys > fill && (steps >= 4000 || nsys >= 5 * fill);
 }
 
+constexpr uint32_t kVariantBits = TRPL_FLAG_KERNEL_PAIR | TRPL_FLAG_KERNEL_SINGLE;
+
+}  // namespace
+
+int check_variant_flags(uint32_t flags, int32_t L)
+{
+    if ((flags & kVariantBits) == kVariantBits)
+        return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_KERNEL_PAIR and TRPL_FLAG_KERNEL_SINGLE exclude each other");
+    if ((flags & TRPL_FLAG_KERNEL_PAIR) && (L != 128 || (flags & (TRPL_FLAG_STRICT | TRPL_FLAG_FP32))))
+        return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_KERNEL_PAIR needs L = 128 (got %d) without TRPL_FLAG_STRICT / TRPL_FLAG_FP32", L);
+    return TRPL_OK;
+}
+
+bool pick_pair_kernel(int64_t nsys, int32_t L, int64_t steps, uint32_t flags)
+{
+    if (L != 128 || (flags & (TRPL_FLAG_STRICT | TRPL_FLAG_FP32))) return false;
+    if (flags & TRPL_FLAG_KERNEL_PAIR) return true;
+    if (flags & TRPL_FLAG_KERNEL_SINGLE) return false;
+    return use_pair_kernel(nsys, steps);
+}
+
+uint32_t pin_variant(uint32_t flags, int64_t nsys, int32_t L, int64_t steps)
+{
+    if (flags & kVariantBits) return flags;
+    return flags | (pick_pair_kernel(nsys, L, steps, flags) ? TRPL_FLAG_KERNEL_PAIR : TRPL_FLAG_KERNEL_SINGLE);
+}
+
+int select_device(int32_t device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return api_fail(TRPL_ERR_NODEVICE, "no HIP device visible");
+    if (device < 0 || device >= n) return api_fail(TRPL_ERR_ARG, "device %d out of range (%d visible)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    return TRPL_OK;
+}
+
+}  // namespace trpl
+
+using namespace trpl;
+#define fail api_fail
+
+namespace {
+
 // steps: how many time steps the launch will take (T, or up to the last observation in likelihood mode)
 int launch(const trpl::StepArgs &a, uint32_t flags, hipStream_t st, int64_t steps)
 {
+    if (int rc = check_variant_flags(flags, a.L)) return rc;
     if (flags & TRPL_FLAG_FP32) {
         if (flags & TRPL_FLAG_STRICT) return fail(TRPL_ERR_ARG, "TRPL_FLAG_FP32 and TRPL_FLAG_STRICT exclude each other");
         if (a.L < 128) return fail(TRPL_ERR_UNSUPPORTED, "the fp32 stepper is built for L >= 128 (got %d)", a.L);
+        if (a.n_snap > 0) return fail(TRPL_ERR_UNSUPPORTED, "state snapshots are not available with TRPL_FLAG_FP32");
         hipError_t e32 = trpl::launch_stepper_f32(a, st);
         if (e32 != hipSuccess) return fail(TRPL_ERR_HIP, "fp32 stepper launch: %s", hipGetErrorString(e32));
         return TRPL_OK;
     }
-    if (!(flags & TRPL_FLAG_STRICT) && a.L == 128 && use_pair_kernel(a.S * a.C, steps)) {
+    if (pick_pair_kernel(a.S * a.C, a.L, steps, flags)) {
         hipError_t ep = trpl::launch_stepper_pair(a, st);
         if (ep != hipSuccess) return fail(TRPL_ERR_HIP, "pair stepper launch: %s", hipGetErrorString(ep));
         return TRPL_OK;
@@ -104,44 +168,6 @@ int launch(const trpl::StepArgs &a, uint32_t flags, hipStream_t st, int64_t step
     hipError_t e = (flags & TRPL_FLAG_STRICT) ? trpl::launch_stepper_strict(a, st) : trpl::launch_stepper_fast(a, st);
     if (e != hipSuccess) return fail(TRPL_ERR_HIP, "stepper launch: %s", hipGetErrorString(e));
     return TRPL_OK;
-}
-
-// Every host-buffer call works on a private non-blocking stream with stream-ordered allocations, so
-// that calls issued from different host threads (or for different devices) overlap on the GPU: nothing
-// here synchronises the whole device.  Declare the CallScope before the DevBufs of a call: the buffers
-// are released (hipFreeAsync) first, then the scope drains and destroys the stream.
-struct CallScope {
-    hipStream_t st = nullptr;
-    hipError_t open() { return hipStreamCreateWithFlags(&st, hipStreamNonBlocking); }
-    ~CallScope()
-    {
-        if (st) {
-            (void)hipStreamSynchronize(st);
-            (void)hipStreamDestroy(st);
-        }
-    }
-};
-struct DevBuf {                      // RAII device allocation for the host-buffer calls
-    void *p = nullptr;
-    hipStream_t st = nullptr;
-    void release() { if (p) (void)hipFreeAsync(p, st); p = nullptr; }
-    ~DevBuf() { release(); }
-    hipError_t alloc(size_t n, hipStream_t s) { st = s; return hipMallocAsync(&p, n ? n : 1, s); }
-    template <typename T> T *as() { return (T *)p; }
-};
-
-int select_device(int32_t device)
-{
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(TRPL_ERR_NODEVICE, "no HIP device visible");
-    if (device < 0 || device >= n) return fail(TRPL_ERR_ARG, "device %d out of range (%d visible)", device, n);
-    HIP_TRY(hipSetDevice(device));
-    return TRPL_OK;
-}
-
-double now_s()
-{
-    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
 }  // namespace
@@ -155,7 +181,7 @@ int trpl_kernel_variant(int64_t nsys, int32_t L, int64_t steps, uint32_t flags)
 {
     if (flags & TRPL_FLAG_FP32) return TRPL_KERNEL_FP32;
     if (flags & TRPL_FLAG_STRICT) return TRPL_KERNEL_STRICT;
-    return (L == 128 && use_pair_kernel(nsys, steps)) ? TRPL_KERNEL_FAST_PAIR : TRPL_KERNEL_FAST;
+    return pick_pair_kernel(nsys, L, steps, flags) ? TRPL_KERNEL_FAST_PAIR : TRPL_KERNEL_FAST;
 }
 
 int trpl_device_count(void)
@@ -166,13 +192,16 @@ int trpl_device_count(void)
 }
 
 /* ------------------------------------------------------------------ solve_pl ------------ */
-int trpl_solve_pl_dev(const double *matpar, int64_t S, double length_nm, double time_ns, int32_t L, int64_t T,
-                      int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN, void *plI,
-                      int32_t pl_elem_bytes, int64_t pl_ld, int32_t *status, int64_t *iters_total, uint32_t flags,
-                      void *stream)
+int trpl_solve_pl_snap_dev(const double *matpar, int64_t S, double length_nm, double time_ns, int32_t L, int64_t T,
+                           int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN, void *plI,
+                           int32_t pl_elem_bytes, int64_t pl_ld, int32_t *status, int64_t *iters_total,
+                           const int64_t *snap_steps, int32_t n_snap, double *plN, double *plP, double *plE,
+                           uint32_t flags, void *stream)
 {
     if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
     if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (n_snap < 0 || n_snap > trpl::kMaxSnaps) return fail(TRPL_ERR_ARG, "n_snap=%d must be in [0, %d]", n_snap, trpl::kMaxSnaps);
+    if (n_snap > 0 && !snap_steps) return fail(TRPL_ERR_ARG, "snap_steps must not be NULL when n_snap > 0");
     if (S == 0) return TRPL_OK;
     if (!matpar || !dN || !plI) return fail(TRPL_ERR_ARG, "matpar, dN and plI must not be NULL");
     if (pl_elem_bytes != 4 && pl_elem_bytes != 8) return fail(TRPL_ERR_ARG, "pl_elem_bytes must be 4 or 8");
@@ -186,7 +215,91 @@ int trpl_solve_pl_dev(const double *matpar, int64_t S, double length_nm, double 
     a.S = S; a.C = 1; a.L = L; a.T = T; a.plT = plT; a.MAX = max_iter; a.flags = flags;
     a.TOL = pow(10.0, -(double)tol_exp);                        /* pvSimPCR.py:112 */
     curve_const(length_nm, time_ns, L, T, a.curve[0]);
+    if (n_snap > 0 && (plN || plP || plE)) {
+        // (step, slot) pairs, steps strictly ascending: the slot of a step is its FIRST position in the
+        // caller's list (Legacy/pvSim.py:122 `pT.index(t)`); steps outside [0, T] are never reached
+        a.snapN = plN; a.snapP = plP; a.snapE = plE; a.snap_ld = n_snap;
+        for (int i = 0; i < n_snap; i++) {
+            const int64_t st = snap_steps[i];
+            if (st < 0 || st > T) continue;
+            bool seen = false;
+            for (int k = 0; k < a.n_snap; k++) seen = seen || a.snap_t[k] == (int32_t)st;
+            if (seen) continue;
+            int at = a.n_snap++;
+            while (at > 0 && a.snap_t[at - 1] > (int32_t)st) {
+                a.snap_t[at] = a.snap_t[at - 1]; a.snap_slot[at] = a.snap_slot[at - 1]; at--;
+            }
+            a.snap_t[at] = (int32_t)st; a.snap_slot[at] = i;
+        }
+    }
     return launch(a, flags, (hipStream_t)stream, T);
+}
+
+int trpl_solve_pl_dev(const double *matpar, int64_t S, double length_nm, double time_ns, int32_t L, int64_t T,
+                      int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN, void *plI,
+                      int32_t pl_elem_bytes, int64_t pl_ld, int32_t *status, int64_t *iters_total, uint32_t flags,
+                      void *stream)
+{
+    return trpl_solve_pl_snap_dev(matpar, S, length_nm, time_ns, L, T, plT, tol_exp, max_iter, dN, plI, pl_elem_bytes,
+                                  pl_ld, status, iters_total, nullptr, 0, nullptr, nullptr, nullptr, flags, stream);
+}
+
+int trpl_solve_pl_snap(const double *matpar, int64_t S, double length_nm, double time_ns, int32_t L, int64_t T,
+                       int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN, void *plI,
+                       int32_t pl_elem_bytes, int64_t pl_ld, int32_t *status, int64_t *iters_total,
+                       const int64_t *snap_steps, int32_t n_snap, double *plN, double *plP, double *plE,
+                       uint32_t flags, int32_t device, double *seconds)
+{
+    if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
+    if (pl_elem_bytes != 4 && pl_elem_bytes != 8) return fail(TRPL_ERR_ARG, "pl_elem_bytes must be 4 or 8");
+    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (n_snap < 0 || n_snap > trpl::kMaxSnaps) return fail(TRPL_ERR_ARG, "n_snap=%d must be in [0, %d]", n_snap, trpl::kMaxSnaps);
+    if (seconds) *seconds = 0.0;
+    if (S == 0) return TRPL_OK;
+    if (!matpar || !dN || !plI) return fail(TRPL_ERR_ARG, "matpar, dN and plI must not be NULL");
+    const int64_t ncol = T / plT + 1;
+    if (pl_ld < ncol) return fail(TRPL_ERR_ARG, "pl_ld=%lld < T/plT+1", (long long)pl_ld);
+    if (int rc = select_device(device)) return rc;
+    // A large PL matrix is written by the kernel STRAIGHT INTO the caller's buffer (pinned and mapped for
+    // the duration of the call): the stores cross PCIe while the time-stepping goes on (a 1024 x 80 001 fp32
+    // block is 328 MB over a ~0.3 s kernel, ~1 GB/s), so there is no device copy of the matrix and no
+    // device-to-host copy after the kernel.  Small or unmappable buffers are staged through device memory.
+    HostMap map;
+    CallScope cs;
+    HIP_TRY(cs.open());
+    const size_t span = ((size_t)(S - 1) * pl_ld + ncol) * pl_elem_bytes;
+    void *pl_direct = map.map(plI, span);
+    DevBuf dm, dn, dp, ds, di, sN, sP, sE;
+    HIP_TRY(dm.alloc((size_t)S * 12 * 8, cs.st));
+    HIP_TRY(dn.alloc((size_t)L * 8, cs.st));
+    if (!pl_direct) HIP_TRY(dp.alloc((size_t)S * ncol * pl_elem_bytes, cs.st));
+    HIP_TRY(ds.alloc((size_t)S * 4, cs.st));
+    HIP_TRY(di.alloc((size_t)S * 8, cs.st));
+    HIP_TRY(hipMemcpyAsync(dm.p, matpar, (size_t)S * 12 * 8, hipMemcpyHostToDevice, cs.st));
+    HIP_TRY(hipMemcpyAsync(dn.p, dN, (size_t)L * 8, hipMemcpyHostToDevice, cs.st));
+    // snapshot buffers start as copies of the caller's (pvSimPCR.py:366-368): unfilled slots keep their contents
+    const size_t nNP = (size_t)S * n_snap * L * 8, nE = (size_t)S * n_snap * (L + 1) * 8;
+    if (n_snap > 0 && plN) { HIP_TRY(sN.alloc(nNP, cs.st)); HIP_TRY(hipMemcpyAsync(sN.p, plN, nNP, hipMemcpyHostToDevice, cs.st)); }
+    if (n_snap > 0 && plP) { HIP_TRY(sP.alloc(nNP, cs.st)); HIP_TRY(hipMemcpyAsync(sP.p, plP, nNP, hipMemcpyHostToDevice, cs.st)); }
+    if (n_snap > 0 && plE) { HIP_TRY(sE.alloc(nE, cs.st)); HIP_TRY(hipMemcpyAsync(sE.p, plE, nE, hipMemcpyHostToDevice, cs.st)); }
+    const double t0 = now_s();
+    if (int rc = trpl_solve_pl_snap_dev(dm.as<double>(), S, length_nm, time_ns, L, T, plT, tol_exp, max_iter,
+                                        dn.as<double>(), pl_direct ? pl_direct : dp.p, pl_elem_bytes,
+                                        pl_direct ? pl_ld : ncol, ds.as<int32_t>(), di.as<int64_t>(), snap_steps, n_snap,
+                                        sN.as<double>(), sP.as<double>(), sE.as<double>(), flags, cs.st))
+        return rc;
+    HIP_TRY(hipStreamSynchronize(cs.st));
+    if (seconds) *seconds = now_s() - t0;                       /* pvSimPCR.py:378-381 */
+    if (!pl_direct)
+        HIP_TRY(hipMemcpy2DAsync(plI, (size_t)pl_ld * pl_elem_bytes, dp.p, (size_t)ncol * pl_elem_bytes,
+                                 (size_t)ncol * pl_elem_bytes, (size_t)S, hipMemcpyDeviceToHost, cs.st));
+    if (status) HIP_TRY(hipMemcpyAsync(status, ds.p, (size_t)S * 4, hipMemcpyDeviceToHost, cs.st));
+    if (iters_total) HIP_TRY(hipMemcpyAsync(iters_total, di.p, (size_t)S * 8, hipMemcpyDeviceToHost, cs.st));
+    if (sN.p) HIP_TRY(hipMemcpyAsync(plN, sN.p, nNP, hipMemcpyDeviceToHost, cs.st));
+    if (sP.p) HIP_TRY(hipMemcpyAsync(plP, sP.p, nNP, hipMemcpyDeviceToHost, cs.st));
+    if (sE.p) HIP_TRY(hipMemcpyAsync(plE, sE.p, nE, hipMemcpyDeviceToHost, cs.st));
+    HIP_TRY(hipStreamSynchronize(cs.st));        // the copies back have landed (and their errors surface here)
+    return TRPL_OK;
 }
 
 int trpl_solve_pl(const double *matpar, int64_t S, double length_nm, double time_ns, int32_t L, int64_t T,
@@ -194,38 +307,8 @@ int trpl_solve_pl(const double *matpar, int64_t S, double length_nm, double time
                   int32_t pl_elem_bytes, int64_t pl_ld, int32_t *status, int64_t *iters_total, uint32_t flags,
                   int32_t device, double *seconds)
 {
-    if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
-    if (pl_elem_bytes != 4 && pl_elem_bytes != 8) return fail(TRPL_ERR_ARG, "pl_elem_bytes must be 4 or 8");
-    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
-    if (seconds) *seconds = 0.0;
-    if (S == 0) return TRPL_OK;
-    if (!matpar || !dN || !plI) return fail(TRPL_ERR_ARG, "matpar, dN and plI must not be NULL");
-    const int64_t ncol = T / plT + 1;
-    if (pl_ld < ncol) return fail(TRPL_ERR_ARG, "pl_ld=%lld < T/plT+1", (long long)pl_ld);
-    if (int rc = select_device(device)) return rc;
-    CallScope cs;
-    HIP_TRY(cs.open());
-    DevBuf dm, dn, dp, ds, di;
-    HIP_TRY(dm.alloc((size_t)S * 12 * 8, cs.st));
-    HIP_TRY(dn.alloc((size_t)L * 8, cs.st));
-    HIP_TRY(dp.alloc((size_t)S * ncol * pl_elem_bytes, cs.st));
-    HIP_TRY(ds.alloc((size_t)S * 4, cs.st));
-    HIP_TRY(di.alloc((size_t)S * 8, cs.st));
-    HIP_TRY(hipMemcpyAsync(dm.p, matpar, (size_t)S * 12 * 8, hipMemcpyHostToDevice, cs.st));
-    HIP_TRY(hipMemcpyAsync(dn.p, dN, (size_t)L * 8, hipMemcpyHostToDevice, cs.st));
-    const double t0 = now_s();
-    if (int rc = trpl_solve_pl_dev(dm.as<double>(), S, length_nm, time_ns, L, T, plT, tol_exp, max_iter,
-                                   dn.as<double>(), dp.p, pl_elem_bytes, ncol, ds.as<int32_t>(),
-                                   di.as<int64_t>(), flags, cs.st))
-        return rc;
-    HIP_TRY(hipStreamSynchronize(cs.st));
-    if (seconds) *seconds = now_s() - t0;                       /* pvSimPCR.py:378-381 */
-    HIP_TRY(hipMemcpy2DAsync(plI, (size_t)pl_ld * pl_elem_bytes, dp.p, (size_t)ncol * pl_elem_bytes,
-                        (size_t)ncol * pl_elem_bytes, (size_t)S, hipMemcpyDeviceToHost, cs.st));
-    if (status) HIP_TRY(hipMemcpyAsync(status, ds.p, (size_t)S * 4, hipMemcpyDeviceToHost, cs.st));
-    if (iters_total) HIP_TRY(hipMemcpyAsync(iters_total, di.p, (size_t)S * 8, hipMemcpyDeviceToHost, cs.st));
-    HIP_TRY(hipStreamSynchronize(cs.st));        // the copies back have landed (and their errors surface here)
-    return TRPL_OK;
+    return trpl_solve_pl_snap(matpar, S, length_nm, time_ns, L, T, plT, tol_exp, max_iter, dN, plI, pl_elem_bytes, pl_ld,
+                              status, iters_total, nullptr, 0, nullptr, nullptr, nullptr, flags, device, seconds);
 }
 
 /* ------------------------------------------------------------------ log10 clamp --------- */
@@ -251,11 +334,13 @@ int trpl_log10_clamp(void *x, int32_t elem_bytes, int64_t rows, int64_t cols, in
     if (rows == 0 || cols == 0) return TRPL_OK;
     if (!x) return fail(TRPL_ERR_ARG, "x must not be NULL");
     if (int rc = select_device(device)) return rc;
+    HostPin pin;
     CallScope cs;
     HIP_TRY(cs.open());
     const double t0 = now_s();                                   /* probs.py:79: includes the copies */
     DevBuf dx;
     const size_t rowb = (size_t)cols * elem_bytes;
+    pin.pin(x, ((size_t)(rows - 1) * ld + cols) * elem_bytes);
     HIP_TRY(dx.alloc(rowb * rows, cs.st));
     HIP_TRY(hipMemcpy2DAsync(dx.p, rowb, x, (size_t)ld * elem_bytes, rowb, (size_t)rows, hipMemcpyHostToDevice, cs.st));
     if (int rc = trpl_log10_clamp_dev(dx.p, elem_bytes, rows, cols, cols, min, cs.st)) return rc;
@@ -288,11 +373,13 @@ int trpl_sse_accumulate(double *P, const void *plI, int32_t elem_bytes, int64_t 
     if (rows == 0) return TRPL_OK;
     if (!P || !mag || (n_obs && (!plI || !values))) return fail(TRPL_ERR_ARG, "NULL pointer argument");
     if (int rc = select_device(device)) return rc;
+    HostPin pin;
     CallScope cs;
     HIP_TRY(cs.open());
     const double t0 = now_s();                                   /* probs.py:51 */
     DevBuf dP, dpl, dv, dm;
     const size_t rowb = (size_t)n_obs * elem_bytes;
+    if (n_obs) pin.pin(plI, ((size_t)(rows - 1) * ld + n_obs) * elem_bytes);
     HIP_TRY(dP.alloc((size_t)rows * 8, cs.st));
     HIP_TRY(dpl.alloc(rowb * rows, cs.st));
     HIP_TRY(dv.alloc((size_t)n_obs * 8, cs.st));
@@ -365,12 +452,7 @@ static int loglik_dev_impl(const double *X, int64_t S, int32_t C, const double *
         curve_const(lengths_nm[c], time_ns, L, T, a.curve[c]);
         a.curve[c].n_obs = n_obs[c];
     }
-    int64_t steps = T;                              // the kernel stops at the last observation (PlSink::t_last)
-    if (!interp) {
-        steps = 0;
-        for (int c = 0; c < C; c++) steps = std::max<int64_t>(steps, (n_obs[c] - 1) * (int64_t)plT);
-    }
-    if (int rc = launch(a, flags, (hipStream_t)stream, steps)) return rc;
+    if (int rc = launch(a, flags, (hipStream_t)stream, loglik_steps(interp, C, n_obs, plT, T))) return rc;
     hipError_t e = trpl::launch_reduce_curves(P, sse, S, C, (hipStream_t)stream);
     if (e != hipSuccess) return fail(TRPL_ERR_HIP, "reduce_curves launch: %s", hipGetErrorString(e));
     return TRPL_OK;
@@ -414,12 +496,7 @@ static int loglik_host_impl(const double *X, int64_t S, int32_t C, const double 
     HIP_TRY(cs.open());
     const bool interp = obs_hi != nullptr;
     if (interp) {                                    // the brackets are host data here: validate them
-        for (int c = 0; c < C; c++)
-            for (int64_t i = 0; i < n_obs[c] && i < obs_ld; i++) {
-                const int32_t h = obs_hi[c * obs_ld + i];
-                if (h < 1 || h > T || (i && h < obs_hi[c * obs_ld + i - 1]))
-                    return fail(TRPL_ERR_ARG, "obs_hi[%d][%lld]=%d must be sorted and in [1, T]", c, (long long)i, h);
-            }
+        if (int rc = check_brackets(obs_hi, obs_dx, obs_h, C, obs_ld, n_obs, T)) return rc;
     }
     DevBuf dX, ddN, dobs, dhi, ddx, dh, dP, dsse, dst, dit;
     const size_t nsys = (size_t)S * C, nobs = (size_t)C * obs_ld;
@@ -475,137 +552,6 @@ int trpl_loglik_obs(const double *X, int64_t S, int32_t C, const double *lengths
     if (!obs_hi || !obs_dx || !obs_h) return fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h must not be NULL");
     return loglik_host_impl(X, S, C, lengths_nm, time_ns, L, T, 1, tol_exp, max_iter, dN, obs, obs_hi, obs_dx, obs_h,
                             obs_ld, n_obs, P, sse, status, iters_total, flags, device, seconds);
-}
-
-/* ------------------------------------------------------------------ multi-device -------- */
-int trpl_shard_bounds(int64_t S, int32_t n_shards, int32_t shard, int64_t *lo, int64_t *hi)
-{
-    if (S < 0 || n_shards < 1 || shard < 0 || shard >= n_shards || !lo || !hi)
-        return fail(TRPL_ERR_ARG, "shard %d of %d over S=%lld is not a valid request", shard, n_shards, (long long)S);
-    const int64_t base = S / n_shards, rem = S % n_shards;
-    *lo = shard * base + (shard < rem ? shard : rem);
-    *hi = *lo + base + (shard < rem ? 1 : 0);
-    return TRPL_OK;
-}
-
-namespace {
-struct Shard {                       // one device's share of the samples; released on its own device
-    int dev = 0;
-    int64_t lo = 0, hi = 0;
-    hipStream_t st = nullptr;
-    DevBuf X, dN, obs, ohi, odx, oh, P, sse, status, iters;
-    ~Shard()
-    {
-        (void)hipSetDevice(dev);
-        for (DevBuf *b : {&X, &dN, &obs, &ohi, &odx, &oh, &P, &sse, &status, &iters}) b->release();   // stream-ordered frees
-        if (st) {
-            (void)hipStreamSynchronize(st);
-            (void)hipStreamDestroy(st);
-        }
-    }
-};
-}  // namespace
-
-int trpl_loglik_multi(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns, int32_t L,
-                      int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN, const double *obs,
-                      const int32_t *obs_hi, const double *obs_dx, const double *obs_h, int64_t obs_ld,
-                      const int64_t *n_obs, double *P, double *sse, int32_t *status, int64_t *iters_total,
-                      uint32_t flags, const int32_t *devices, int32_t n_devices, double *seconds)
-{
-    if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
-    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
-    if (C < 1 || C > trpl::kMaxCurves) return fail(TRPL_ERR_ARG, "C=%d must be in [1, %d]", C, trpl::kMaxCurves);
-    if (seconds) *seconds = 0.0;
-    if (!X || !lengths_nm || !dN || !obs || !n_obs || !P) return fail(TRPL_ERR_ARG, "NULL pointer argument");
-    if (obs_ld < 1) return fail(TRPL_ERR_ARG, "obs_ld must be >= 1");
-    const bool interp = obs_hi || obs_dx || obs_h;
-    if (interp && !(obs_hi && obs_dx && obs_h)) return fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h go together");
-    int visible = 0;
-    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) return fail(TRPL_ERR_NODEVICE, "no HIP device visible");
-    if (n_devices <= 0) {
-        if (devices) return fail(TRPL_ERR_ARG, "a device list needs n_devices >= 1");
-        n_devices = visible;
-    }
-    if (n_devices > 64) return fail(TRPL_ERR_ARG, "n_devices=%d exceeds 64", n_devices);
-    for (int r = 0; devices && r < n_devices; r++)
-        if (devices[r] < 0 || devices[r] >= visible)
-            return fail(TRPL_ERR_ARG, "devices[%d]=%d out of range (%d visible)", r, devices[r], visible);
-    if (S == 0) return TRPL_OK;
-    int prev = 0;
-    (void)hipGetDevice(&prev);
-
-    std::vector<Shard> sh(n_devices);
-    const size_t nobs = (size_t)C * obs_ld;
-    const double t0 = now_s();
-    int rc = TRPL_OK;
-    // stage and launch on every device before waiting for any of them
-    for (int r = 0; r < n_devices && rc == TRPL_OK; r++) {
-        Shard &q = sh[r];
-        q.dev = devices ? devices[r] : r;
-        (void)trpl_shard_bounds(S, n_devices, r, &q.lo, &q.hi);
-        const int64_t n = q.hi - q.lo;
-        if (n == 0) continue;
-        const size_t nsys = (size_t)n * C;
-        rc = [&]() -> int {
-            HIP_TRY(hipSetDevice(q.dev));
-            HIP_TRY(hipStreamCreateWithFlags(&q.st, hipStreamNonBlocking));
-            HIP_TRY(q.X.alloc((size_t)n * 13 * 8, q.st)); HIP_TRY(q.dN.alloc((size_t)C * L * 8, q.st)); HIP_TRY(q.obs.alloc(nobs * 8, q.st));
-            HIP_TRY(q.P.alloc((size_t)n * 8, q.st)); HIP_TRY(q.sse.alloc(nsys * 8, q.st)); HIP_TRY(q.status.alloc(nsys * 4, q.st));
-            HIP_TRY(q.iters.alloc(nsys * 8, q.st));
-            HIP_TRY(hipMemcpyAsync(q.X.p, X + q.lo * 13, (size_t)n * 13 * 8, hipMemcpyHostToDevice, q.st));
-            HIP_TRY(hipMemcpyAsync(q.dN.p, dN, (size_t)C * L * 8, hipMemcpyHostToDevice, q.st));
-            HIP_TRY(hipMemcpyAsync(q.obs.p, obs, nobs * 8, hipMemcpyHostToDevice, q.st));
-            HIP_TRY(hipMemcpyAsync(q.P.p, P + q.lo, (size_t)n * 8, hipMemcpyHostToDevice, q.st));
-            if (interp) {
-                HIP_TRY(q.ohi.alloc(nobs * 4, q.st)); HIP_TRY(q.odx.alloc(nobs * 8, q.st)); HIP_TRY(q.oh.alloc(nobs * 8, q.st));
-                HIP_TRY(hipMemcpyAsync(q.ohi.p, obs_hi, nobs * 4, hipMemcpyHostToDevice, q.st));
-                HIP_TRY(hipMemcpyAsync(q.odx.p, obs_dx, nobs * 8, hipMemcpyHostToDevice, q.st));
-                HIP_TRY(hipMemcpyAsync(q.oh.p, obs_h, nobs * 8, hipMemcpyHostToDevice, q.st));
-            }
-            if (int e = loglik_dev_impl(q.X.as<double>(), n, C, lengths_nm, time_ns, L, T, plT, tol_exp, max_iter,
-                                        q.dN.as<double>(), q.obs.as<double>(), interp ? q.ohi.as<int32_t>() : nullptr,
-                                        interp ? q.odx.as<double>() : nullptr, interp ? q.oh.as<double>() : nullptr,
-                                        obs_ld, n_obs, q.P.as<double>(), q.sse.as<double>(), q.status.as<int32_t>(),
-                                        q.iters.as<int64_t>(), flags, q.st))
-                return e;
-            return TRPL_OK;
-        }();
-    }
-    // only now the copies back: a device-to-host copy into pageable memory blocks the calling thread until
-    // the shard's kernel has finished, so issuing it inside the loop above would run the devices one
-    // after the other
-    for (int r = 0; r < n_devices && rc == TRPL_OK; r++) {
-        Shard &q = sh[r];
-        const int64_t n = q.hi - q.lo;
-        if (n == 0 || !q.st) continue;
-        rc = [&]() -> int {
-            HIP_TRY(hipSetDevice(q.dev));
-            HIP_TRY(hipMemcpyAsync(P + q.lo, q.P.p, (size_t)n * 8, hipMemcpyDeviceToHost, q.st));
-            // per-curve outputs are [C][S] on the host and [C][n] on the device: one strided copy each
-            if (sse)
-                HIP_TRY(hipMemcpy2DAsync(sse + q.lo, (size_t)S * 8, q.sse.p, (size_t)n * 8, (size_t)n * 8, C,
-                                         hipMemcpyDeviceToHost, q.st));
-            if (status)
-                HIP_TRY(hipMemcpy2DAsync(status + q.lo, (size_t)S * 4, q.status.p, (size_t)n * 4, (size_t)n * 4, C,
-                                         hipMemcpyDeviceToHost, q.st));
-            if (iters_total)
-                HIP_TRY(hipMemcpy2DAsync(iters_total + q.lo, (size_t)S * 8, q.iters.p, (size_t)n * 8, (size_t)n * 8, C,
-                                         hipMemcpyDeviceToHost, q.st));
-            return TRPL_OK;
-        }();
-    }
-    // drain every stream that was started, also after a failure (the host buffers are borrowed)
-    for (int r = 0; r < n_devices; r++) {
-        if (!sh[r].st) continue;
-        hipError_t e = hipSetDevice(sh[r].dev);
-        if (e == hipSuccess) e = hipStreamSynchronize(sh[r].st);
-        if (e != hipSuccess && rc == TRPL_OK)
-            rc = fail(TRPL_ERR_HIP, "device %d (shard %d): %s", sh[r].dev, r, hipGetErrorString(e));
-    }
-    if (seconds) *seconds = now_s() - t0;
-    sh.clear();
-    (void)hipSetDevice(prev);
-    return rc;
 }
 
 /* ------------------------------------------------------------------ posterior core ------ */

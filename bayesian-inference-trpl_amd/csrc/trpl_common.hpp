@@ -6,6 +6,7 @@
 namespace trpl {
 
 constexpr int kMaxCurves = 16;
+constexpr int kMaxSnaps = 16;      // state snapshots per solve (trpl_solve_pl_snap)
 
 // Per-curve constants, computed on the host exactly as pvSim does (pvSimPCR.py:314-331,
 // :393) so that the in-kernel products X[s][i] * scales[i] round like numpy's.
@@ -13,6 +14,7 @@ struct CurveConst {
     double scales[12];   // dx3,dx3,dt/dx2,dt/dx2,dt/dx3,dt/dx,dt/dx,dt/dx6,dt/dx6,1/dt,1/dt,1/dx
     double dx3;          // excitation scale (pvSimPCR.py:356)
     double plnorm;       // dx^2 * dt        (pvSimPCR.py:393)
+    double dx;           // Length / L: re-dimensionalises the field snapshots (Legacy/pvSim.py:171)
     int64_t n_obs;       // likelihood mode: number of PL columns compared (<= T/plT + 1)
 };
 
@@ -28,6 +30,9 @@ struct StepArgs {
     double *sse;            // [C][S] out (likelihood mode) or nullptr
     int32_t *status;        // [C][S] out or nullptr
     int64_t *iters_total;   // [C][S] out or nullptr
+    // state snapshots (solve mode only; pvSimPCR.py:283-288, Legacy/pvSim.py:121-126,:169-171): the state
+    // at time step snap_t[i] goes to slot snap_slot[i] of snapN/snapP [C*S][snap_ld][L], snapE [..][L+1]
+    double *snapN, *snapP, *snapE;
     int64_t S;
     int64_t T;
     int64_t pl_ld;
@@ -40,6 +45,10 @@ struct StepArgs {
     int32_t MAX;
     int32_t pl_bytes;       // 4 or 8
     uint32_t flags;         // TRPL_FLAG_*
+    int32_t n_snap;         // number of (step, slot) pairs below, steps strictly ascending
+    int32_t snap_ld;        // slots per system in the snapshot arrays
+    int32_t snap_t[kMaxSnaps];
+    int32_t snap_slot[kMaxSnaps];
     CurveConst curve[kMaxCurves];
 };
 

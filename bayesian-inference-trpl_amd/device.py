@@ -175,3 +175,106 @@ def loglik_from_pl_device(pl, obs, mag, P=None, sse=None, obs_hi=None, obs_dx=No
         obs.shape[0], _chk(mag, torch.float64, "mag"), None if status is None else _chk(status, torch.int32, "status"),
         None if P is None else _chk(P, torch.float64, "P"),
         None if sse is None else _chk(sse, torch.float64, "sse"), int(flags), _stream()))
+
+
+def solve_pl_snap_device(matPar, Length, Time, L, T, dN, plI, snap_steps, plN=None, plP=None, plE=None, status=None,
+                         iters_total=None, tol=7, MAX=10000, plT=1, flags=0):
+    """trpl_solve_pl_snap_dev: solve_pl_device that also records the state at the time steps snap_steps
+    (host sequence) into plN, plP (S, len(snap_steps), L) and plE (S, len(snap_steps), L+1), f64 tensors."""
+    import torch
+    S = matPar.shape[0]
+    steps = np.ascontiguousarray(snap_steps, dtype=np.int64)
+    n = len(steps)
+    if matPar.shape[1] != 12 or tuple(dN.shape) != (L,) or tuple(plI.shape) != (S, T // plT + 1):
+        raise ValueError("shape mismatch")
+    for t, w in ((plN, L), (plP, L), (plE, L + 1)):
+        if t is not None and tuple(t.shape) != (S, n, w):
+            raise ValueError("snapshot tensors must be (S, len(snap_steps), L) / (.., L+1)")
+    _abi.check(_abi.lib().trpl_solve_pl_snap_dev(
+        _chk(matPar, torch.float64, "matPar"), S, float(Length), float(Time), int(L), int(T), int(plT), int(tol),
+        int(MAX), _chk(dN, torch.float64, "dN"), _chk(plI, plI.dtype, "plI"), plI.element_size(), plI.shape[1],
+        None if status is None else _chk(status, torch.int32, "status"),
+        None if iters_total is None else _chk(iters_total, torch.int64, "iters_total"), _abi.ptr(steps), n,
+        None if plN is None else _chk(plN, torch.float64, "plN"), None if plP is None else _chk(plP, torch.float64, "plP"),
+        None if plE is None else _chk(plE, torch.float64, "plE"), int(flags), _stream()))
+
+
+class MultiDevice:
+    """One process, several GPUs, results resident on every GPU (trpl_multi_* / trpl_loglik_multi_dev, SURVEY
+    8e): contiguous sample shards, one RCCL all-gather of the per-sample likelihoods over xGMI.  The handle
+    owns one stream and one RCCL rank per device; create it once and reuse it."""
+
+    def __init__(self, devices=None):
+        self._h = _abi.C.c_void_p()
+        dev = None if devices is None else np.ascontiguousarray(devices, dtype=np.int32)
+        _abi.check(_abi.lib().trpl_multi_create(_abi.ptr(dev), 0 if dev is None else len(dev), _abi.C.byref(self._h)))
+        self.n = int(_abi.lib().trpl_multi_device_count(self._h))
+        self.devices = list(range(self.n)) if dev is None else [int(d) for d in dev]
+
+    def close(self):
+        if self._h:
+            _abi.lib().trpl_multi_destroy(self._h)
+            self._h = _abi.C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def synchronize(self):
+        _abi.check(_abi.lib().trpl_multi_synchronize(self._h))
+
+    def shard_bounds(self, S):
+        from .dist import shard_bounds
+        return [shard_bounds(S, self.n, r) for r in range(self.n)]
+
+    def _table(self, tensors, dtype, name, optional=False):
+        import torch
+        if tensors is None:
+            if optional:
+                return None
+            raise ValueError("%s: one tensor per device is required" % name)
+        if len(tensors) != self.n:
+            raise ValueError("%s: need %d per-device tensors" % (name, self.n))
+        tab = (_abi.C.c_void_p * self.n)()
+        for r, t in enumerate(tensors):
+            if t is None or t.numel() == 0:
+                tab[r] = None
+                continue
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.is_contiguous()
+                    and t.device.index == self.devices[r]):
+                raise ValueError("%s[%d] must be a contiguous %s tensor on cuda:%d" % (name, r, dtype, self.devices[r]))
+            tab[r] = t.data_ptr()
+        return tab
+
+    def loglik(self, X, init_params, lengths, Time, L, T, obs, n_obs, P_full, sse=None, status=None, iters_total=None,
+               obs_hi=None, obs_dx=None, obs_h=None, tol=7, MAX=10000, plT=1, flags=0):
+        """Enqueue the sharded fused likelihood + the all-gather; returns at once (synchronize() waits).
+        X: list of per-device shards (n_r, 13); init_params / obs (/ obs_hi, obs_dx, obs_h): lists of per-device
+        replicas; P_full: list of per-device (S,) f64 outputs; sse / status / iters_total: optional lists of
+        per-device (C, n_r) outputs.  S is taken from P_full."""
+        import torch
+        S = int(P_full[0].shape[0])
+        Cn = int(init_params[0].shape[0])
+        bounds = self.shard_bounds(S)
+        for r, (lo, hi) in enumerate(bounds):
+            if tuple(X[r].shape) != (hi - lo, 13) or tuple(P_full[r].shape) != (S,) \
+                    or tuple(init_params[r].shape) != (Cn, L) or obs[r].shape[0] != Cn:
+                raise ValueError("rank %d: shapes do not match the shard [%d, %d) of S=%d" % (r, lo, hi, S))
+            for name, lst, dt in (("sse", sse, torch.float64), ("status", status, torch.int32),
+                                  ("iters_total", iters_total, torch.int64)):
+                if lst is not None and tuple(lst[r].shape) != (Cn, hi - lo):
+                    raise ValueError("%s[%d] must be (C, %d)" % (name, r, hi - lo))
+        lengths = np.ascontiguousarray(np.broadcast_to(np.asarray(lengths, dtype=np.float64), (Cn,)))
+        n_obs = np.ascontiguousarray(np.broadcast_to(np.asarray(n_obs, dtype=np.int64), (Cn,)))
+        _abi.check(_abi.lib().trpl_loglik_multi_dev(
+            self._h, self._table(X, torch.float64, "X"), S, Cn, _abi.ptr(lengths), float(Time), int(L), int(T), int(plT),
+            int(tol), int(MAX), self._table(init_params, torch.float64, "init_params"),
+            self._table(obs, torch.float64, "obs"), self._table(obs_hi, torch.int32, "obs_hi", True),
+            self._table(obs_dx, torch.float64, "obs_dx", True), self._table(obs_h, torch.float64, "obs_h", True),
+            int(obs[0].shape[1]), _abi.ptr(n_obs), self._table(P_full, torch.float64, "P_full"),
+            self._table(sse, torch.float64, "sse", True), self._table(status, torch.int32, "status", True),
+            self._table(iters_total, torch.int64, "iters_total", True), int(flags)))

@@ -69,7 +69,7 @@ def bracket_times(sim_t, times):
 
 
 def loglik(X, init_params, lengths, Time, L, T, obs, tol=7, MAX=10000, plT=1, P=None, pl_f32=False,
-           normalize=False, strict=False, device=0, info=None, times=None, fp32=False, devices=None):
+           normalize=False, strict=False, device=0, info=None, times=None, fp32=False, devices=None, kernel=None):
     """Fused likelihood of one experiment (trpl_loglik / trpl_loglik_obs / trpl_loglik_multi).
 
     X (S,13) solver units; init_params (C,L) nm^-3; lengths scalar or (C,); obs = list of C
@@ -79,6 +79,7 @@ def loglik(X, init_params, lengths, Time, L, T, obs, tol=7, MAX=10000, plT=1, P=
     Accumulates into P (S,) if given (like probs.prob), else starts from zeros.  Returns P.
     devices: None = the single `device`; "all" = every visible device; or a list of device ordinals
     (contiguous sample shards, one per entry, run concurrently from this host thread).
+    kernel: None (the library picks the stepper by launch size), "pair" or "single" (TRPL_FLAG_KERNEL_*).
     """
     X = np.ascontiguousarray(X, dtype=np.float64)
     if X.ndim != 2 or X.shape[1] != 13:
@@ -122,7 +123,7 @@ def loglik(X, init_params, lengths, Time, L, T, obs, tol=7, MAX=10000, plT=1, P=
     status = np.zeros((Cn, S), dtype=np.int32)
     iters = np.zeros((Cn, S), dtype=np.int64)
     flags = (_abi.FLAG_STRICT if strict else 0) | (_abi.FLAG_PL_F32 if pl_f32 else 0) \
-        | (_abi.FLAG_NORMALIZE if normalize else 0) | (_abi.FLAG_FP32 if fp32 else 0)
+        | (_abi.FLAG_NORMALIZE if normalize else 0) | (_abi.FLAG_FP32 if fp32 else 0) | _abi.kernel_flag(kernel)
     sec = _abi.C.c_double(0.0)
     lib = _abi.lib()
     if devices is not None:

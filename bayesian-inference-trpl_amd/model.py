@@ -11,9 +11,16 @@ def _as_f64(a):
 
 
 def solve_pl(matPar, Length, Time, L, T, dN, plT=1, tol=7, MAX=10000, out=None, dtype=np.float64,
-             strict=False, device=0, fp32=False):
+             strict=False, device=0, fp32=False, kernel=None, snap_steps=None, plN=None, plP=None, plE=None,
+             snapshots=None):
     """PL(t) for S systems of one curve.  matPar (S,12) and dN (L,) in nm/ns units.
-    Returns (plI, status, iters_total, seconds)."""
+    Returns (plI, status, iters_total, seconds).
+
+    kernel: None (the library picks by launch size), "pair" or "single" (TRPL_FLAG_KERNEL_*).
+    snap_steps: time-step indices at which the state is recorded (the reference's pT after
+    bayeslib.py:123); the snapshots are written into plN, plP (S, len(snap_steps), L) and plE
+    (S, len(snap_steps), L+1) when given (float64, C-contiguous, filled in place like the reference's
+    plN_main / plP_main / plE_main), or returned in the dict `snapshots` (keys 'plN', 'plP', 'plE')."""
     matPar = _as_f64(matPar)
     if matPar.ndim != 2 or matPar.shape[1] != 12:
         raise ValueError("matPar must have shape (S, 12)")
@@ -30,19 +37,49 @@ def solve_pl(matPar, Length, Time, L, T, dN, plT=1, tol=7, MAX=10000, out=None, 
     status = np.zeros(S, dtype=np.int32)
     iters = np.zeros(S, dtype=np.int64)
     sec = _abi.C.c_double(0.0)
-    flags = (_abi.FLAG_STRICT if strict else 0) | (_abi.FLAG_FP32 if fp32 else 0)
-    _abi.check(_abi.lib().trpl_solve_pl(_abi.ptr(matPar), S, float(Length), float(Time), int(L), int(T), int(plT),
-                                        int(tol), int(MAX), _abi.ptr(dN), _abi.ptr(out), out.itemsize,
-                                        out.strides[0] // out.itemsize, _abi.ptr(status), _abi.ptr(iters), flags,
-                                        int(device), _abi.C.byref(sec)))
+    flags = (_abi.FLAG_STRICT if strict else 0) | (_abi.FLAG_FP32 if fp32 else 0) | _abi.kernel_flag(kernel)
+    steps = None
+    n_snap = 0
+    if snap_steps is not None and len(snap_steps):
+        steps = np.ascontiguousarray(snap_steps, dtype=np.int64)
+        n_snap = len(steps)
+        if steps.ndim != 1 or n_snap > _abi.MAX_SNAPS:
+            raise ValueError("snap_steps must be a 1-D list of at most %d time-step indices" % _abi.MAX_SNAPS)
+        if snapshots is not None:
+            plN = np.zeros((S, n_snap, L)) if plN is None else plN
+            plP = np.zeros((S, n_snap, L)) if plP is None else plP
+            plE = np.zeros((S, n_snap, L + 1)) if plE is None else plE
+        for name, arr, width in (("plN", plN, L), ("plP", plP, L), ("plE", plE, L + 1)):
+            if arr is not None and not (isinstance(arr, np.ndarray) and arr.dtype == np.float64 and arr.flags.c_contiguous
+                                        and arr.shape == (S, n_snap, width)):
+                raise ValueError("%s must be a C-contiguous float64 array of shape (%d, %d, %d)" % (name, S, n_snap, width))
+    _abi.check(_abi.lib().trpl_solve_pl_snap(_abi.ptr(matPar), S, float(Length), float(Time), int(L), int(T), int(plT),
+                                             int(tol), int(MAX), _abi.ptr(dN), _abi.ptr(out), out.itemsize,
+                                             out.strides[0] // out.itemsize, _abi.ptr(status), _abi.ptr(iters),
+                                             _abi.ptr(steps), n_snap, _abi.ptr(plN) if n_snap else None,
+                                             _abi.ptr(plP) if n_snap else None, _abi.ptr(plE) if n_snap else None,
+                                             flags, int(device), _abi.C.byref(sec)))
+    if snapshots is not None:
+        snapshots.update(plN=plN, plP=plP, plE=plE)
     return out, status, iters, sec.value
+
+
+def _snapshot_target(arr, S, n, width):
+    """The caller's plN/plP/plE buffer if the kernel can fill it in place (pvSimPCR.py:366-368 ships whatever
+    it is given to the device): a float64 C-contiguous (S, len(pT), width) array."""
+    return arr if (isinstance(arr, np.ndarray) and arr.dtype == np.float64 and arr.flags.c_contiguous
+                   and arr.shape == (S, n, width)) else None
 
 
 def pvSim(plI_main, plN_main, plP_main, plE_main, matPar, simPar, iniPar, TPB=None, BPG=None,
           max_sims_per_block=1, init_mode="exp", strict=False, device=0, info=None):
-    """pvSimPCR.pvSim (pvSimPCR.py:309).  plN/plP/plE (unused debug buffers there, :368-370),
-    TPB, BPG and max_sims_per_block (CUDA launch shape) are accepted and ignored: one
-    wavefront owns one system.  `info`, if a dict, receives 'status' and 'iters_total'."""
+    """pvSimPCR.pvSim (pvSimPCR.py:309).  TPB, BPG and max_sims_per_block (CUDA launch shape) are accepted
+    and ignored: one wavefront owns one system (or two).  plN_main / plP_main / plE_main, the reference's
+    debug outputs (recording hook pvSimPCR.py:283-288, disabled there; working form Legacy/pvSim.py:121-126,
+    :169-171), are FILLED when they are float64 arrays of shape (S, len(pT), L) / (S, len(pT), L+1): the
+    densities (nm^-3) and the field (nm^-1) of the state at the time steps pT = simPar[5]; anything else
+    (None, the dummies bayeslib passes) is ignored as before.  `info`, if a dict, receives 'status' and
+    'iters_total'."""
     Length, Time, L, T, plT, pT, tol, MAX = simPar
     if max_sims_per_block != 1:
         # bundling couples the convergence of unrelated samples in the reference
@@ -58,8 +95,21 @@ def pvSim(plI_main, plN_main, plP_main, plE_main, matPar, simPar, iniPar, TPB=No
     else:
         raise ValueError("init_mode %r is not supported (the reference's 'continue' is broken, "
                          "pvSimPCR.py:357-362)" % (init_mode,))
+    S = len(matPar)
+    steps = None
+    try:
+        steps = [int(v) for v in pT] if pT is not None else None
+    except TypeError:
+        steps = None
+    snaps = {}
+    if steps and 0 < len(steps) <= _abi.MAX_SNAPS:
+        snaps = {"plN": _snapshot_target(plN_main, S, len(steps), int(L)),
+                 "plP": _snapshot_target(plP_main, S, len(steps), int(L)),
+                 "plE": _snapshot_target(plE_main, S, len(steps), int(L) + 1)}
+    want = any(v is not None for v in snaps.values())
     _, status, iters, sec = solve_pl(matPar, Length, Time, int(L), int(T), dN, plT=int(plT), tol=int(tol),
-                                     MAX=int(MAX), out=plI_main, strict=strict, device=device)
+                                     MAX=int(MAX), out=plI_main, strict=strict, device=device,
+                                     snap_steps=steps if want else None, **(snaps if want else {}))
     if info is not None:
         info["status"] = status
         info["iters_total"] = iters

@@ -19,6 +19,9 @@ steps after the excitation need many more inner iterations than the rest, so sho
 under-state the full-length rate (3.2 iterations per step at T = 1000, 2.2 at 8000, 2.0 at 80 000):
 `--T 80000` runs the full length, `--T 1000` the transient-dominated case of the earlier profiles.
 
+At N = 1 the line also carries `full_length`: ONE extra pass at the production length T = 80 000 over the
+same resident batch (event-timed, ~26 s), so that the full-length rate is measured by every driver run.
+
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline      the dominant kernel (the fused time-stepper): achieved fp64 FLOP/s from the
                 device's own iteration counters (268*L flop per inner iteration)
@@ -26,7 +29,8 @@ Rank 0 prints ONE JSON line (contract in the task statement) with two extra obje
                 the fp64 vector peak.  It is VALU-bound by construction (state lives in
                 registers), so `bound` is "valu-fp64"; `roofline_hbm_pcr` is the HBM roofline of
                 the stand-alone batched PCR solve (U1, 5*L*8 B per system), the kernel the
-                north-star's ">= 40 % of HBM roofline" target names.
+                north-star's ">= 40 % of HBM roofline" target names; its launches rotate over four
+                distinct operand sets (1.34 GB, 5x the Infinity Cache) so the rate is an HBM rate.
   cpu_baseline  the CPU oracle (the reference's algorithm restated in C, bit-identical to it)
                 timed on this host's cores on a bounded sample of the same workload.
 """
@@ -61,6 +65,12 @@ def main():
     ap.add_argument("--tol", type=int, default=None, help="convergence exponent (default 7, the reference's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcr", action="store_true")
+    ap.add_argument("--no-full-length", action="store_true",
+                    help="skip the one extra pass at the reference's production length T = 80000 (N = 1 only, ~26 s)")
+    ap.add_argument("--full-length-T", type=int, default=80000)
+    ap.add_argument("--traffic-profile", default=None,
+                    help="tag of the committed profiles/<tag>_hbm_traffic.json to quote (default: highest round/version)")
+    ap.add_argument("--dump-p", default=None, help="rank 0 saves the gathered likelihood vector of the last pass (.npy)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (one GPU per rank); gloo = rehearsal of the N>1 control flow "
@@ -112,6 +122,9 @@ def main():
     S = hi - lo
     X_host = wl.samples(S_total)[lo:hi]                      # same seeded draw on every rank, own shard
     flags = (trpl_amd.FLAG_STRICT if args.strict else 0) | (trpl_amd.FLAG_FP32 if args.fp32 else 0)
+    # the stepper variant is a property of the LOGICAL batch (all ranks' samples), not of this rank's shard:
+    # a sample's bits then do not depend on how many GPUs the batch is cut over (include/trpl.h)
+    flags = trpl_amd._abi.pin_variant(flags, S_total * C, L, T)
 
     # ---- inputs resident in HBM before anything is timed ----
     X = torch.from_numpy(np.ascontiguousarray(X_host)).to(dev)
@@ -166,6 +179,8 @@ def main():
     n_fail = int((status != 0).sum().item())
     it_total = int(iters.sum().item())                        # inner iterations in ONE pass on this rank
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if rank == 0 and args.dump_p:
+        np.save(args.dump_p, full.detach().cpu().numpy())
     if world > 1:
         agg = torch.tensor([it_total, n_fail], dtype=torch.float64, device=cdev)
         dist.all_reduce(agg)
@@ -175,20 +190,26 @@ def main():
     assert full.shape == (1, S_total) and bool(torch.isfinite(full).sum() >= S_total - fail_all)
 
     sys_steps = S_total * C * (T + 1)                         # system-timesteps per pass, all ranks
+    lost = (status > 0).to(torch.float64) * (float(T + 1) - status.to(torch.float64))     # status = 1 + failing step
+    steps_lost = float(lost.sum().item())
+    if world > 1:
+        lt = torch.tensor([steps_lost], dtype=torch.float64, device=cdev)
+        dist.all_reduce(lt)
+        steps_lost = float(lt.item())
     value = sys_steps * args.steps / elapsed
     flop_launch = it_total * FLOP_PER_ITER_PER_NODE * L       # this rank's launch
     achieved_tf = flop_launch / (kern_ms * 1e-3) / 1e12
 
     # which time-stepper this launch ran (the library picks the two-systems-per-wavefront kernel for
     # fp64 L = 128 launches that fill the chip)
-    variant = trpl_amd._abi.lib().trpl_kernel_variant(int(args.samples_per_gpu) * C, L, T, flags)
+    variant = trpl_amd._abi.lib().trpl_kernel_variant(S_total * C, L, T, flags)
     if variant == trpl_amd._abi.KERNEL_FAST_PAIR:
         kernel_name = "pair::stepper_pair_kernel (2 x L=128 systems per wavefront; fused time-stepper + likelihood)"
-        rocprof_name = "void trpl::pair::stepper_pair_kernel<true, 1>"
+        rocprof_name = "void trpl::pair::stepper_pair_kernel<true, 1, false>"
     else:
         kernel_name = "%sstepper_kernel<%d> (fused time-stepper + likelihood)" % ("f32::" if args.fp32 else "", L)
         rocprof_name = ("void trpl::f32::stepper_kernel<%d>" % L) if args.fp32 else \
-            "void trpl::stepper_kernel<%d, %s>" % (L, "true" if args.strict else "false")
+            "void trpl::stepper_kernel<%d, %s, false>" % (L, "true" if args.strict else "false")
     out = {
         "metric": "TRPL timesteps/sec at %d nodes (system = parameter sample x excitation; fused solve + "
                   "log-likelihood; parameter-sample likelihoods/sec in likelihoods_per_s_*)" % L,
@@ -214,6 +235,8 @@ def main():
         "inner_iterations_per_s": it_all * args.steps / elapsed,
         "mean_inner_iterations_per_step": it_all / sys_steps,
         "nonconverged_systems": fail_all,
+        # a flagged system stops at its failing step: the steps actually taken, beside the nominal S*C*(T+1)
+        "system_timesteps_taken_per_pass": int(sys_steps - steps_lost),
         "roofline": {"kernel": kernel_name, "rocprof_name": rocprof_name,
                      "bound": "valu-fp32" if args.fp32 else "valu-fp64",
                      "achieved": achieved_tf, "peak": FP64_VECTOR_PEAK_TFLOPS * (2 if args.fp32 else 1), "unit": "TFLOP/s",
@@ -226,8 +249,11 @@ def main():
     if rank == 0 and not args.no_pcr:
         out["roofline_hbm_pcr"] = bench_pcr(torch, tdev, dev, flags & trpl_amd.FLAG_STRICT, L=L,
                                             dtype=torch.float32 if args.fp32 else torch.float64)
+    if rank == 0 and world == 1 and not args.no_full_length and args.full_length_T != T:
+        out["full_length"] = full_length_pass(torch, tdev, trpl_amd, dev, X, ini_d, mark, lens, L, args.full_length_T, dt_ns,
+                                              flags, tol, C, args.fp32)
     if rank == 0:
-        attach_traffic(out)
+        attach_traffic(out, args.traffic_profile)
     out.update(cpu_legs)
     if world > 1:
         dist.barrier()
@@ -236,59 +262,125 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-def attach_traffic(out):
+def full_length_pass(torch, tdev, trpl_amd, dev, X, ini_d, mark, lens, L, T, dt_ns, flags, tol, C, fp32):
+    """ONE pass at the reference's production length (parallel_bayes_gpu.py:75: T = 80 000 steps of 0.025 ns)
+    over the same resident batch, timed with events on the launch stream: the headline K-step loop uses a
+    shorter window because K x 26 s would not fit the driver's time limit; the per-step rate of the short
+    window UNDER-states this one (more of it is the stiff start of the decay)."""
+    Time = T * dt_ns
+    S = X.shape[0]
+    obs = torch.empty((C, T + 1), dtype=torch.float64, device=dev)
+    for c in range(C):
+        pl = torch.empty((1, T + 1), dtype=torch.float64, device=dev)
+        tdev.solve_pl_device(mark, lens[c], Time, L, T, ini_d[c].contiguous(), pl, flags=trpl_amd.FLAG_STRICT, tol=7)
+        obs[c] = torch.log10(pl[0])
+    P = torch.zeros(S, dtype=torch.float64, device=dev)
+    sse = torch.empty((C, S), dtype=torch.float64, device=dev)
+    status = torch.empty((C, S), dtype=torch.int32, device=dev)
+    iters = torch.empty((C, S), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    tdev.loglik_device(X, ini_d, lens, Time, L, T, obs, [T + 1] * C, P, sse, status, iters, flags=flags, tol=tol)
+    e1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ms = e0.elapsed_time(e1)
+    it = int(iters.sum().item())
+    peak = FP64_VECTOR_PEAK_TFLOPS * (2 if fp32 else 1)
+    tf = it * FLOP_PER_ITER_PER_NODE * L / (ms * 1e-3) / 1e12
+    return {"T": T, "passes": 1, "ms": ms, "wall_ms": wall * 1e3,
+            "system_timesteps_per_s": S * C * (T + 1) / (ms * 1e-3), "likelihoods_per_s": S / (ms * 1e-3),
+            "inner_iterations": it, "mean_inner_iterations_per_step": it / (S * C * (T + 1)),
+            "nonconverged_systems": int((status != 0).sum().item()),
+            "roofline_achieved_tflops": tf, "roofline_frac": tf / peak,
+            "finite_likelihoods": int(torch.isfinite(P).sum().item())}
+
+
+def _profile_key(path):
+    """Sort key of profiles/<tag>_hbm_traffic.json by the numbers in its tag (r2_v10 > r2_v9 > r1_v9)."""
+    import re
+    tag = os.path.basename(path)[:-len("_hbm_traffic.json")]
+    return [int(n) for n in re.findall(r"\d+", tag)], tag
+
+
+def attach_traffic(out, tag=None):
     """`traffic` = HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in
     separate runs, gfx950 x2 read correction) of tools/profile_round.sh, as committed under
-    profiles/<tag>_hbm_traffic.json (newest tag).  PMC counters cannot be read from inside this
-    process, so the figure comes from that profile of the same kernels; null if none is committed.
-    The stepper's figure is for the profile's T (its traffic is the observation stream, ~8 B per
-    system-step through L2), the PCR's is size-matched (65 536 x 128)."""
+    profiles/<tag>_hbm_traffic.json.  PMC counters cannot be read from inside this process, so the figure
+    is that of ANOTHER run of the same kernels -- the profile named in `traffic_source` (chosen by tag:
+    --traffic-profile, else the highest round/version number; never by file time) -- not of the run being
+    timed; null if none is committed.  The stepper's traffic scales with the profile's T (the observation
+    stream, ~8 B per system-step through L2); the PCR's is size-matched (65 536 x 128)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), key=_profile_key)
+    if tag is not None:
+        files = [f for f in files if os.path.basename(f) == tag + "_hbm_traffic.json"]
     if not files:
         return
     t = json.load(open(files[-1]))
     src = os.path.basename(files[-1])
+    meta = t.get("_meta", {})
+    # kernel names gained a template argument in round 2: accept the profile's spelling of the same kernel
+    def find(name):
+        base = name.split("<")[0]
+        hits = [k for k in t if k != "_meta" and k.split("<")[0] == base and (k == name or name.startswith(k[:-1]) or k.startswith(name[:-1]))]
+        return t[hits[0]] if hits else None
     for key, obj in ((out["roofline"]["rocprof_name"], "roofline"),
                      ("void trpl::pcr_batched_kernel<double, 128, false>", "roofline_hbm_pcr")):
-        if key in t and obj in out and (obj == "roofline" or "double,128" in out[obj]["kernel"]):
-            out[obj]["traffic"] = t[key]["hbm_bytes_per_launch"]
-            out[obj]["traffic_source"] = "profiles/" + src
+        rec = find(key)
+        if rec and obj in out and (obj == "roofline" or "double,128" in out[obj]["kernel"]):
+            out[obj]["traffic"] = rec["hbm_bytes_per_launch"]
+            out[obj]["traffic_source"] = "from profile %s (profiles/%s%s): a separate rocprofv3 --pmc run of the same " \
+                                         "kernels, not this timed run" % (src[:-len("_hbm_traffic.json")], src,
+                                                                          ", T=%s" % meta["T"] if "T" in meta else "")
 
 
-def bench_pcr(torch, tdev, dev, flags, S=65536, L=128, reps=50, dtype=None):
-    """U1: stand-alone batched PCR tridiagonal solve, HBM -> HBM, 5*L*w B per system."""
+def bench_pcr(torch, tdev, dev, flags, S=65536, L=128, reps=48, dtype=None, nsets=4):
+    """U1: stand-alone batched PCR tridiagonal solve, HBM -> HBM, 5*L*w B per system.  The launches rotate
+    over `nsets` DISTINCT operand sets (4 x 335 MB = 1.34 GB at the default size, 5x the 256 MiB Infinity
+    Cache), so no launch can find its operands cached by the previous one: the rate is an HBM rate."""
     dtype = dtype or torch.float64
     w = 8 if dtype == torch.float64 else 4
     g = torch.Generator(device=dev)
     g.manual_seed(7)
-    ld = torch.rand((S, L), dtype=dtype, device=dev, generator=g) * 2 - 1
-    ud = torch.rand((S, L), dtype=dtype, device=dev, generator=g) * 2 - 1
-    d = torch.rand((S, L), dtype=dtype, device=dev, generator=g) * 1.5 + 2.5
-    b = torch.randn((S, L), dtype=dtype, device=dev, generator=g)
-    ld[:, 0] = 0
-    ud[:, -1] = 0
-    x = torch.empty_like(d)
-    for _ in range(5):
+    sets = []
+    for _ in range(nsets):
+        ld = torch.rand((S, L), dtype=dtype, device=dev, generator=g) * 2 - 1
+        ud = torch.rand((S, L), dtype=dtype, device=dev, generator=g) * 2 - 1
+        d = torch.rand((S, L), dtype=dtype, device=dev, generator=g) * 1.5 + 2.5
+        b = torch.randn((S, L), dtype=dtype, device=dev, generator=g)
+        ld[:, 0] = 0
+        ud[:, -1] = 0
+        sets.append((ld, d, ud, b, torch.empty_like(d)))
+    for i in range(2 * nsets):
+        ld, d, ud, b, x = sets[i % nsets]
         tdev.pcr_solve_device(ld, d, ud, b, x, flags=flags)
     torch.cuda.synchronize()
+    reps -= reps % nsets
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
+    for i in range(reps):
+        ld, d, ud, b, x = sets[i % nsets]
         tdev.pcr_solve_device(ld, d, ud, b, x, flags=flags)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    # residual check so a fast wrong kernel cannot hide
-    r = d * x
-    r[:, 1:] += ld[:, 1:] * x[:, :-1]
-    r[:, :-1] += ud[:, :-1] * x[:, 1:]
-    res = float((r - b).abs().max().item())
+    # residual check on every operand set so a fast wrong kernel cannot hide
+    res = 0.0
+    for ld, d, ud, b, x in sets:
+        r = d * x
+        r[:, 1:] += ld[:, 1:] * x[:, :-1]
+        r[:, :-1] += ud[:, :-1] * x[:, 1:]
+        res = max(res, float((r - b).abs().max().item()))
+        del r
     nbytes = 5 * L * w * S
     gbs = nbytes / (ms * 1e-3) / 1e9
     return {"kernel": "pcr_batched_kernel<%s,%d>" % ("double" if w == 8 else "float", L), "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "systems": S, "L": L,
             "bytes_per_launch": nbytes, "avg_launch_ms": ms, "systems_per_s": S / (ms * 1e-3),
+            "operand_sets": nsets, "operand_bytes_rotated": nsets * nbytes, "launches_timed": reps,
             "max_abs_residual": res}
 
 

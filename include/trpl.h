@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TRPL_ABI_VERSION 1
+#define TRPL_ABI_VERSION 2
 
 /* status codes */
 #define TRPL_OK 0
@@ -56,9 +56,18 @@ extern "C" {
                                      tol_exp 4-5 (fp32's residual floor is ~1e-7).  No reference exists for
                                      this mode (the reference is fp64 only) */
 
+#define TRPL_FLAG_KERNEL_PAIR 0x10    /* run the two-systems-per-wavefront stepper whatever the launch size (L = 128,
+                                        fp64, not STRICT -- anything else is TRPL_ERR_ARG) */
+#define TRPL_FLAG_KERNEL_SINGLE 0x20  /* run the one-system-per-wavefront stepper whatever the launch size */
+/* Without either bit the library picks by launch size (below).  The two FAST kernels agree to rounding
+ * (~1e-12 relative on a likelihood: their tridiagonal eliminations and node sums are ordered differently),
+ * not bit for bit, so a caller that cuts ONE logical batch into several launches -- sample shards over
+ * devices or ranks, blocks of a larger run -- and wants every sample's bits to be independent of the cut
+ * pins the variant of the whole batch: flags |= the bit trpl_kernel_variant(total systems, ...) names.
+ * trpl_loglik_multi and trpl_loglik_multi_dev do this themselves. */
+
 /* which time-stepper kernel a launch of nsys = S * C systems on L nodes taking `steps` time steps (T, or up
- * to the last observation in likelihood mode) with these flags runs on the current device (the choice
- * never changes a system's result beyond the rounding of its node sums) */
+ * to the last observation in likelihood mode) with these flags runs on the current device */
 #define TRPL_KERNEL_FAST 0        /* one system per wavefront */
 #define TRPL_KERNEL_FAST_PAIR 1   /* two systems per wavefront: L = 128, launches that keep the chip full */
 #define TRPL_KERNEL_STRICT 2
@@ -95,6 +104,31 @@ int trpl_solve_pl_dev(const double *matpar, int64_t S, double length_nm, double 
                       int32_t L, int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter,
                       const double *dN, void *plI, int32_t pl_elem_bytes, int64_t pl_ld,
                       int32_t *status, int64_t *iters_total, uint32_t flags, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * trpl_solve_pl_snap -- trpl_solve_pl that also fills pvSim's debug outputs plN, plP, plE
+ * (pvSimPCR.py:309 arguments 2-4; recording hook :283-288, disabled in that file; the working form is
+ * Legacy/pvSim.py:121-126 with the re-dimensionalisation of :169-171; consumer Testing/compare.py:22-31):
+ * the carrier densities on the L nodes and the field on the L + 1 edges of the state at the time steps
+ * snap_steps[i] -- the state PL(t) is computed from -- in nm^-3 and nm^-1.
+ *   snap_steps [n_snap] HOST int64 time-step indices (the reference's pT after bayeslib.py:123),
+ *              n_snap <= 16, any order.  Like Legacy's `pT.index(t)`, a step listed twice fills its
+ *              first slot only; a step outside [0, T] is never reached.  Slots that are not filled keep
+ *              the caller's contents.
+ *   plN, plP   [S][n_snap][L] fp64 (each nullable);  plE [S][n_snap][L+1] fp64 (nullable), E_0 = E_L = 0.
+ * A system flagged at step t (status = 1 + t) gets NaN in the slots of steps >= t, like its PL.
+ * Not available with TRPL_FLAG_FP32 (TRPL_ERR_UNSUPPORTED).
+ * ------------------------------------------------------------------------------------- */
+int trpl_solve_pl_snap(const double *matpar, int64_t S, double length_nm, double time_ns, int32_t L,
+                       int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN,
+                       void *plI, int32_t pl_elem_bytes, int64_t pl_ld, int32_t *status,
+                       int64_t *iters_total, const int64_t *snap_steps, int32_t n_snap, double *plN,
+                       double *plP, double *plE, uint32_t flags, int32_t device, double *seconds);
+int trpl_solve_pl_snap_dev(const double *matpar, int64_t S, double length_nm, double time_ns, int32_t L,
+                           int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN,
+                           void *plI, int32_t pl_elem_bytes, int64_t pl_ld, int32_t *status,
+                           int64_t *iters_total, const int64_t *snap_steps /*host*/, int32_t n_snap,
+                           double *plN, double *plP, double *plE, uint32_t flags, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * trpl_log10_clamp -- replaces probs.fastlog(plI, MIN, TPB, BPG)  (probs.py:64-85):
@@ -196,7 +230,9 @@ int trpl_loglik_obs_dev(const double *X, int64_t S, int32_t C, const double *len
  *             or NULL for 0..n_devices-1;  n_devices <= 0 with devices == NULL means every visible device.
  *   obs_hi / obs_dx / obs_h  all NULL: observations on the simulation grid (as trpl_loglik);
  *             all non-NULL: off-grid observations (as trpl_loglik_obs, plT must be 1).
- * Results are identical to a single-device call (each system is computed by one wavefront either way).
+ * The stepper variant is chosen once, from the size of the WHOLE batch (S * C systems), and pinned for every
+ * shard, and a system's result does not depend on which other systems share its launch or its wavefront:
+ * the results are bit-identical to a single-device call on the same batch, however it is cut.
  * ------------------------------------------------------------------------------------- */
 int trpl_loglik_multi(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns,
                       int32_t L, int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter,
@@ -205,10 +241,48 @@ int trpl_loglik_multi(const double *X, int64_t S, int32_t C, const double *lengt
                       int32_t *status, int64_t *iters_total, uint32_t flags, const int32_t *devices,
                       int32_t n_devices, double *seconds);
 
+/* ---------------------------------------------------------------------------------------
+ * trpl_multi_* / trpl_loglik_multi_dev -- the device-resident multi-GPU form: ONE process drives
+ * n_devices HIP devices; the samples are cut into contiguous shards (trpl_shard_bounds), every device solves
+ * its shard, and ONE collective -- an RCCL ncclAllGather over xGMI of ceil(S / n_devices) fp64 per rank --
+ * leaves the complete likelihood vector P[S] in the memory of EVERY device, where the posterior core
+ * (trpl_posterior_*_dev) consumes it.  Replaces what the reference's commented-out threaded driver
+ * (bayeslib.py:235-246) and its one-SLURM-task-per-GPU distribution (:131,:231) leave to separate .npy files.
+ *
+ * trpl_multi_create: ncclCommInitAll over `devices` (NULL: 0..n_devices-1; n_devices <= 0: every visible
+ *   device; ordinals must be distinct), one non-blocking stream per device.  RCCL (librccl.so.1) is bound at
+ *   this call, not at library load.  The handle is reusable and not thread-safe.
+ * trpl_loglik_multi_dev: per-device pointer tables (host arrays of n_devices device pointers, entry r valid
+ *   on devices[r]):
+ *     X[r]      [n_r][13]   that shard's samples, n_r = hi_r - lo_r of trpl_shard_bounds(S, n_devices, r)
+ *     dN[r]     [C][L]      replicated;  obs[r] [C][obs_ld] replicated (obs_hi / obs_dx / obs_h: tables of
+ *               replicated bracket arrays, or all three NULL for on-grid observations)
+ *     P_full[r] [S]         OUT on every device: P[s] = - sum_c sse[c][s], the all-gathered likelihoods
+ *     sse[r], status[r], iters_total[r]  [C][n_r] per-shard outputs (tables nullable, as are entries)
+ *   Everything is enqueued on the handle's streams (solve, all-gather, unpadding) and the call returns
+ *   without waiting; trpl_multi_synchronize waits for all devices.  The kernel variant is pinned from the
+ *   whole batch, as in trpl_loglik_multi.
+ * ------------------------------------------------------------------------------------- */
+typedef struct trpl_multi trpl_multi_t;
+int trpl_multi_create(const int32_t *devices, int32_t n_devices, trpl_multi_t **handle);
+int trpl_multi_destroy(trpl_multi_t *handle);
+int trpl_multi_device_count(const trpl_multi_t *handle);
+int trpl_multi_synchronize(trpl_multi_t *handle);
+int trpl_loglik_multi_dev(trpl_multi_t *handle, const double *const *X, int64_t S, int32_t C,
+                          const double *lengths_nm /*host*/, double time_ns, int32_t L, int64_t T, int32_t plT,
+                          int32_t tol_exp, int32_t max_iter, const double *const *dN, const double *const *obs,
+                          const int32_t *const *obs_hi, const double *const *obs_dx, const double *const *obs_h,
+                          int64_t obs_ld, const int64_t *n_obs /*host*/, double *const *P_full,
+                          double *const *sse, int32_t *const *status, int64_t *const *iters_total,
+                          uint32_t flags);
+
 /* [lo, hi) of shard `shard` of S samples cut into n_shards contiguous ranges; the first S % n_shards
  * shards hold one more.  The same rule shards the samples over ranks in the one-process-per-GPU
  * driver (bench.py, trpl_amd.dist.shard_bounds). */
 int trpl_shard_bounds(int64_t S, int32_t n_shards, int32_t shard, int64_t *lo, int64_t *hi);
+/* the shard whose range contains sample s (the inverse of trpl_shard_bounds; the unpadding pass after the
+ * all-gather of trpl_loglik_multi_dev indexes with it); -1 for arguments out of range */
+int64_t trpl_shard_of(int64_t S, int32_t n_shards, int64_t s);
 
 /* ---------------------------------------------------------------------------------------
  * trpl_sample_box -- replaces bayeslib.random_grid(minX, maxX, do_log, num_points) after
@@ -271,9 +345,13 @@ int trpl_posterior_hist_dev(const double *x, const double *y, const double *W, i
 /* ---------------------------------------------------------------------------------------
  * trpl_pcr_solve_batched_dev -- the stand-alone batched tridiagonal solve (unit U1 of the
  * measurement plan): S independent systems  ld[i] x[i-1] + d[i] x[i] + ud[i] x[i+1] = b[i],
- * i < L, by parallel cyclic reduction with pcreduce's elimination order (pvSimPCR.py:42-81),
- * operands and result in HBM, arrays [S][L], elem_bytes 8 (fp64) or 4 (fp32).  Inputs are
- * not modified.  Algorithmic traffic 5 * L * elem_bytes per system.
+ * i < L, the problem pcreduce solves (pvSimPCR.py:42-81), operands and result in HBM, arrays
+ * [S][L], elem_bytes 8 (fp64) or 4 (fp32).  Inputs are not modified.  With TRPL_FLAG_STRICT:
+ * parallel cyclic reduction in pcreduce's elimination order with IEEE divides, bit-identical to
+ * it.  Default (FAST): in-lane cyclic-reduction levels, then PCR on one row per lane with
+ * Newton-refined reciprocals, then back-substitution -- the same solution to rounding
+ * (both are exact eliminations), not the same operation order.
+ * Algorithmic traffic 5 * L * elem_bytes per system.
  * ------------------------------------------------------------------------------------- */
 int trpl_pcr_solve_batched_dev(const void *ld, const void *d, const void *ud, const void *b,
                                void *x, int64_t S, int32_t L, int32_t elem_bytes, uint32_t flags,

@@ -35,6 +35,9 @@ class OracleLib:
                                    C.c_int, C.c_int, _dp, C.c_void_p, C.c_int, C.c_long,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         d.oracle_pvsim.restype = C.c_int
+        d.oracle_pvsim_snap.argtypes = d.oracle_pvsim.argtypes[:-1] + [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                                      C.c_void_p, C.c_int]
+        d.oracle_pvsim_snap.restype = C.c_int
         d.oracle_fastlog.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_long, C.c_long, C.c_double]
         d.oracle_fastlog.restype = None
         d.oracle_prob.argtypes = [_dp, C.c_void_p, C.c_int, C.c_long, C.c_long, C.c_long, _dp, _dp]
@@ -88,8 +91,9 @@ def scales(length, time_ns, L, T):
 
 
 def pvsim(mat12, length, time_ns, L, T, ini, plT=1, tol=7, MAX=10000, dtype=np.float64, nthreads=1,
-          want_step_iters=False):
-    """pvSim(..., init_mode="points") semantics.  Returns dict(plI, status, iters_total, iters_max[, step_iters])."""
+          want_step_iters=False, snap_steps=None):
+    """pvSim(..., init_mode="points") semantics.  Returns dict(plI, status, iters_total, iters_max[, step_iters]
+    [, plN, plP, plE: the state at the time steps snap_steps, pvSimPCR.py:283-288 / Legacy/pvSim.py:121-126])."""
     mat12 = _f64(mat12)
     S = mat12.shape[0]
     assert mat12.shape[1] == 12
@@ -101,12 +105,19 @@ def pvsim(mat12, length, time_ns, L, T, ini, plT=1, tol=7, MAX=10000, dtype=np.f
     itot = np.zeros(S, dtype=np.int64)
     imax = np.zeros(S, dtype=np.int32)
     steps = np.zeros((S, T + 1), dtype=np.int32) if want_step_iters else None
-    rc = load().dll.oracle_pvsim(_ptr(mat12, _dp), S, float(length), float(time_ns), int(L), int(T), int(plT),
-                                 int(tol), int(MAX), _ptr(ini, _dp), _ptr(pl), pl.dtype.itemsize, ncol,
-                                 _ptr(status), _ptr(itot), _ptr(imax), _ptr(steps), int(nthreads))
+    snaps = np.ascontiguousarray(snap_steps if snap_steps is not None else [], dtype=np.int64)   # C long
+    ns = len(snaps)
+    plN, plP, plE = np.zeros((S, ns, L)), np.zeros((S, ns, L)), np.zeros((S, ns, L + 1))
+    rc = load().dll.oracle_pvsim_snap(_ptr(mat12, _dp), S, float(length), float(time_ns), int(L), int(T), int(plT),
+                                      int(tol), int(MAX), _ptr(ini, _dp), _ptr(pl), pl.dtype.itemsize, ncol,
+                                      _ptr(status), _ptr(itot), _ptr(imax), _ptr(steps), _ptr(snaps) if ns else None,
+                                      ns, _ptr(plN) if ns else None, _ptr(plP) if ns else None,
+                                      _ptr(plE) if ns else None, int(nthreads))
     if rc != 0:
         raise ValueError("oracle_pvsim: bad arguments")
     out = {"plI": pl, "status": status, "iters_total": itot, "iters_max": imax}
+    if ns:
+        out.update(plN=plN, plP=plP, plE=plE)
     if want_step_iters:
         out["step_iters"] = steps
     return out

@@ -321,7 +321,10 @@ def case_legacy_odeint():
     Length, L, T, dt = 311.0, 128, 240, 0.025
     Time = T * dt
     a_nm3, l_nm = 1e18 * 1e-21, 100.0
-    simPar = [Length, Time, L, T, 1, (0, 1), 7, 10000]
+    # state snapshots (Legacy/pvSim.py:121-126,:169-171): the steps on which BDF1/BDF2 and the BDF ramp
+    # coincide (0, 1, 2) and 3 / 10 / 30 / 100 % of the window (Testing/compare.py samples N, P, E there)
+    pT = (0, 1, 2, 7, 24, 72, 240)
+    simPar = [Length, Time, L, T, 1, pT, 7, 10000]
     with contextlib.redirect_stdout(io.StringIO()):
         itrs, (plN, plP, plE, plI) = legacy.pvSim(m10.copy(), simPar, (a_nm3, l_nm))
     # PV_tester2's recipe, non-dimensional (its __main__ :55-99)
@@ -350,7 +353,8 @@ def case_legacy_odeint():
         assert conv < 1e-7, (thr, conv)
         pl_ode[thr] = mp[thr, 4] * np.sum(N * P - mp[thr, 0] * mp[thr, 1], axis=1) / (dx ** 2 * dt)   # pvSim's units
     np.savez_compressed(os.path.join(OUT, "legacy_odeint.npz"), X=X, length=Length, L=L, T=T, time=Time,
-                        a_nm3=a_nm3, l_nm=l_nm, plI_legacy=plI, iters_legacy=np.array(itrs), plI_odeint=pl_ode)
+                        a_nm3=a_nm3, l_nm=l_nm, plI_legacy=plI, iters_legacy=np.array(itrs), plI_odeint=pl_ode,
+                        pT=np.array(pT), plN_legacy=plN, plP_legacy=plP, plE_legacy=plE)
 
 
 def case_posterior():

@@ -268,13 +268,24 @@ void oracle_scales(double length, double time_, int L, long T, double *scales /*
  *   step_iters [S][T+1] (optional) iterate()'s return per step.
  * Returns 0, or -1 on bad arguments / allocation failure.
  * ---------------------------------------------------------------------------------- */
-int oracle_pvsim(const double *matpar, long S, double length, double time_, int L, long T,
-                 int plT, int tol, int MAX, const double *inipar, void *plI, int plI_bytes,
-                 long ldp, int32_t *status, int64_t *iters_total, int32_t *iters_max,
-                 int32_t *step_iters, int nthreads)
+/*
+ * oracle_pvsim_snap additionally fills the reference's debug outputs plN, plP [S][n_snap][L] and
+ * plE [S][n_snap][L+1] (each nullable): the state of level k at the time steps snap_steps[i].  In
+ * pvSimPCR.py the recording hook is commented out (:283-288, right after the PL sum, reading level k);
+ * the working form is Legacy/pvSim.py:121-126 -- `if t in pT: ind = pT.index(t)` (first position of a
+ * repeated step), all L + 1 field edges copied -- with the re-dimensionalisation of :169-171
+ * (plN, plP /= dx**3; plE /= dx).  Slots that are not reached keep their contents; a flagged system's
+ * slots from its failing step on are NaN (oracle convention, like its PL).
+ */
+int oracle_pvsim_snap(const double *matpar, long S, double length, double time_, int L, long T,
+                      int plT, int tol, int MAX, const double *inipar, void *plI, int plI_bytes,
+                      long ldp, int32_t *status, int64_t *iters_total, int32_t *iters_max,
+                      int32_t *step_iters, const long *snap_steps, int n_snap, double *plN, double *plP,
+                      double *plE, int nthreads)
 {
-    if (L < 4 || (L & (L - 1)) || T < 1 || plT < 1 || (plI_bytes != 4 && plI_bytes != 8))
+    if (L < 4 || (L & (L - 1)) || T < 1 || plT < 1 || (plI_bytes != 4 && plI_bytes != 8) || n_snap < 0)
         return -1;
+    const double dx = length / L;                                               /* Legacy/pvSim.py:133 */
     double scales[12], dx3, plnorm;
     oracle_scales(length, time_, L, T, scales, &dx3, &plnorm);
     const double TOL = pow(10.0, -(double)tol);                                 /* :112 */
@@ -317,12 +328,30 @@ int oracle_pvsim(const double *matpar, long S, double length, double time_, int 
                 if (plI_bytes == 4) pf[t / plT] = (float)v / (float)plnorm;     /* :281,:393 */
                 else                pd[t / plT] = v / plnorm;
             }
+            for (int ind = 0; ind < n_snap; ind++) {                            /* :283-288, Legacy :121-126 */
+                if (snap_steps[ind] != t) continue;
+                const size_t at = (size_t)y * n_snap + ind;
+                for (int n = 0; n < L; n++) {
+                    if (plN) plN[at * L + n] = w.N[k * L + n] / dx3;            /* Legacy :169 */
+                    if (plP) plP[at * L + n] = w.P[k * L + n] / dx3;            /* :170 */
+                }
+                if (plE) for (int n = 0; n <= L; n++) plE[at * (L + 1) + n] = w.E[k * (L + 1) + n] / dx;   /* :171 */
+                break;                                                          /* pT.index(t): first match */
+            }
         }
         if (st) {
             for (long tt = t; tt <= T; tt++)
                 if (tt % plT == 0) {
                     if (plI_bytes == 4) pf[tt / plT] = NAN; else pd[tt / plT] = NAN;
                 }
+            for (int ind = 0; ind < n_snap; ind++) {
+                int first = 1;
+                for (int q = 0; q < ind; q++) if (snap_steps[q] == snap_steps[ind]) first = 0;
+                if (!first || snap_steps[ind] < t || snap_steps[ind] > T) continue;
+                const size_t at = (size_t)y * n_snap + ind;
+                for (int n = 0; n < L; n++) { if (plN) plN[at * L + n] = NAN; if (plP) plP[at * L + n] = NAN; }
+                if (plE) for (int n = 0; n <= L; n++) plE[at * (L + 1) + n] = NAN;
+            }
         }
         if (status) status[y] = st;
         if (iters_total) iters_total[y] = itot;
@@ -330,6 +359,15 @@ int oracle_pvsim(const double *matpar, long S, double length, double time_, int 
         ws_free(&w);
     }
     return fail ? -1 : 0;
+}
+
+int oracle_pvsim(const double *matpar, long S, double length, double time_, int L, long T,
+                 int plT, int tol, int MAX, const double *inipar, void *plI, int plI_bytes,
+                 long ldp, int32_t *status, int64_t *iters_total, int32_t *iters_max,
+                 int32_t *step_iters, int nthreads)
+{
+    return oracle_pvsim_snap(matpar, S, length, time_, L, T, plT, tol, MAX, inipar, plI, plI_bytes, ldp, status,
+                             iters_total, iters_max, step_iters, NULL, 0, NULL, NULL, NULL, nthreads);
 }
 
 /* ------------------------------------------------------------------------------------

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(trpl):
     for n in names:
         assert hasattr(dll, n), n
     assert set(trpl._abi.SIGNATURES) == set(names)       # the binding covers the whole header
-    assert dll.trpl_abi_version() == 1
+    assert dll.trpl_abi_version() == 2
 
 
 def test_cites_reference_interfaces():
@@ -100,3 +100,82 @@ def test_product_package_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "liboracle" not in src and "trpl_oracle" not in src, f
+
+
+def test_round2_entry_points_validate_without_a_device(trpl):
+    lib = trpl._abi.lib()
+    A = trpl._abi
+    z = np.zeros(16 * 12)
+    pl = np.zeros((1, 11))
+    steps = np.zeros(17, dtype=np.int64)
+    # more snapshots than the kernel argument block holds
+    rc = lib.trpl_solve_pl_snap(z.ctypes.data, 1, 100.0, 1.0, 16, 10, 1, 7, 100, z.ctypes.data, pl.ctypes.data, 8, 11,
+                                None, None, steps.ctypes.data, 17, None, None, None, 0, 0, None)
+    assert rc == A.ERR_ARG and b"n_snap" in lib.trpl_last_error()
+    rc = lib.trpl_solve_pl_snap_dev(z.ctypes.data, 1, 100.0, 1.0, 16, 10, 1, 7, 100, z.ctypes.data, pl.ctypes.data, 8,
+                                    11, None, None, None, 3, None, None, None, 0, None)
+    assert rc == A.ERR_ARG and b"snap_steps" in lib.trpl_last_error()
+    # kernel-variant bits: reported choice honours them, contradictory requests are refused at the launch
+    assert lib.trpl_kernel_variant(10, 128, 10, A.FLAG_KERNEL_PAIR) == A.KERNEL_FAST_PAIR
+    assert lib.trpl_kernel_variant(10 ** 7, 128, 80000, A.FLAG_KERNEL_SINGLE) == A.KERNEL_FAST
+    assert lib.trpl_kernel_variant(10 ** 7, 128, 80000, A.FLAG_KERNEL_PAIR | A.FLAG_STRICT) == A.KERNEL_STRICT
+    assert lib.trpl_kernel_variant(10 ** 7, 256, 80000, 0) == A.KERNEL_FAST          # the paired kernel is L = 128 only
+    assert A.pin_variant(0, 10 ** 7, 128, 80000) == A.FLAG_KERNEL_PAIR
+    assert A.pin_variant(0, 30, 128, 80000) == A.FLAG_KERNEL_SINGLE
+    assert A.pin_variant(A.FLAG_STRICT, 10 ** 7, 128, 80000) == A.FLAG_STRICT         # nothing to pin
+    assert A.pin_variant(A.FLAG_KERNEL_SINGLE, 10 ** 7, 128, 80000) == A.FLAG_KERNEL_SINGLE
+    with pytest.raises(ValueError):
+        A.kernel_flag("both")
+    # the inverse of trpl_shard_bounds
+    for S in (1, 5, 64, 1000, 65537):
+        for n in (1, 2, 3, 7, 8):
+            for s in {0, S // 3, S // 2, S - 1}:
+                r = lib.trpl_shard_of(S, n, s)
+                lo, hi = trpl.dist.shard_bounds(S, n, r)
+                assert lo <= s < hi
+    assert lib.trpl_shard_of(10, 3, 10) == -1 and lib.trpl_shard_of(10, 0, 1) == -1
+    # multi-device handle: argument errors come before any device or RCCL is touched
+    assert lib.trpl_multi_create(None, 0, None) == A.ERR_ARG
+    assert lib.trpl_multi_device_count(None) == 0 and lib.trpl_multi_destroy(None) == A.OK
+    assert lib.trpl_multi_synchronize(None) == A.ERR_ARG
+    assert lib.trpl_loglik_multi_dev(None, None, 0, 1, None, 1.0, 128, 10, 1, 7, 10, None, None, None, None, None, 1,
+                                     None, None, None, None, None, 0) == A.ERR_ARG
+
+
+def test_library_has_no_link_dependency_on_rccl():
+    """RCCL (0.5 GB) is bound with dlopen when trpl_multi_create is first called, never at load time."""
+    import subprocess
+    so = os.path.join(ROOT, "bayesian-inference-trpl_amd", "libtrpl_hip.so")
+    out = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
+    assert "NEEDED" in out and "rccl" not in out.lower()
+
+
+def test_concurrent_first_imports_build_the_library_once(tmp_path):
+    """Three processes that find no shared object at the same time (the ranks of torch.distributed.run on a
+    fresh checkout): the build is serialised by a lock file and re-checked under it -- one build runs, every
+    process loads a complete library.  The package tree is copied and its Makefile replaced by a stand-in that
+    logs each invocation and installs the real library the way the real Makefile does (temporary name + rename)."""
+    import shutil
+    import subprocess
+    import sys
+    pkg = os.path.join(ROOT, "bayesian-inference-trpl_amd")
+    dst = tmp_path / "pkg"
+    dst.mkdir()
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            shutil.copy(os.path.join(pkg, f), dst / f)
+    real = os.path.join(pkg, "libtrpl_hip.so")
+    (dst / "Makefile").write_text(
+        "libtrpl_hip.so:\n\techo build >> builds.log; sleep 1; cp %s $@.tmp.$$$$ && mv -f $@.tmp.$$$$ $@\n" % real)
+    code = ("import importlib.util, sys\n"
+            "spec = importlib.util.spec_from_file_location('trpl_tmp', %r, submodule_search_locations=[%r])\n"
+            "m = importlib.util.module_from_spec(spec); sys.modules['trpl_tmp'] = m; spec.loader.exec_module(m)\n"
+            "assert m._abi.lib().trpl_abi_version() == m._abi.ABI_VERSION\n"
+            "print('loaded', m._abi.LIB_PATH)\n") % (str(dst / "__init__.py"), str(dst))
+    env = {k: v for k, v in os.environ.items() if k not in ("TRPL_LIBRARY", "TRPL_AUTOBUILD")}
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True) for _ in range(3)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0 and str(dst) in o, e[-1500:]
+    assert (dst / "builds.log").read_text().count("build") == 1

@@ -1,0 +1,416 @@
+"""GPU parity tests added in round 2 (all through the C ABI):
+
+* the two-systems-per-wavefront stepper -- the kernel bench.py times -- DIRECTLY against the pinned CPU
+  oracle and the reference's own golden vectors (Power_scan and Twothick 311 / 2000 nm), forced per call
+  with TRPL_FLAG_KERNEL_PAIR and at a size where the library selects it by itself;
+* sharding invariance: a logical batch above the pair threshold cut into shards below it gives the same
+  bits as one launch (trpl_loglik_multi and the rank driver's pinned flags);
+* state snapshots plN / plP / plE against the oracle and Legacy/pvSim.py's own output;
+* the device-resident multi-GPU entry point (RCCL all-gather) on a one-rank communicator;
+* bench.py's N = 2 control flow as child processes (gloo) against the single-rank run.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def nthreads():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(n, 64))
+
+
+def above_floor(pl, rel=1e-12):
+    """PL points above the cancellation floor: >= rel * PL(0)."""
+    return np.abs(pl) >= rel * np.abs(pl[:, :1])
+
+
+# ------------------------------------------------------------------ paired kernel vs oracle / goldens
+def _check_pl_against(gpu, X12, length, Time, L, T, ini, want_pl, want_iters, kernel, rtol=1e-9):
+    pl, st, it, _ = gpu.solve_pl(X12, length, Time, L, T, ini, kernel=kernel)
+    assert not st.any()
+    ok = above_floor(want_pl)
+    assert ok.mean() > 0.95
+    err = np.max(np.abs(pl[ok] - want_pl[ok]) / np.abs(want_pl[ok]))
+    assert err < rtol, err
+    # iteration totals: +-1 % in sum (the FAST kernels may flip a knife-edge convergence decision)
+    assert abs(it.sum() / want_iters.sum() - 1) < 0.01
+    return err, float((it == want_iters).mean())
+
+
+def test_paired_kernel_reproduces_the_reference_goldens(gpu, golden):
+    """pvsim_power.npz / pvsim_twothick.npz (the reference's own pvSim outputs, incl. the 311 nm curves
+    with 567 iterations on step 0) pushed through the two-systems-per-wavefront kernel."""
+    lib = gpu._abi.lib()
+    assert lib.trpl_kernel_variant(5, 128, 160, gpu._abi.FLAG_KERNEL_PAIR) == gpu._abi.KERNEL_FAST_PAIR
+    assert lib.trpl_kernel_variant(5, 128, 160, 0) == gpu._abi.KERNEL_FAST      # too small to be picked unforced
+    for name in ("pvsim_power", "pvsim_twothick"):
+        g = golden(name)
+        X12, Time, L, T = g["X"][:, :12], float(g["time"]), int(g["L"]), int(g["T"])
+        lengths = g["lengths"] if "lengths" in g.files else np.full(len(g["ini"]), float(g["length"]))
+        for c in range(len(g["ini"])):
+            want, iters = g["plI"][c], g["iters"][c].sum(axis=1)             # iterate()'s return per step, summed
+            pl, st, it, _ = gpu.solve_pl(X12, float(lengths[c]), Time, L, T, g["ini"][c], kernel="pair")
+            assert not st.any() and np.all(np.abs(it - iters) <= 0.01 * iters + 1), (name, c)
+            assert np.max(np.abs(pl - want) / np.abs(want)) < 1e-9, (name, c)
+    # an odd sample count (the last wavefront holds one system) and a single sample
+    g = golden("pvsim_power")
+    for n in (1, 3):
+        pl, st, it, _ = gpu.solve_pl(g["X"][:n, :12], 2000.0, float(g["time"]), 128, int(g["T"]), g["ini"][1], kernel="pair")
+        assert np.max(np.abs(pl - g["plI"][1][:n]) / np.abs(g["plI"][1][:n])) < 1e-9
+
+
+def test_paired_kernel_vs_oracle_power_scan_at_natural_size(gpu, oracle):
+    """Power_scan, 5 123 samples x 3 curves (odd tail included): the library selects the paired kernel by
+    itself (asserted, not skipped); fused likelihoods against oracle.simulate_loglik on all host threads."""
+    w = gpu.workloads
+    S, T = 5123, 100
+    Time = T * 0.025
+    lib = gpu._abi.lib()
+    assert lib.trpl_kernel_variant(3 * S, 128, T, 0) == gpu._abi.KERNEL_FAST_PAIR
+    ini, lens = w.power_scan(128)
+    X = w.samples(S, seed=21)
+    mark = (w.MARKED_POINT * gpu.UNIT_CONVERSIONS)[None, :-1]
+    obs = [np.log10(oracle.pvsim(mark, lens[c], Time, 128, T, ini[c])["plI"][0]) for c in range(3)]
+    e_data = [([np.linspace(0, Time, T + 1)] * 3, obs)]
+    want = oracle.simulate_loglik(X, ini, lens, Time, 128, T, e_data, pl_dtype=np.float64, nthreads=nthreads())[0]
+    info = {}
+    P = gpu.loglik(X, ini, lens, Time, 128, T, obs, info=info)
+    assert not info["status"].any()
+    rel = np.abs(P - want) / np.abs(want)
+    assert rel.max() < 1e-8, rel.max()
+    # and the same systems' PL and iteration counts, one curve, straight from the paired kernel
+    r = oracle.pvsim(X[:, :12], lens[2], Time, 128, T, ini[2], nthreads=nthreads())
+    assert lib.trpl_kernel_variant(S, 128, T, gpu._abi.FLAG_KERNEL_PAIR) == gpu._abi.KERNEL_FAST_PAIR
+    err, same = _check_pl_against(gpu, X[:, :12], lens[2], Time, 128, T, ini[2], r["plI"], r["iters_total"], "pair")
+    assert same > 0.99, same
+
+
+def test_paired_kernel_vs_oracle_twothick(gpu, oracle):
+    """Twothick (311 / 2000 nm alternating, the 311 nm stencil ~40x stiffer): 320 samples x 6 curves through
+    the paired kernel against the oracle -- PL to 1e-9, iteration totals, likelihoods to 1e-8."""
+    w = gpu.workloads
+    S, T = 320, 100
+    Time = T * 0.025
+    ini, lens = w.twothick(128)
+    X = w.samples(S, seed=22)
+    mark = (w.MARKED_POINT * gpu.UNIT_CONVERSIONS)[None, :-1]
+    obs = [np.log10(oracle.pvsim(mark, lens[c], Time, 128, T, ini[c])["plI"][0]) for c in range(6)]
+    e_data = [([np.linspace(0, Time, T + 1)] * 6, obs)]
+    want = oracle.simulate_loglik(X, ini, lens, Time, 128, T, e_data, pl_dtype=np.float64, nthreads=nthreads())[0]
+    info = {}
+    P = gpu.loglik(X, ini, lens, Time, 128, T, obs, info=info, kernel="pair")
+    assert not info["status"].any()
+    assert np.max(np.abs(P - want) / np.abs(want)) < 1e-8
+    for c in (0, 4):                               # 311 nm at the lowest and at the highest power
+        r = oracle.pvsim(X[:, :12], lens[c], Time, 128, T, ini[c], nthreads=nthreads())
+        assert r["iters_max"].max() > 100          # the stiff start is really in the comparison
+        err, same = _check_pl_against(gpu, X[:, :12], lens[c], Time, 128, T, ini[c], r["plI"], r["iters_total"], "pair")
+        assert same > 0.97, (c, same)
+    # the one-system kernel on the same inputs: both FAST kernels sit within rounding of the oracle
+    P1 = gpu.loglik(X, ini, lens, Time, 128, T, obs, kernel="single")
+    assert np.max(np.abs(P1 - want) / np.abs(want)) < 1e-8
+
+
+def test_variant_flags_are_validated(gpu):
+    w = gpu.workloads
+    ini, lens = w.power_scan(64)
+    X = w.samples(4)
+    with pytest.raises(gpu.TrplError):             # the paired kernel exists for L = 128 only
+        gpu.solve_pl(X[:, :12], lens[0], 0.25, 64, 10, ini[0], kernel="pair")
+    ini, lens = w.power_scan(128)
+    with pytest.raises(gpu.TrplError):
+        gpu.solve_pl(X[:, :12], lens[0], 0.25, 128, 10, ini[0], kernel="pair", strict=True)
+    lib = gpu._abi.lib()
+    pl = np.zeros((4, 11))
+    both = gpu._abi.FLAG_KERNEL_PAIR | gpu._abi.FLAG_KERNEL_SINGLE
+    rc = lib.trpl_solve_pl(X[:, :12].copy().ctypes.data, 4, 2000.0, 0.25, 128, 10, 1, 7, 100, ini[0].ctypes.data,
+                           pl.ctypes.data, 8, 11, None, None, both, 0, None)
+    assert rc == gpu._abi.ERR_ARG
+
+
+# ------------------------------------------------------------------ sharding invariance
+def test_sharded_batch_equals_single_launch_across_the_pair_threshold(gpu):
+    """The whole batch is above the paired kernel's threshold, every shard is below it: the variant is a
+    property of the logical batch, so trpl_loglik_multi (4 shards) and a rank driver that pins its flags
+    from the total (dist / bench.py) return bit for bit the single launch's likelihoods."""
+    w = gpu.workloads
+    S, T, Time = 5124, 40, 1.0
+    lib = gpu._abi.lib()
+    A = gpu._abi
+    assert lib.trpl_kernel_variant(3 * S, 128, T, 0) == A.KERNEL_FAST_PAIR
+    assert lib.trpl_kernel_variant(3 * (S // 4), 128, T, 0) == A.KERNEL_FAST
+    ini, lens = w.power_scan(128)
+    X = w.samples(S, seed=31)
+    obs = [np.full(T + 1, 20.0) - 0.01 * np.arange(T + 1)] * 3
+    one, multi = {}, {}
+    want = gpu.loglik(X, ini, lens, Time, 128, T, obs, info=one)
+    got = gpu.loglik(X, ini, lens, Time, 128, T, obs, info=multi, devices=[0, 0, 0, 0])
+    assert np.array_equal(got, want)
+    for k in ("sse", "status", "iters_total"):
+        assert np.array_equal(multi[k], one[k]), k
+    # the rank driver: each rank launches its own shard with the flags pinned from the TOTAL
+    flags = A.pin_variant(0, 3 * S, 128, T)
+    assert flags == A.FLAG_KERNEL_PAIR
+    for world in (2, 8):
+        parts = []
+        for r in range(world):
+            lo, hi = gpu.dist.shard_bounds(S, world, r)
+            parts.append(gpu.loglik(X[lo:hi], ini, lens, Time, 128, T, obs, kernel="pair"))
+        assert np.array_equal(np.concatenate(parts), want)
+    # without the pin the shards would run the other kernel: close (rounding), not identical -- the
+    # documented reason for pinning
+    lo, hi = gpu.dist.shard_bounds(S, 4, 1)
+    unpinned = gpu.loglik(X[lo:hi], ini, lens, Time, 128, T, obs)
+    assert np.allclose(unpinned, want[lo:hi], rtol=1e-10, atol=0)
+    # a small batch stays on the one-system kernel in every shard
+    small = gpu.loglik(X[:300], ini, lens, Time, 128, T, obs)
+    assert np.array_equal(gpu.loglik(X[:300], ini, lens, Time, 128, T, obs, devices=[0, 0, 0]), small)
+
+
+def test_multi_validates_observation_brackets_like_the_single_device_call(gpu):
+    w = gpu.workloads
+    ini, lens = w.power_scan(128)
+    X = w.samples(6)
+    T, Time = 40, 1.0
+    lib = gpu._abi.lib()
+    A = gpu._abi
+    n = 5
+    obs = np.full((3, n), 19.0)
+    n_obs = np.full(3, n, dtype=np.int64)
+    hi = np.tile(np.array([3, 2, 5, 7, 9], dtype=np.int32), (3, 1))        # not sorted
+    dx = np.full((3, n), 0.01)
+    h = np.full((3, n), 0.025)
+    P = np.zeros(6)
+    dev = np.zeros(2, dtype=np.int32)
+
+    def call(hi_, dx_, h_):
+        return lib.trpl_loglik_multi(X.ctypes.data, 6, 3, lens.ctypes.data, Time, 128, T, 1, 7, 1000, ini.ctypes.data,
+                                     obs.ctypes.data, hi_.ctypes.data, dx_.ctypes.data, h_.ctypes.data, n,
+                                     n_obs.ctypes.data, P.ctypes.data, None, None, None, 0, dev.ctypes.data, 2, None)
+    assert call(hi, dx, h) == A.ERR_ARG and b"sorted" in lib.trpl_last_error()
+    good = np.tile(np.array([2, 3, 5, 7, 9], dtype=np.int32), (3, 1))
+    bad_hi = good.copy(); bad_hi[1, 4] = T + 1
+    assert call(bad_hi, dx, h) == A.ERR_ARG
+    bad_h = h.copy(); bad_h[2, 0] = 0.0
+    assert call(good, dx, bad_h) == A.ERR_ARG
+    bad_dx = dx.copy(); bad_dx[0, 1] = 0.05                                # beyond the bracket
+    assert call(good, bad_dx, h) == A.ERR_ARG
+    assert call(good, dx, h) == A.OK
+    with pytest.raises(gpu.TrplError):                                      # through the Python driver too
+        gpu.loglik(X, ini, lens, Time, 128, T, [np.full(3, 19.0)] * 3, times=[np.array([0.1, 0.2, 2.0])] * 3,
+                   devices=[0, 0])
+
+
+# ------------------------------------------------------------------ state snapshots (f-4)
+SNAPS = [0, 1, 2, 7, 24, 72, 100, 100, 400]          # a repeated step and one beyond T
+
+
+def _snap_case(gpu, oracle, **kw):
+    w = gpu.workloads
+    ini, lens = w.twothick(128)
+    X = w.samples(7, seed=41)[:, :12]
+    T, Time = 100, 2.5
+    want = oracle.pvsim(X, lens[0], Time, 128, T, ini[0], snap_steps=SNAPS)
+    got = {}
+    pl, st, it, _ = gpu.solve_pl(X, lens[0], Time, 128, T, ini[0], snap_steps=SNAPS, snapshots=got, **kw)
+    return want, got, pl, st, it
+
+
+def test_snapshots_strict_are_bit_identical_to_the_oracle(gpu, oracle):
+    """plN / plP / plE of the STRICT kernel: the reference's state bit for bit at every recorded step, the
+    repeated step fills its first slot only and the step beyond T is never reached (Legacy/pvSim.py:121-126)."""
+    want, got, pl, st, it = _snap_case(gpu, oracle, strict=True)
+    assert np.array_equal(pl, want["plI"]) and np.array_equal(it, want["iters_total"])
+    for k in ("plN", "plP", "plE"):
+        assert got[k].shape == want[k].shape
+        assert np.array_equal(got[k], want[k]), k
+    assert (got["plN"][:, 7] == 0).all() and (got["plN"][:, 8] == 0).all()          # untouched slots
+    assert (got["plE"][:, :, 0] == 0).all() and (got["plE"][:, :, 128] == 0).all()   # E_0 = E_L = 0
+    assert (got["plN"][:, :7] > 0).all()
+
+
+@pytest.mark.parametrize("kernel", ["single", "pair"])
+def test_snapshots_fast_kernels_vs_oracle(gpu, oracle, kernel):
+    want, got, pl, st, it = _snap_case(gpu, oracle, kernel=kernel)
+    assert not st.any()
+    for k in ("plN", "plP"):
+        assert np.max(np.abs(got[k][:, :7] - want[k][:, :7]) / want[k][:, :7]) < 1e-9, k
+        assert (got[k][:, 7:] == 0).all()
+    # the field is the integral of the (tiny) charge imbalance P - N: compare against the largest field
+    # of the snapshot
+    scale = np.abs(want["plE"]).max(axis=2, keepdims=True)
+    assert np.max(np.abs(got["plE"][:, 1:7] - want["plE"][:, 1:7]) / scale[:, 1:7]) < 1e-6
+    assert (got["plE"][:, 0] == 0).all()                                            # t = 0: no field yet
+
+
+def test_snapshots_vs_legacy_pvsim_golden_and_dropin_signature(gpu, golden):
+    """Against what Legacy/pvSim.pvSim itself returned (legacy_odeint.npz: BDF2 / Thomas, no Auger,
+    exponential excitation): the steps on which the schemes coincide (t = 0, 1, 2) to 1e-12 for N and P,
+    afterwards within the BDF-order gap at the five Testing/compare.py:22 sample points; through the
+    drop-in pvSim(), which fills the caller's plN / plP / plE like the reference's signature promises."""
+    g = golden("legacy_odeint")
+    X = g["X"].copy()
+    X[:, 7:9] = 0.0                                                         # Legacy has no Auger terms
+    L, T, Length, Time = int(g["L"]), int(g["T"]), float(g["length"]), float(g["time"])
+    pT = tuple(int(v) for v in g["pT"])
+    S = len(X)
+    for strict in (True, False):
+        plI = np.empty((S, T + 1))
+        plN = np.zeros((S, len(pT), L)); plP = np.zeros((S, len(pT), L)); plE = np.zeros((S, len(pT), L + 1))
+        gpu.pvSim(plI, plN, plP, plE, X[:, :12], [Length, Time, L, T, 1, pT, 7, 10000],
+                  (float(g["a_nm3"]), float(g["l_nm"])), (128,), 2048, 1, init_mode="exp", strict=strict)
+        for mine, ref in ((plN, g["plN_legacy"]), (plP, g["plP_legacy"])):
+            assert np.max(np.abs(mine[:, :3] - ref[:, :3]) / ref[:, :3]) < 1e-12
+            locs = (np.array([0.1, 0.3, 0.5, 0.7, 0.9]) * L).astype(int)     # Testing/compare.py:22
+            for thr in range(S):
+                a, b = mine[thr][3:, locs].ravel(), ref[thr][3:, locs].ravel()
+                assert np.linalg.norm(a - b) / np.linalg.norm(b) < 5e-3      # compare.py:43's norm
+        scale = np.abs(g["plE_legacy"][:, :3]).max(axis=2, keepdims=True)
+        scale[scale == 0] = 1.0
+        assert np.max(np.abs(plE[:, :3] - g["plE_legacy"][:, :3]) / scale) < 1e-5
+        assert np.max(np.abs(plI[:, :3] / g["plI_legacy"][:, :3] - 1)) < 1e-13
+    # the dummies bayeslib passes (shape (S, 2, L), bayeslib.py:141-143) do not match len(pT): ignored
+    junk = np.full((S, 2, L), 7.0)
+    gpu.pvSim(plI, junk, junk.copy(), np.full((S, 2, L + 1), 7.0), X[:, :12], [Length, Time, L, 16, 1, pT, 7, 10000],
+              (float(g["a_nm3"]), float(g["l_nm"])), init_mode="exp")
+    assert (junk == 7.0).all()
+
+
+def test_snapshots_nonconvergence_small_grids_and_device_entry(gpu, oracle):
+    """A system flagged at step t gets NaN from that step's slot on (like its PL) while its wavefront
+    partner's snapshots are complete; L = 16 / 64 (blocked layouts); the device-resident entry point."""
+    import torch
+    w = gpu.workloads
+    ini, lens = w.twothick(128)
+    X = w.samples(64, seed=43)[:, :12]
+    T, Time = 30, 0.75
+    steps = [0, 3, 10, 30]
+    for kernel in ("single", "pair"):
+        got = {}
+        pl, st, it, _ = gpu.solve_pl(X, lens[4], Time, 128, T, ini[4], MAX=60, snap_steps=steps, snapshots=got,
+                                     kernel=kernel)
+        want = oracle.pvsim(X, lens[4], Time, 128, T, ini[4], MAX=60, snap_steps=steps, nthreads=4)
+        assert np.array_equal(st, want["status"]) and 0 < (st > 0).sum() < len(st)
+        for k in ("plN", "plP", "plE"):
+            assert np.array_equal(np.isnan(got[k]), np.isnan(want[k])), (kernel, k)
+        live = st == 0
+        assert np.max(np.abs(got["plN"][live] - want["plN"][live]) / want["plN"][live]) < 1e-9
+    for L in (16, 64):
+        ini_s, lens_s = w.power_scan(L)
+        want = oracle.pvsim(X[:5], lens_s[1], 0.5, L, 20, ini_s[1], snap_steps=[20, 0, 5])
+        for strict in (True, False):
+            got = {}
+            gpu.solve_pl(X[:5], lens_s[1], 0.5, L, 20, ini_s[1], snap_steps=[20, 0, 5], snapshots=got, strict=strict)
+            for k in ("plN", "plP", "plE"):
+                if strict:
+                    assert np.array_equal(got[k], want[k]), (L, k)
+                else:
+                    scale = np.abs(want[k]).max(axis=2, keepdims=True) + 1e-300
+                    assert np.max(np.abs(got[k] - want[k]) / scale) < 1e-6, (L, k)
+    # device-resident form, unordered steps, only plP requested
+    dev = torch.device("cuda", 0)
+    Xd = torch.from_numpy(X[:9].copy()).to(dev)
+    pl_d = torch.empty((9, T + 1), dtype=torch.float64, device=dev)
+    plP_d = torch.zeros((9, 3, 128), dtype=torch.float64, device=dev)
+    gpu.device.solve_pl_snap_device(Xd, lens[1], Time, 128, T, torch.from_numpy(ini[1]).to(dev), pl_d, [10, 0, 3],
+                                    plP=plP_d, flags=gpu.FLAG_STRICT)
+    torch.cuda.synchronize()
+    want = oracle.pvsim(X[:9], lens[1], Time, 128, T, ini[1], snap_steps=[10, 0, 3])
+    assert np.array_equal(plP_d.cpu().numpy(), want["plP"])
+    with pytest.raises(gpu.TrplError):                                      # not built for the fp32 stepper
+        gpu.solve_pl(X[:4], lens[1], Time, 128, T, ini[1], snap_steps=[0], snapshots={}, fp32=True, tol=4)
+
+
+# ------------------------------------------------------------------ device-resident multi-GPU (RCCL)
+@pytest.mark.parametrize("force_pad", [False, True])
+def test_multi_device_resident_allgather_on_a_one_rank_communicator(gpu, force_pad):
+    """trpl_multi_create (ncclCommInitAll, RCCL bound at first use) + trpl_loglik_multi_dev with the one device
+    of this box: the all-gathered P[S] left in device memory equals trpl_loglik_dev's, per-shard outputs
+    included; with TRPL_MULTI_FORCE_PAD the padded exchange + unpadding pass runs instead of the direct one.
+    (The force_pad case is a child process: the knob is read once per process.)"""
+    if force_pad:
+        env = dict(os.environ, TRPL_MULTI_FORCE_PAD="1", PYTHONPATH=ROOT)
+        code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_round2 as t; "
+                "import trpl_amd; t._multi_dev_check(trpl_amd); print('PAD-OK')") % (ROOT, os.path.join(ROOT, "tests"))
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "PAD-OK" in out.stdout, out.stderr[-2000:]
+        return
+    _multi_dev_check(gpu)
+
+
+def _multi_dev_check(gpu):
+    import torch
+    w = gpu.workloads
+    dev = torch.device("cuda", 0)
+    ini, lens = w.power_scan(128)
+    S, T, Time = 777, 60, 1.5
+    X = torch.from_numpy(w.samples(S, seed=51)).to(dev)
+    ini_d = torch.from_numpy(ini).to(dev)
+    obs = torch.full((3, T + 1), 20.0, dtype=torch.float64, device=dev) - 0.01 * torch.arange(T + 1, device=dev)
+    P = torch.zeros(S, dtype=torch.float64, device=dev)
+    sse = torch.empty((3, S), dtype=torch.float64, device=dev)
+    st = torch.empty((3, S), dtype=torch.int32, device=dev)
+    it = torch.empty((3, S), dtype=torch.int64, device=dev)
+    gpu.device.loglik_device(X, ini_d, lens, Time, 128, T, obs, [T + 1] * 3, P, sse, st, it)
+    torch.cuda.synchronize()
+    with gpu.device.MultiDevice([0]) as md:
+        assert md.n == 1
+        Pf = torch.full((S,), 123.0, dtype=torch.float64, device=dev)
+        sse2, st2, it2 = torch.empty_like(sse), torch.empty_like(st), torch.empty_like(it)
+        for _ in range(2):                                                  # the handle is reusable
+            md.loglik([X], [ini_d], lens, Time, 128, T, [obs], [T + 1] * 3, [Pf], sse=[sse2], status=[st2],
+                      iters_total=[it2])
+            md.synchronize()
+            assert torch.equal(Pf, P) and torch.equal(sse2, sse) and torch.equal(st2, st) and torch.equal(it2, it)
+        Pg = torch.zeros(S, dtype=torch.float64, device=dev)               # optional outputs left out
+        md.loglik([X], [ini_d], lens, Time, 128, T, [obs], [T + 1] * 3, [Pg])
+        md.synchronize()
+        assert torch.equal(Pg, P)
+        # off-grid observations through the same entry point
+        times = np.sort(np.random.default_rng(3).uniform(0, Time, 25))
+        hi, dx, h = gpu.bracket_times(np.linspace(0, Time, T + 1), times)
+        rep = lambda a, dt: torch.from_numpy(np.ascontiguousarray(np.tile(a, (3, 1)))).to(dev).to(dt)
+        o2 = torch.full((3, 25), 19.5, dtype=torch.float64, device=dev)
+        hi_d, dx_d, h_d = rep(hi, torch.int32), rep(dx, torch.float64), rep(h, torch.float64)
+        P2 = torch.zeros(S, dtype=torch.float64, device=dev)
+        sse3 = torch.empty((3, S), dtype=torch.float64, device=dev)
+        gpu.device.loglik_obs_device(X, ini_d, lens, Time, 128, T, o2, hi_d, dx_d, h_d, [25] * 3, P2, sse3)
+        md.loglik([X], [ini_d], lens, Time, 128, T, [o2], [25] * 3, [Pg], obs_hi=[hi_d], obs_dx=[dx_d], obs_h=[h_d])
+        md.synchronize()
+        torch.cuda.synchronize()
+        assert torch.equal(Pg, P2)
+    with pytest.raises(gpu.TrplError):                                      # one RCCL rank per device
+        gpu.device.MultiDevice([0, 0])
+
+
+# ------------------------------------------------------------------ bench.py, N = 2 control flow
+def test_bench_two_rank_rehearsal_gathers_the_single_rank_likelihoods(gpu, tmp_path):
+    """bench.py --gpus 2 --backend gloo as fresh child processes sharing this box's GPU (the N > 1 path:
+    sample shards, pinned kernel variant, all-gather, max-over-ranks timing) must print one contract line
+    and gather exactly the likelihood vector a single rank computes for the same 4 096 samples."""
+    common = ["--steps", "1", "--warmup", "0", "--T", "200", "--no-cpu-baseline", "--no-pcr", "--no-full-length"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", TRPL_AUTOBUILD="0")
+    p1, p2 = str(tmp_path / "p1.npy"), str(tmp_path / "p2.npy")
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--samples-per-gpu", "4096",
+                         "--dump-p", p1] + common, env=env, capture_output=True, text=True, timeout=900)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                         "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"),
+                         "--gpus", "2", "--backend", "gloo", "--samples-per-gpu", "2048", "--dump-p", p2] + common,
+                        env=env, capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    line1 = json.loads(r1.stdout.strip().splitlines()[-1])
+    line2 = json.loads(r2.stdout.strip().splitlines()[-1])
+    assert line2["n_gpus"] == 2 and line2["scaling"] == "weak" and line2["config"]["samples_total"] == 4096
+    assert line1["config"]["samples_total"] == 4096
+    assert line2["nonconverged_systems"] == line1["nonconverged_systems"] == 0
+    a, b = np.load(p1), np.load(p2)
+    assert a.shape == b.shape == (1, 4096) and np.array_equal(a, b)

@@ -155,6 +155,41 @@ def test_against_legacy_pvsim_and_odeint(oracle, golden):
     assert np.max(np.abs(pl[:, -1] / g["plI_odeint"][:, -1] - 1)) < 5e-4
 
 
+def test_state_snapshots_against_legacy_pvsim(oracle, golden):
+    """The oracle's plN / plP / plE (pvSimPCR.py:283-288 restated; Legacy/pvSim.py:121-126,:169-171) against
+    what Legacy/pvSim.pvSim itself returned: on the steps where BDF1 / BDF2 and the BDF ramp coincide
+    (t = 0, 1, 2) N and P agree to 1e-12 (Thomas vs PCR rounding) and the field -- the integral of the tiny
+    charge imbalance P - N, so 1e-14 of N is 1e-7 of E -- to 1e-6 of its largest value; afterwards the
+    densities stay within the BDF-order gap (< 5e-3) at the Testing/compare.py:22 sample points."""
+    g = golden("legacy_odeint")
+    X, L, T, length, Time, dN = _legacy_inputs(g)
+    pT = [int(v) for v in g["pT"]]
+    r = oracle.pvsim(X[:, :-1], length, Time, L, T, dN, snap_steps=pT)
+    for k in ("plN", "plP"):
+        ref = g[k + "_legacy"]
+        assert r[k].shape == ref.shape
+        assert np.max(np.abs(r[k][:, :3] - ref[:, :3]) / ref[:, :3]) < 1e-12
+        locs = (np.array([0.1, 0.3, 0.5, 0.7, 0.9]) * L).astype(int)
+        for thr in range(len(X)):
+            a, b = r[k][thr][3:, locs].ravel(), ref[thr][3:, locs].ravel()
+            assert np.linalg.norm(a - b) / np.linalg.norm(b) < 5e-3
+    refE = g["plE_legacy"]
+    assert (r["plE"][:, 0] == 0).all() and (refE[:, 0] == 0).all()           # t = 0: no field yet
+    scale = np.abs(refE[:, 1:3]).max(axis=2, keepdims=True)
+    assert np.max(np.abs(r["plE"][:, 1:3] - refE[:, 1:3]) / scale) < 1e-6
+    assert (r["plE"][:, :, 0] == 0).all() and (r["plE"][:, :, L] == 0).all()   # E_0 = E_L = 0 (pvSimPCR.py:205)
+    # the snapshot of step t is the state PL(t) is computed from: rebuild PL from it (pvSimPCR.py:276-281,:393)
+    dx = length / L
+    rate = X[:, 4]
+    for i, t in enumerate(pT):
+        pl = rate * dx * np.sum(r["plN"][:, i] * r["plP"][:, i] - (X[:, 0] * X[:, 1])[:, None], axis=1)
+        assert np.max(np.abs(pl / r["plI"][:, t] - 1)) < 1e-9
+    # a repeated step fills its first slot only, a step beyond T none (Legacy `pT.index(t)`)
+    r2 = oracle.pvsim(X[:1, :-1], length, Time, L, 20, dN, snap_steps=[5, 5, 40, 0])
+    assert (r2["plN"][0, 1] == 0).all() and (r2["plN"][0, 2] == 0).all() and (r2["plN"][0, 0] > 0).all()
+    assert np.array_equal(r2["plN"][0, 3], r["plN"][0, 0])
+
+
 def test_posterior_core_restatement_matches_the_reference(golden):
     """oracle/posterior.py against the outputs of the reference's own Visualization/utils.py functions
     (normalize, w_*, covariance, credible_interval, marginalize_1D/2D; golden made by gen_golden.py)."""

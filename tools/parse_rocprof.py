@@ -54,6 +54,9 @@ for k, d in traffic.items():
               "hbm_read_bytes_per_launch_corrected": fetch * 1024 * 2,
               "hbm_write_bytes_per_launch": write * 1024,
               "hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024}
+# what the PMC passes ran (bench.py reads this back to label `traffic`)
+out["_meta"] = {"tag": tag, "T": bench["config"].get("T"), "workload": bench["config"].get("workload"),
+                "command": "bench.py --no-cpu-baseline --no-full-length (tools/profile_round.sh)"}
 json.dump(out, open(os.path.join(dst, tag + "_hbm_traffic.json"), "w"), indent=1)
-print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in out.items()}, indent=1))
+print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in out.items() if k != "_meta"}, indent=1))
 print("value", bench["value"], "pcr frac", bench.get("roofline_hbm_pcr", {}).get("frac"))
