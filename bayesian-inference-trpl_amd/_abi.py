@@ -15,8 +15,8 @@ LIB_PATH = os.environ.get("TRPL_LIBRARY", os.path.join(_HERE, "libtrpl_hip.so"))
 # status codes / flags (include/trpl.h)
 OK, ERR_ARG, ERR_HIP, ERR_NODEVICE, ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 FLAG_STRICT, FLAG_PL_F32, FLAG_NORMALIZE, FLAG_FP32 = 0x1, 0x2, 0x4, 0x8
-FLAG_KERNEL_PAIR, FLAG_KERNEL_SINGLE = 0x10, 0x20
-KERNEL_FAST, KERNEL_FAST_PAIR, KERNEL_STRICT, KERNEL_FP32 = 0, 1, 2, 3
+FLAG_KERNEL_PAIR, FLAG_KERNEL_SINGLE, FLAG_MIXED = 0x10, 0x20, 0x40
+KERNEL_FAST, KERNEL_FAST_PAIR, KERNEL_STRICT, KERNEL_FP32, KERNEL_MIXED = 0, 1, 2, 3, 4
 ABI_VERSION = 2
 MAX_SNAPS = 16
 
@@ -113,6 +113,33 @@ def ensure_built():
         _build_if_missing()
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  A PyTorch-ROCm wheel bundles its own libamdhip64 / libhsa-runtime64 and
+    loads them by path; if libtrpl_hip.so has pulled in /opt/rocm's copies first, a later `import torch` maps a
+    SECOND runtime and torch.cuda reports no GPU (measured on this image, tools/load_order_probe.py).  So when
+    torch is installed and not yet imported, its two runtime libraries are loaded first (without importing
+    torch): libtrpl_hip.so's `NEEDED libamdhip64.so.7` then binds to them by soname, whichever of the two is
+    imported first.  TRPL_HIP_RUNTIME=system skips this (pure-ctypes callers that never import torch)."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("TRPL_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.isfile(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def lib():
     """Load libtrpl_hip.so once; raise loudly if it is absent and cannot be built."""
     global _lib
@@ -122,6 +149,7 @@ def lib():
         if not os.path.isfile(LIB_PATH):
             raise ImportError("%s not found: build it with `make -C %s` (hipcc, gfx950); "
                               "there is no CPU fallback" % (LIB_PATH, _HERE))
+        _share_torch_hip_runtime()
         dll = C.CDLL(LIB_PATH)
         dll.trpl_abi_version.restype = C.c_int
         if dll.trpl_abi_version() != ABI_VERSION:

@@ -100,6 +100,44 @@ __device__ __forceinline__ bool residual_below(const double (&l)[NR], const doub
 }
 
 
+// MIXED arithmetic (TRPL_FLAG_MIXED): the same test as residual_below<2> and, beside it, the residual itself,
+// r = b - A c in fp64 -- the right-hand side of the correction equation A delta = r that is then solved in fp32.
+template <int NR>
+__device__ __forceinline__ bool residual_vec(const double (&l)[NR], const double (&dg)[NR], const double (&u)[NR],
+                                             const double (&b)[NR], const double (&c)[NR], double TOL, int ln,
+                                             double (&r)[NR])
+{
+    double cm[NR], cp[NR], q[NR];
+    nbrB_dn<double, NR, 1>(c, cm, ln);
+    nbrB_up<double, NR, 1>(c, cp, ln);
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        r[j] = b[j] - (l[j] * cm[j] + dg[j] * c[j] + u[j] * cp[j]);
+        q[j] = __builtin_fma(-TOL, fabs(b[j]), fabs(r[j]));
+    }
+    return sum_nodes<2, NR, 64>(q) < 0.0;
+}
+
+// One correction of iterate c of the system (lo, dg, up | bb): delta from the fp32 solve of A delta = r,
+// c += delta in fp64.  The fp32 solve has a relative error of ~cond(A) * 6e-8 ON THE CORRECTION, which is
+// itself O(change per time step) in the first and O(tolerance) in the last inner iteration: the state keeps
+// fp64 accuracy, the residual that decides convergence is the fp64 one.
+template <int NR>
+__device__ __forceinline__ bool correct_mixed(const double (&lo)[NR], const double (&dg)[NR], const double (&up)[NR],
+                                              const double (&bb)[NR], double (&c)[NR], double TOL, int ln, float *xch)
+{
+    double r[NR];
+    const bool ok = residual_vec<NR>(lo, dg, up, bb, c, TOL, ln, r);
+    float lf[NR], df[NR], uf[NR], rf[NR], xf[NR];
+#pragma unroll
+    for (int j = 0; j < NR; j++) { lf[j] = (float)lo[j]; df[j] = (float)dg[j]; uf[j] = (float)up[j]; rf[j] = (float)r[j]; }
+    cr_pcr_solve<float, NR>(lf, df, uf, rf, xf, ln, xch);
+#pragma unroll
+    for (int j = 0; j < NR; j++) c[j] += (double)xf[j];
+    return ok;
+}
+
+
 // What a system emits: PL(t) to memory (pvSim mode, pvSimPCR.py:281,:393) and/or the running squared
 // log-error against the observations (fused likelihood: bayeslib.py:150-157,:184-191, probs.py:29-44).
 // Shared by the fp64 and fp32 steppers; every member is wave-uniform.
@@ -430,12 +468,13 @@ __device__ __forceinline__ void update_field(const MatPar &m, double a0, const d
     }
 }
 
-template <int L, bool STRICT, bool SNAP = false>
+template <int L, bool STRICT, bool SNAP = false, bool MIXED = false>
 __global__ void __launch_bounds__(64, (STRICT || L > 128) ? (L > 256 ? 1 : 2) : TRPL_FAST_WAVES) stepper_kernel(const StepArgs a)
 {
     constexpr int W = L < 64 ? L : 64;
     constexpr int NR = L / W;
     constexpr int LAY = STRICT ? 0 : (L >= 128 ? 2 : 1);   // node layout / arithmetic flavour
+    static_assert(!MIXED || LAY == 2, "the mixed-precision correction exists for the interleaved layout (L >= 128)");
     const int ln = threadIdx.x & (W - 1);          // lanes >= W replicate lane (lane mod W)
     const int64_t sys = blockIdx.x;
     const int c = (int)(sys % a.C);
@@ -557,14 +596,23 @@ __global__ void __launch_bounds__(64, (STRICT || L > 128) ? (L > 256 ? 1 : 2) : 
         for (int iters = 0; iters < MAX; iters++) {
             double lo_[NR], dg[NR], up[NR], bb[NR], Ep[NR];
             shift_up1<LAY, NR, W>(Ek, Ep, ln);
+            bool okN, okP;
             // ---- electrons (:148-175) ----
             assemble<LAY, true, NR, W, L>(mp, a0, Nk, Pk, Ek, Ep, bN, lo_, dg, up, bb, ln);
-            const bool okN = residual_below<LAY, NR, W>(lo_, dg, up, bb, Nk, TOL, ln);             // :172
-            solve_lay<LAY, NR, W, L>(lo_, dg, up, bb, Nk, ln, xch);                                     // :175
+            if constexpr (MIXED) {
+                okN = correct_mixed<NR>(lo_, dg, up, bb, Nk, TOL, ln, (float *)xch);
+            } else {
+                okN = residual_below<LAY, NR, W>(lo_, dg, up, bb, Nk, TOL, ln);                    // :172
+                solve_lay<LAY, NR, W, L>(lo_, dg, up, bb, Nk, ln, xch);                                 // :175
+            }
             // ---- holes, with the updated electrons (:178-202) ----
             assemble<LAY, false, NR, W, L>(mp, a0, Nk, Pk, Ek, Ep, bP, lo_, dg, up, bb, ln);
-            const bool okP = residual_below<LAY, NR, W>(lo_, dg, up, bb, Pk, TOL, ln);             // :200
-            solve_lay<LAY, NR, W, L>(lo_, dg, up, bb, Pk, ln, xch);                                     // :202
+            if constexpr (MIXED) {
+                okP = correct_mixed<NR>(lo_, dg, up, bb, Pk, TOL, ln, (float *)xch);
+            } else {
+                okP = residual_below<LAY, NR, W>(lo_, dg, up, bb, Pk, TOL, ln);                    // :200
+                solve_lay<LAY, NR, W, L>(lo_, dg, up, bb, Pk, ln, xch);                                 // :202
+            }
             // ---- field on edges 1..L-1 (:205-209) ----
             update_field<LAY, NR, W>(mp, a0, Nk, Pk, bE, Ek, ln);
             if (okN && okP) { it = iters + 1; break; }                                             // :213-216
@@ -616,6 +664,26 @@ hipError_t launch_stepper(const StepArgs &a, hipStream_t stream)
         break;
         TRPL_CASE(4) TRPL_CASE(8) TRPL_CASE(16) TRPL_CASE(32) TRPL_CASE(64) TRPL_CASE(128)
         TRPL_CASE(256) TRPL_CASE(512)
+#undef TRPL_CASE
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// MIXED: fp64 state, history, assembly and residuals; fp32 correction solves (L >= 128, FAST arithmetic)
+inline hipError_t launch_stepper_mixed_impl(const StepArgs &a, hipStream_t stream)
+{
+    const int64_t nsys = a.S * a.C;
+    if (nsys <= 0) return hipSuccess;
+    dim3 grid((unsigned)nsys), block(64);
+    const bool snap = a.n_snap > 0;
+    switch (a.L) {
+#define TRPL_CASE(LL) \
+    case LL: \
+        if (snap) hipLaunchKernelGGL((stepper_kernel<LL, false, true, true>), grid, block, 0, stream, a); \
+        else      hipLaunchKernelGGL((stepper_kernel<LL, false, false, true>), grid, block, 0, stream, a); \
+        break;
+        TRPL_CASE(128) TRPL_CASE(256) TRPL_CASE(512)
 #undef TRPL_CASE
     default: return hipErrorInvalidValue;
     }

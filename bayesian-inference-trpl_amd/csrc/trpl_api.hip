@@ -113,14 +113,14 @@ int check_variant_flags(uint32_t flags, int32_t L)
 {
     if ((flags & kVariantBits) == kVariantBits)
         return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_KERNEL_PAIR and TRPL_FLAG_KERNEL_SINGLE exclude each other");
-    if ((flags & TRPL_FLAG_KERNEL_PAIR) && (L != 128 || (flags & (TRPL_FLAG_STRICT | TRPL_FLAG_FP32))))
-        return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_KERNEL_PAIR needs L = 128 (got %d) without TRPL_FLAG_STRICT / TRPL_FLAG_FP32", L);
+    if ((flags & TRPL_FLAG_KERNEL_PAIR) && (L != 128 || (flags & (TRPL_FLAG_STRICT | TRPL_FLAG_FP32 | TRPL_FLAG_MIXED))))
+        return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_KERNEL_PAIR needs L = 128 (got %d) without TRPL_FLAG_STRICT / _FP32 / _MIXED", L);
     return TRPL_OK;
 }
 
 bool pick_pair_kernel(int64_t nsys, int32_t L, int64_t steps, uint32_t flags)
 {
-    if (L != 128 || (flags & (TRPL_FLAG_STRICT | TRPL_FLAG_FP32))) return false;
+    if (L != 128 || (flags & (TRPL_FLAG_STRICT | TRPL_FLAG_FP32 | TRPL_FLAG_MIXED))) return false;
     if (flags & TRPL_FLAG_KERNEL_PAIR) return true;
     if (flags & TRPL_FLAG_KERNEL_SINGLE) return false;
     return use_pair_kernel(nsys, steps);
@@ -153,11 +153,18 @@ int launch(const trpl::StepArgs &a, uint32_t flags, hipStream_t st, int64_t step
 {
     if (int rc = check_variant_flags(flags, a.L)) return rc;
     if (flags & TRPL_FLAG_FP32) {
-        if (flags & TRPL_FLAG_STRICT) return fail(TRPL_ERR_ARG, "TRPL_FLAG_FP32 and TRPL_FLAG_STRICT exclude each other");
+        if (flags & (TRPL_FLAG_STRICT | TRPL_FLAG_MIXED)) return fail(TRPL_ERR_ARG, "TRPL_FLAG_FP32 excludes TRPL_FLAG_STRICT and TRPL_FLAG_MIXED");
         if (a.L < 128) return fail(TRPL_ERR_UNSUPPORTED, "the fp32 stepper is built for L >= 128 (got %d)", a.L);
         if (a.n_snap > 0) return fail(TRPL_ERR_UNSUPPORTED, "state snapshots are not available with TRPL_FLAG_FP32");
         hipError_t e32 = trpl::launch_stepper_f32(a, st);
         if (e32 != hipSuccess) return fail(TRPL_ERR_HIP, "fp32 stepper launch: %s", hipGetErrorString(e32));
+        return TRPL_OK;
+    }
+    if (flags & TRPL_FLAG_MIXED) {
+        if (flags & TRPL_FLAG_STRICT) return fail(TRPL_ERR_ARG, "TRPL_FLAG_MIXED and TRPL_FLAG_STRICT exclude each other");
+        if (a.L < 128) return fail(TRPL_ERR_UNSUPPORTED, "the mixed-precision stepper is built for L >= 128 (got %d)", a.L);
+        hipError_t em = trpl::launch_stepper_mixed(a, st);
+        if (em != hipSuccess) return fail(TRPL_ERR_HIP, "mixed stepper launch: %s", hipGetErrorString(em));
         return TRPL_OK;
     }
     if (pick_pair_kernel(a.S * a.C, a.L, steps, flags)) {
@@ -181,6 +188,7 @@ int trpl_kernel_variant(int64_t nsys, int32_t L, int64_t steps, uint32_t flags)
 {
     if (flags & TRPL_FLAG_FP32) return TRPL_KERNEL_FP32;
     if (flags & TRPL_FLAG_STRICT) return TRPL_KERNEL_STRICT;
+    if (flags & TRPL_FLAG_MIXED) return TRPL_KERNEL_MIXED;
     return pick_pair_kernel(nsys, L, steps, flags) ? TRPL_KERNEL_FAST_PAIR : TRPL_KERNEL_FAST;
 }
 

@@ -69,7 +69,8 @@ def bracket_times(sim_t, times):
 
 
 def loglik(X, init_params, lengths, Time, L, T, obs, tol=7, MAX=10000, plT=1, P=None, pl_f32=False,
-           normalize=False, strict=False, device=0, info=None, times=None, fp32=False, devices=None, kernel=None):
+           normalize=False, strict=False, device=0, info=None, times=None, fp32=False, devices=None, kernel=None,
+           mixed=False):
     """Fused likelihood of one experiment (trpl_loglik / trpl_loglik_obs / trpl_loglik_multi).
 
     X (S,13) solver units; init_params (C,L) nm^-3; lengths scalar or (C,); obs = list of C
@@ -123,7 +124,8 @@ def loglik(X, init_params, lengths, Time, L, T, obs, tol=7, MAX=10000, plT=1, P=
     status = np.zeros((Cn, S), dtype=np.int32)
     iters = np.zeros((Cn, S), dtype=np.int64)
     flags = (_abi.FLAG_STRICT if strict else 0) | (_abi.FLAG_PL_F32 if pl_f32 else 0) \
-        | (_abi.FLAG_NORMALIZE if normalize else 0) | (_abi.FLAG_FP32 if fp32 else 0) | _abi.kernel_flag(kernel)
+        | (_abi.FLAG_NORMALIZE if normalize else 0) | (_abi.FLAG_FP32 if fp32 else 0) | _abi.kernel_flag(kernel) \
+        | (_abi.FLAG_MIXED if mixed else 0)
     sec = _abi.C.c_double(0.0)
     lib = _abi.lib()
     if devices is not None:

@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--strict", action="store_true", help="bit-reproducible arithmetic mode")
     ap.add_argument("--L", type=int, default=128, help="spatial nodes (configs[4]: 512)")
     ap.add_argument("--fp32", action="store_true", help="fp32 solver state (configs[4]); implies --tol 3 at L=512, 4 otherwise")
+    ap.add_argument("--mixed", action="store_true",
+                    help="fp64 state + fp32 correction solves (TRPL_FLAG_MIXED; the accurate path for configs[4])")
     ap.add_argument("--tol", type=int, default=None, help="convergence exponent (default 7, the reference's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcr", action="store_true")
@@ -121,7 +123,8 @@ def main():
     lo, hi = trpl_amd.dist.shard_bounds(S_total, world, rank)
     S = hi - lo
     X_host = wl.samples(S_total)[lo:hi]                      # same seeded draw on every rank, own shard
-    flags = (trpl_amd.FLAG_STRICT if args.strict else 0) | (trpl_amd.FLAG_FP32 if args.fp32 else 0)
+    flags = (trpl_amd.FLAG_STRICT if args.strict else 0) | (trpl_amd.FLAG_FP32 if args.fp32 else 0) \
+        | (trpl_amd.FLAG_MIXED if args.mixed else 0)
     # the stepper variant is a property of the LOGICAL batch (all ranks' samples), not of this rank's shard:
     # a sample's bits then do not depend on how many GPUs the batch is cut over (include/trpl.h)
     flags = trpl_amd._abi.pin_variant(flags, S_total * C, L, T)
@@ -207,9 +210,11 @@ def main():
         kernel_name = "pair::stepper_pair_kernel (2 x L=128 systems per wavefront; fused time-stepper + likelihood)"
         rocprof_name = "void trpl::pair::stepper_pair_kernel<true, 1, false>"
     else:
-        kernel_name = "%sstepper_kernel<%d> (fused time-stepper + likelihood)" % ("f32::" if args.fp32 else "", L)
+        kernel_name = "%sstepper_kernel<%d%s> (fused time-stepper + likelihood)" % ("f32::" if args.fp32 else "", L,
+                                                                                   ", mixed" if args.mixed else "")
         rocprof_name = ("void trpl::f32::stepper_kernel<%d>" % L) if args.fp32 else \
-            "void trpl::stepper_kernel<%d, %s, false>" % (L, "true" if args.strict else "false")
+            "void trpl::stepper_kernel<%d, %s, false, %s>" % (L, "true" if args.strict else "false",
+                                                              "true" if args.mixed else "false")
     out = {
         "metric": "TRPL timesteps/sec at %d nodes (system = parameter sample x excitation; fused solve + "
                   "log-likelihood; parameter-sample likelihoods/sec in likelihoods_per_s_*)" % L,
@@ -222,12 +227,13 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32 state, f64 reductions" if args.fp32 else "f64",
+        "dtype": "f32 state, f64 reductions" if args.fp32 else ("f64 state, f32 correction solves" if args.mixed else "f64"),
         "data": "synthetic",
         "config": {"workload": "%s x %d samples/GPU (%d total), %d curves, L=%d nodes, T=%d steps of dt=0.025 ns, "
                                "tol=1e-%d, MAX=10000, %s, arithmetic=%s"
                                % (args.workload, args.samples_per_gpu, S_total, C, L, T, tol,
-                                  "fp32 state" if args.fp32 else "fp64", "strict" if args.strict else "fast"),
+                                  "fp32 state" if args.fp32 else ("fp64 state + fp32 solves" if args.mixed else "fp64"),
+                                  "strict" if args.strict else "fast"),
                    "samples_total": S_total, "curves": C, "L": L, "T": T, "parallelism": "sample-shard x%d" % world,
                    "collective": "none" if world == 1 else ("RCCL all_gather" if args.backend == "nccl" else "gloo all_gather (rehearsal)")},
         "likelihoods_per_s_at_T": S_total * args.steps / elapsed,

@@ -56,6 +56,13 @@ extern "C" {
                                      tol_exp 4-5 (fp32's residual floor is ~1e-7).  No reference exists for
                                      this mode (the reference is fp64 only) */
 
+#define TRPL_FLAG_MIXED 0x40      /* fp64 state, history, assembly, residuals, PL and likelihood; each inner iteration
+                                     solves its tridiagonal CORRECTION equation A delta = b - A c in fp32 (L >= 128, not
+                                     combinable with STRICT / FP32).  Same convergence test as fp64 (the fp64 residual of
+                                     the reference's norm2), so the accuracy is that of the fp64 solver at the same tol;
+                                     an fp32 solve resolves ~1e-5 of a correction, so tol_exp 5-6 converges in the fp64
+                                     iteration count and tol_exp 7 may take one more.  The accurate path for configs[4]
+                                     (L = 512); no reference exists for it (the reference is fp64 only) */
 #define TRPL_FLAG_KERNEL_PAIR 0x10    /* run the two-systems-per-wavefront stepper whatever the launch size (L = 128,
                                         fp64, not STRICT -- anything else is TRPL_ERR_ARG) */
 #define TRPL_FLAG_KERNEL_SINGLE 0x20  /* run the one-system-per-wavefront stepper whatever the launch size */
@@ -72,6 +79,7 @@ extern "C" {
 #define TRPL_KERNEL_FAST_PAIR 1   /* two systems per wavefront: L = 128, launches that keep the chip full */
 #define TRPL_KERNEL_STRICT 2
 #define TRPL_KERNEL_FP32 3
+#define TRPL_KERNEL_MIXED 4
 int trpl_kernel_variant(int64_t nsys, int32_t L, int64_t steps, uint32_t flags);
 
 int trpl_abi_version(void);

@@ -282,8 +282,8 @@ def test_snapshots_vs_legacy_pvsim_golden_and_dropin_signature(gpu, golden):
         assert np.max(np.abs(plI[:, :3] / g["plI_legacy"][:, :3] - 1)) < (1e-13 if strict else 1e-12)
     # the dummies bayeslib passes (shape (S, 2, L), bayeslib.py:141-143) do not match len(pT): ignored
     junk = np.full((S, 2, L), 7.0)
-    gpu.pvSim(plI, junk, junk.copy(), np.full((S, 2, L + 1), 7.0), X[:, :12], [Length, Time, L, 16, 1, pT, 7, 10000],
-              (float(g["a_nm3"]), float(g["l_nm"])), init_mode="exp")
+    gpu.pvSim(np.empty((S, 17)), junk, junk.copy(), np.full((S, 2, L + 1), 7.0), X[:, :12],
+              [Length, 16 * 0.025, L, 16, 1, pT, 7, 10000], (float(g["a_nm3"]), float(g["l_nm"])), init_mode="exp")
     assert (junk == 7.0).all()
 
 
@@ -330,6 +330,51 @@ def test_snapshots_nonconvergence_small_grids_and_device_entry(gpu, oracle):
     assert np.array_equal(plP_d.cpu().numpy(), want["plP"])
     with pytest.raises(gpu.TrplError):                                      # not built for the fp32 stepper
         gpu.solve_pl(X[:4], lens[1], Time, 128, T, ini[1], snap_steps=[0], snapshots={}, fp32=True, tol=4)
+
+
+# ------------------------------------------------------------------ configs[4]: L = 512 at an accuracy worth reporting
+@pytest.mark.parametrize("L", [128, 512])
+def test_cfg4_fp64_state_paths_against_the_oracle(gpu, oracle, L):
+    """The accurate paths for BASELINE configs[4] (L = 512; profiles/r2_cfg4_frontier.json): the fp64 stepper
+    and the mixed one (TRPL_FLAG_MIXED: fp64 state / assembly / residuals, fp32 correction solves) against the
+    fp64 tol-7 oracle over a 400-step window, gates = the measured frontier with a margin:
+      tol 7  fp64 1e-9 (FAST parity);  mixed 1e-7, the SAME iteration counts as fp64 (the fp32 solve resolves
+             ~1e-5 of a correction that is itself O(tolerance) by the last iteration)
+      tol 6  both: PL <= 2e-5, log-likelihood <= 1e-5 -- the accuracy the frontier table recommends
+    (the fp32-STATE stepper's gates stay in test_fp32_stepper_vs_fp64_oracle: 2e-3 at 60 steps, and tens of
+    percent over 8000 steps -- measured)."""
+    w = gpu.workloads
+    X = w.samples(8, seed=61)
+    T, length = 400, 2000.0
+    Time = T * 0.025
+    ini = np.stack([w.beer_lambert(A, length, L) for A in w.POWER_SCAN_A_CM3])
+    ref = [oracle.pvsim(X[:, :-1], length, Time, L, T, ini[c], nthreads=nthreads()) for c in range(3)]
+    obs = [np.log10(r["plI"][3]) + 0.02 for r in ref]
+    want = oracle.simulate_loglik(X, ini, length, Time, L, T, [([np.linspace(0, Time, T + 1)] * 3, obs)],
+                                  pl_dtype=np.float64, nthreads=nthreads())[0]
+    lib = gpu._abi.lib()
+    assert lib.trpl_kernel_variant(10 ** 6, L, T, gpu._abi.FLAG_MIXED) == gpu._abi.KERNEL_MIXED
+    for mixed, tol, pl_gate, ll_gate in ((False, 7, 1e-9, 1e-8), (True, 7, 1e-7, 1e-7), (False, 6, 2e-5, 1e-5), (True, 6, 2e-5, 1e-5)):
+        for c in range(3):
+            pl, st, it, _ = gpu.solve_pl(X[:, :-1], length, Time, L, T, ini[c], tol=tol, mixed=mixed, kernel="single" if not mixed else None)
+            assert not st.any()
+            ok = above_floor(ref[c]["plI"])
+            err = np.max(np.abs(pl[ok] - ref[c]["plI"][ok]) / np.abs(ref[c]["plI"][ok]))
+            assert err < pl_gate, (mixed, tol, c, err)
+            if tol == 7:
+                assert abs(it.sum() / ref[c]["iters_total"].sum() - 1) < 0.01, (mixed, c)
+            else:
+                assert np.all(it <= ref[c]["iters_total"])
+        info = {}
+        P = gpu.loglik(X, ini, length, Time, L, T, obs, tol=tol, mixed=mixed, info=info)
+        assert not info["status"].any()
+        assert np.max(np.abs(P - want) / np.abs(want)) < ll_gate, (mixed, tol)
+    with pytest.raises(gpu.TrplError):
+        gpu.solve_pl(X[:, :-1], length, Time, L, T, ini[0], mixed=True, strict=True)
+    with pytest.raises(gpu.TrplError):
+        gpu.solve_pl(X[:, :-1], length, Time, L, T, ini[0], mixed=True, fp32=True)
+    with pytest.raises(gpu.TrplError):
+        gpu.solve_pl(X[:, :-1], length, Time, 64, T, w.beer_lambert(1e17, length, 64), mixed=True)
 
 
 # ------------------------------------------------------------------ device-resident multi-GPU (RCCL)
