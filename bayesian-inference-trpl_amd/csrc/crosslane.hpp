@@ -35,6 +35,9 @@
 #ifndef TRPL_PCR_SETPRIO
 #define TRPL_PCR_SETPRIO 2        // s_setprio level inside the cross-lane PCR levels (0 = off)
 #endif
+#ifndef TRPL_RCP_QUAD
+#define TRPL_RCP_QUAD 1       // four row reciprocals from one v_rcp_f64 (rcp_rows, NR % 4 == 0); measured, see DESIGN.md section 8
+#endif
 #ifndef TRPL_RCP_PAIR
 #define TRPL_RCP_PAIR 1       // pair reciprocals (rcp_rows); 0 only for A/B measurements
 #endif

@@ -670,24 +670,4 @@ hipError_t launch_stepper(const StepArgs &a, hipStream_t stream)
     return hipGetLastError();
 }
 
-// MIXED: fp64 state, history, assembly and residuals; fp32 correction solves (L >= 128, FAST arithmetic)
-inline hipError_t launch_stepper_mixed_impl(const StepArgs &a, hipStream_t stream)
-{
-    const int64_t nsys = a.S * a.C;
-    if (nsys <= 0) return hipSuccess;
-    dim3 grid((unsigned)nsys), block(64);
-    const bool snap = a.n_snap > 0;
-    switch (a.L) {
-#define TRPL_CASE(LL) \
-    case LL: \
-        if (snap) hipLaunchKernelGGL((stepper_kernel<LL, false, true, true>), grid, block, 0, stream, a); \
-        else      hipLaunchKernelGGL((stepper_kernel<LL, false, false, true>), grid, block, 0, stream, a); \
-        break;
-        TRPL_CASE(128) TRPL_CASE(256) TRPL_CASE(512)
-#undef TRPL_CASE
-    default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
 }  // namespace trpl

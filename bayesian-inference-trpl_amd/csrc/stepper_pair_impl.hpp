@@ -199,8 +199,16 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
         // ---------------- iterate, pvSimPCR.py:93-225, both systems ----------------
         bool doneA = deadA, doneB = deadB;
         int itA = MAX, itB = MAX;                   // value if the loop runs to exhaustion (:225)
-        for (int iters = 0; iters < MAX; iters++) {
-            const bool act = hi ? !doneB : !doneA;  // lanes of a system that is still iterating
+        // One inner iteration of both systems.  FROZEN = false is the common case -- both systems still
+        // iterating: every lane takes its solve's result, no selects (25 fewer instructions); FROZEN = true keeps
+        // the state of a system that has already converged in this time step (or is dead) while its partner
+        // iterates on.  Both flavours are the same source: this translation unit is compiled with
+        // -ffp-contract=on (fusion decided by the syntax of each expression, not by the optimiser's view of the
+        // surrounding code), so a system's arithmetic is bit-identical in the two -- its result must not depend
+        // on when its partner converges.
+        auto iterate_once = [&](auto frozen_c, int iters) {
+            constexpr bool FROZEN = decltype(frozen_c)::value;
+            const bool act = FROZEN ? (hi ? !doneB : !doneA) : true;   // lanes of a system that is still iterating
             double lo_[NR], dg[NR], up[NR], bb[NR], Ep[NR], x[NR];
             nbrB_up<double, NR, 1>(Ek, Ep, lane);   // a system's last lane reads the partner's E_0 = 0: E_L = 0
             bool okNA, okNB, okPA, okPB;
@@ -220,8 +228,13 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
             update_field2<ISO>(mp, a0, Nk, Pk, bE, Ek, lane, act);
             if (!doneA && okNA && okPA) { doneA = true; itA = iters + 1; }                         // :213-216
             if (!doneB && okNB && okPB) { doneB = true; itB = iters + 1; }
-            if (doneA && doneB) break;
-        }
+        };
+        // within a time step a system only ever goes from iterating to done: first the iterations with both
+        // systems active, then those with one of them frozen (two loops, not a branch inside one: the register
+        // allocator handles them separately; a branch inside the loop spilled 89 VGPRs)
+        int iters = 0;
+        for (; iters < MAX && !(doneA || doneB); iters++) iterate_once(std::false_type{}, iters);
+        for (; iters < MAX && !(doneA && doneB); iters++) iterate_once(std::true_type{}, iters);
         bool killA = false, killB = false;
         // :269-274 -- like the reference, converging only in iteration MAX itself counts as a failure
         if (!deadA) { itotA += itA; if (itA >= MAX) { statusA = 1 + (int)t; killA = true; } }
