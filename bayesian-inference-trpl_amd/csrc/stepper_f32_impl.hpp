@@ -217,6 +217,7 @@ __global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
     int status = 0;
     int64_t itot = 0;
 
+    int64_t pl_next = 0, pl_col = 0;               // next step with t % plT == 0 and its PL column t / plT
     for (int64_t t = 0; t <= sink.t_last; t++) {
         float a0, a1, a2, a3, a4, a5;              // BDF table, pvSimPCR.py:241-250
         if (t == 0)      { a0 = 1.0f; a1 = -1.0f; a2 = 0.0f; a3 = 0.0f; a4 = 0.0f; a5 = 0.0f; }
@@ -226,7 +227,7 @@ __global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
         else             { a0 = (float)(137.0 / 60); a1 = -5.0f; a2 = 5.0f; a3 = (float)(-10.0 / 3); a4 = 1.25f; a5 = -0.2f; }
 
         double plv = 0.0;
-        const bool pl_step = (t % a.plT) == 0;
+        const bool pl_step = t == pl_next;
         if (pl_step) {                             // midpoint PL in fp64 (pvSimPCR.py:276-281), per-node excess first
             double q = 0.0;
 #pragma unroll
@@ -266,8 +267,10 @@ __global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
         if (it >= MAX) { status = 1 + (int)t; break; }
 
         if (pl_step) {
-            if (sink.interp) sink.emit(t, plv);
-            else sink.push(t, plv);
+            if (sink.interp) sink.emit(pl_col, plv);
+            else sink.push(pl_col, plv);
+            pl_next += a.plT;
+            pl_col++;
         }
 #pragma unroll
         for (int j = 0; j < NR; j++) {

@@ -174,10 +174,10 @@ struct PlSink {
         t_last = want_pl ? a.T : (interp ? (int64_t)obs_hi[ncol_ll - 1] : (ncol_ll - 1) * a.plT);
     }
 
-    // plv = rate * (sum N P - L n0 p0) of the state at time t, non-dimensional
-    __device__ __forceinline__ void emit(int64_t t, double plv)
+    // plv = rate * (sum N P - L n0 p0) of the state at time t = col * plT, non-dimensional.  The steppers count
+    // PL columns instead of dividing t by plT every step (a 64-bit scalar division is ~130 instructions).
+    __device__ __forceinline__ void emit(int64_t col, double plv)
     {
-        const int64_t col = t / a.plT;
         if (want_pl && threadIdx.x == 0) {                                             // :281,:393
             if (a.pl_bytes == 4) ((float *)a.pl)[orow * a.pl_ld + col] = (float)plv / (float)cc.plnorm;
             else                 ((double *)a.pl)[orow * a.pl_ld + col] = plv / cc.plnorm;
@@ -222,9 +222,8 @@ struct PlSink {
     // batch are added by a wave reduction, so the likelihood sum is associated differently from the
     // reference's serial loop (~1e-16 relative; STRICT keeps emit()).  Not used for off-grid
     // observation times, which need consecutive values in order (emit()).
-    __device__ __forceinline__ void push(int64_t t, double plv)
+    __device__ __forceinline__ void push(int64_t col, double plv)
     {
-        const int64_t col = t / a.plT;
         if ((int64_t)threadIdx.x == col - base) pend = plv;
         if (col - base == 63) flush_batch(64);
     }
@@ -527,6 +526,7 @@ __global__ void __launch_bounds__(64, (STRICT || L > 128) ? (L > 256 ? 1 : 2) : 
     int status = 0;
     int64_t itot = 0;
 
+    int64_t pl_next = 0, pl_col = 0;               // next step with t % plT == 0 and its PL column t / plT (:276)
     for (int64_t t = 0; t <= sink.t_last; t++) {   // tEvol, pvSimPCR.py:237
         if constexpr (SNAP) {                      // the state at time t, before it is stepped (:283-288)
             if (snap.due(t))
@@ -542,7 +542,7 @@ __global__ void __launch_bounds__(64, (STRICT || L > 128) ? (L > 256 ? 1 : 2) : 
 
         // PL of the state at time t (level k), pvSimPCR.py:276-281: rate * (sum_i N_i P_i - L N0 P0).
         double plv = 0.0;
-        const bool pl_step = (t % a.plT) == 0;
+        const bool pl_step = t == pl_next;
         if (pl_step) {
             if constexpr (STRICT) {
                 // the reference's serial loop, node by node (:278-280), so that PL is bit-identical
@@ -621,8 +621,10 @@ __global__ void __launch_bounds__(64, (STRICT || L > 128) ? (L > 256 ? 1 : 2) : 
         if (it >= MAX) { status = 1 + (int)t; break; }                                     // :269-274
 
         if (pl_step) {
-            if (STRICT || sink.interp) sink.emit(t, plv);
-            else sink.push(t, plv);
+            if (STRICT || sink.interp) sink.emit(pl_col, plv);
+            else sink.push(pl_col, plv);
+            pl_next += a.plT;
+            pl_col++;
         }
 
 #pragma unroll

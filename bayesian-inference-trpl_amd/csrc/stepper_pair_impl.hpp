@@ -152,6 +152,7 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
     int64_t itotA = 0, itotB = 0;
     SnapSink snap(a, cc);
 
+    int64_t pl_next = 0, pl_col = 0;                // next step with t % plT == 0 and its PL column t / plT (:276)
     for (int64_t t = 0; t <= sinkA.t_last; t++) {   // tEvol, pvSimPCR.py:237
         if (deadA && deadB) break;
         if constexpr (SNAP) {                       // the state at time t, before it is stepped (:283-288)
@@ -168,7 +169,7 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
 
         // PL of the state at time t, pvSimPCR.py:276-281, per-node excess first (see stepper_impl.hpp)
         double plA = 0.0, plB = 0.0;
-        const bool pl_step = (t % a.plT) == 0;
+        const bool pl_step = t == pl_next;
         if (pl_step) {
             double q = __builtin_fma(Nk[0], Pk[0], -n0p0);
 #pragma unroll
@@ -259,8 +260,10 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
         }
 
         if (pl_step) {
-            if (!deadA) { if (sinkA.interp) sinkA.emit(t, plA); else sinkA.push(t, plA); }
-            if (!deadB) { if (sinkB.interp) sinkB.emit(t, plB); else sinkB.push(t, plB); }
+            if (!deadA) { if (sinkA.interp) sinkA.emit(pl_col, plA); else sinkA.push(pl_col, plA); }
+            if (!deadB) { if (sinkB.interp) sinkB.emit(pl_col, plB); else sinkB.push(pl_col, plB); }
+            pl_next += a.plT;
+            pl_col++;
         }
 
 #pragma unroll
