@@ -1,7 +1,12 @@
 // Stand-alone batched tridiagonal solve (measurement unit U1): S systems of L unknowns,
-// operands and result in HBM ([S][L] arrays), one wavefront per system, the elimination order
-// of pcreduce (pvSimPCR.py:42-81).  Bound: HBM bandwidth, 5*L*sizeof(T) algorithmic bytes per
-// system (read ld, d, ud, b; write x).
+// operands and result in HBM ([S][L] arrays), one wavefront per system; STRICT: the elimination order
+// of pcreduce (pvSimPCR.py:42-81), FAST: cyclic reduction in-lane + PCR on one row per lane (pcr.hpp).
+// Bound: HBM bandwidth, 5*L*sizeof(T) algorithmic bytes per system (read ld, d, ud, b; write x).
+// Measured and NOT adopted (round 2, operands rotated through 1.34 GB so that nothing is served by the
+// Infinity Cache; tools/bench_pcr_ab.py): a persistent launch whose waves load system i+1 before solving
+// system i: 5.17 TB/s against 5.41 TB/s for this one-pass form (the hardware's own wave switching already
+// overlaps the loads of 16 resident waves per CU with the solves); the same with non-temporal loads: 5.48.
+// Four read streams + one write stream saturate at ~5.5 TB/s here (the guide's 6.3 TB/s is a 1:1 copy).
 #pragma once
 #include "stepper_f32_impl.hpp"
 
@@ -16,8 +21,11 @@ __global__ void __launch_bounds__(256) pcr_batched_kernel(const T *__restrict__ 
     constexpr int NR = L / W;
     const int lane = threadIdx.x & 63;
     const int ln = lane & (W - 1);
-    __shared__ __attribute__((aligned(16))) T xch_all[(!STRICT && L >= 128) ? 4 * 3 * L : 4];
-    T *xch = xch_all + (threadIdx.x >> 6) * 3 * L;              // this wave's private exchange buffer
+    // exchange buffer of the solve, private to each of the 4 waves: the cyclic-reduction + PCR solver stages one
+    // value per lane and array (3 x 64), the pure-PCR variants all L rows
+    constexpr int XW = TRPL_CR_HYBRID != 0 ? 64 : L;
+    __shared__ __attribute__((aligned(16))) T xch_all[(!STRICT && L >= 128) ? 4 * 3 * XW : 4];
+    T *xch = xch_all + (threadIdx.x >> 6) * 3 * XW;
     (void)xch;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
