@@ -88,14 +88,20 @@ for name, flags, tol in MODES:
     pl_err = float(np.max(np.abs(pl_h[good] - ref_pl_h[good]) / np.abs(ref_pl_h[good])))
     pl_err_med = float(np.median(np.max(np.where(good, np.abs(pl_h - ref_pl_h) / np.abs(ref_pl_h), 0), axis=2)))
     fin = np.isfinite(Pa_h)
-    ll_err = float(np.max(np.abs(Pa_h[fin] - ref_P_h[fin]) / np.abs(ref_P_h[fin])))
+    ll_rel = np.abs(Pa_h[fin] - ref_P_h[fin]) / np.abs(ref_P_h[fin])
+    ll_err = float(np.max(ll_rel))
+    # the same PL error over the part of every decay a measurement resolves (>= 1e-6 of its start)
+    top = good & (np.abs(ref_pl_h) >= 1e-6 * np.abs(ref_pl_h[:, :, :1]))
+    pl_err_top = float(np.max(np.abs(pl_h[top] - ref_pl_h[top]) / np.abs(ref_pl_h[top])))
     row = {"arithmetic": name, "tol": tol, "L": L, "S": S, "T": T, "ms": ms,
            "system_timesteps_per_s": S * C * (T + 1) / (ms * 1e-3), "inner_iterations_per_step": itn / (S * C * (T + 1)),
            "nonconverged": nfail, "subset_nonconverged": int((sts != 0).sum().item()),
-           "pl_max_rel_err": pl_err, "pl_median_of_row_max_rel_err": pl_err_med, "loglik_max_rel_err": ll_err}
+           "pl_max_rel_err": pl_err, "pl_median_of_row_max_rel_err": pl_err_med, "loglik_max_rel_err": ll_err,
+           "pl_max_rel_err_above_1e-6_of_start": pl_err_top, "loglik_median_rel_err": float(np.median(ll_rel))}
     rows.append(row)
     print("%-24s tol %d: %.3e system-timesteps/s  %.2f it/step  nonconv %d  PL err max %.2e (median row max %.2e)  "
-          "loglik err %.2e" % (name, tol, row["system_timesteps_per_s"], row["inner_iterations_per_step"], nfail,
-                              pl_err, pl_err_med, ll_err), flush=True)
+          "loglik err %.2e (median %.2e)  PL err where PL >= 1e-6 PL(0): %.2e"
+          % (name, tol, row["system_timesteps_per_s"], row["inner_iterations_per_step"], nfail, pl_err, pl_err_med, ll_err,
+             row["loglik_median_rel_err"], pl_err_top), flush=True)
 if out_path:
     json.dump(rows, open(out_path, "w"), indent=1)
