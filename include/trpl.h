@@ -53,16 +53,21 @@ extern "C" {
                                      (bayeslib.py:150-154) */
 #define TRPL_FLAG_FP32 0x8        /* solver state, BDF history and PCR in fp32 (node sums, PL, log10 and the
                                      squared error stay fp64); L >= 128, not combinable with STRICT; use
-                                     tol_exp 4-5 (fp32's residual floor is ~1e-7).  No reference exists for
-                                     this mode (the reference is fp64 only) */
+                                     tol_exp 3-4 (fp32's residual floor is ~1e-7).  A SCREENING mode: an fp32
+                                     state cannot hold the BDF history differences, and over thousands of time
+                                     steps the PL error grows to percents and, on the decayed tail, tens of
+                                     percent (measured at L = 512, T = 8000: DESIGN.md section 7); use the
+                                     default fp64 path (or TRPL_FLAG_MIXED) at tol_exp 6 for results.  No
+                                     reference exists for this mode (the reference is fp64 only) */
 
 #define TRPL_FLAG_MIXED 0x40      /* fp64 state, history, assembly, residuals, PL and likelihood; each inner iteration
                                      solves its tridiagonal CORRECTION equation A delta = b - A c in fp32 (L >= 128, not
                                      combinable with STRICT / FP32).  Same convergence test as fp64 (the fp64 residual of
                                      the reference's norm2), so the accuracy is that of the fp64 solver at the same tol;
                                      an fp32 solve resolves ~1e-5 of a correction, so tol_exp 5-6 converges in the fp64
-                                     iteration count and tol_exp 7 may take one more.  The accurate path for configs[4]
-                                     (L = 512); no reference exists for it (the reference is fp64 only) */
+                                     iteration count (measured: tol_exp 7 too).  Measured on MI355X it is NOT faster than
+                                     the fp64 stepper (a plain fp32 VALU instruction issues at the fp64 rate on CDNA4);
+                                     it exists as the measured point of DESIGN.md section 7.  No reference exists for it */
 #define TRPL_FLAG_KERNEL_PAIR 0x10    /* run the two-systems-per-wavefront stepper whatever the launch size (L = 128,
                                         fp64, not STRICT -- anything else is TRPL_ERR_ARG) */
 #define TRPL_FLAG_KERNEL_SINGLE 0x20  /* run the one-system-per-wavefront stepper whatever the launch size */
