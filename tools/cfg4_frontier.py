@@ -104,4 +104,5 @@ for name, flags, tol in MODES:
           % (name, tol, row["system_timesteps_per_s"], row["inner_iterations_per_step"], nfail, pl_err, pl_err_med, ll_err,
              row["loglik_median_rel_err"], pl_err_top), flush=True)
 if out_path:
+    os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
     json.dump(rows, open(out_path, "w"), indent=1)
