@@ -117,8 +117,10 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
                  tauN = xs[9] * cc.scales[9], tauP = xs[10] * cc.scales[10],
                  Lambda = xs[11] * cc.scales[11];
     const double n0p0 = N0 * P0;
-    const MatPar mp = {N0, P0, DN, DP, rate, sr0, srL, CN, CP, tauN, tauP, Lambda, n0p0,
-                       ln == 0 ? 1.0 : 0.0, ln == WS - 1 ? 1.0 : 0.0};
+    MatPar mp_ = {N0, P0, DN, DP, rate, sr0, srL, CN, CP, tauN, tauP, Lambda, n0p0,
+                  ln == 0 ? 1.0 : 0.0, ln == WS - 1 ? 1.0 : 0.0};
+    mp_.fast_constants();
+    const MatPar mp = mp_;
     const double mag = a.xld > 12 ? xs[12] : 0.0;
     const double TOL = a.TOL;
     const int MAX = a.MAX;
