@@ -448,11 +448,24 @@ template <typename T, int NR, int H, int WS = 64, bool ISO = false, int XM = 0>
 __device__ __forceinline__ void cr_forward(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], int lane)
 {
     if constexpr (H < NR) {
-        // normalise the eliminated rows in place: (ld, ud, B)[q] become (a^, c^, b^)
+        // normalise the eliminated rows in place: (ld, ud, B)[q] become (a^, c^, b^); in fp64 two rows share
+        // one v_rcp_f64 (r = 1/(d_q d_q'), 1/d_q = d_q' r: the diagonals are O(1..1e3))
+        constexpr int NQ = (NR - H + 2 * H - 1) / (2 * H);          // rows H, 3H, 5H, ...
+        if constexpr (sizeof(T) == 8 && NQ % 2 == 0 && TRPL_RCP_PAIR != 0) {
 #pragma unroll
-        for (int q = H; q < NR; q += 2 * H) {
-            const T r = rcp_fast<T>(d[q]);
-            ld[q] *= r; ud[q] *= r; B[q] *= r;
+            for (int q = H; q < NR; q += 4 * H) {
+                const int q2 = q + 2 * H;
+                const T rp = rcp_fast<T>(d[q] * d[q2]);
+                const T r1 = d[q2] * rp, r2 = d[q] * rp;
+                ld[q] *= r1; ud[q] *= r1; B[q] *= r1;
+                ld[q2] *= r2; ud[q2] *= r2; B[q2] *= r2;
+            }
+        } else {
+#pragma unroll
+            for (int q = H; q < NR; q += 2 * H) {
+                const T r = rcp_fast<T>(d[q]);
+                ld[q] *= r; ud[q] *= r; B[q] *= r;
+            }
         }
         // the left neighbour of row 0 is row NR-H of lane l-1
         T aL0, cL0, bL0;

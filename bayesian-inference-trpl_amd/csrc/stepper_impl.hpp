@@ -395,8 +395,12 @@ __device__ __forceinline__ void assemble(const MatPar &m, double a0, const doubl
             const double hD = IS_N ? 0.5 * D : -0.5 * D;
             const double tauO = IS_N ? m.tauN : m.tauP;
             const double Co2 = IS_N ? m.Co2N : m.Co2P, Con0 = IS_N ? m.Con0N : m.Con0P, tVn0 = IS_N ? m.tVn0N : m.tVn0P;
-            const double u_i = last ? 0.0 : __builtin_fma(-hD, Ep[j], -D);
-            const double l_i = first ? 0.0 : __builtin_fma(hD, Ek[j], -D);
+            // boundary rows: with per-lane 0/1 masks (the paired kernel) x - mask * x is x or an exact 0 in one
+            // fma, instead of a two-dword select
+            auto zero_if_first = [&](double x) { return SURF_FMA ? (j == 0 ? __builtin_fma(-m.mfirst, x, x) : x) : (first ? 0.0 : x); };
+            auto zero_if_last = [&](double x) { return SURF_FMA ? (j == NR - 1 ? __builtin_fma(-m.mlast, x, x) : x) : (last ? 0.0 : x); };
+            const double u_i = zero_if_last(__builtin_fma(-hD, Ep[j], -D));
+            const double l_i = zero_if_first(__builtin_fma(hD, Ek[j], -D));
             const double tp = __builtin_fma(Pk[j], m.tauN, Nk[j] * m.tauP);
             const double np_ = __builtin_fma(Nk[j], Pk[j], -m.n0p0);
             const double inv = LAY == 2 ? inv_tp[j] : rcp_nr(tp);
@@ -409,8 +413,8 @@ __device__ __forceinline__ void assemble(const MatPar &m, double a0, const doubl
             if (j >= 1 && j <= NR - 2) {            // a row that is never the system's first or last
                 dg[j] = __builtin_fma(hD, Ek[j] - Ep[j], a0 + 2.0 * D) + s;
             } else {
-                const double u_m = first ? 0.0 : __builtin_fma(-hD, Ek[j], -D);
-                const double l_p = last ? 0.0 : __builtin_fma(hD, Ep[j], -D);
+                const double u_m = zero_if_first(__builtin_fma(-hD, Ek[j], -D));
+                const double l_p = zero_if_last(__builtin_fma(hD, Ep[j], -D));
                 dg[j] = a0 - u_m - l_p + s;
             }
             bb[j] = __builtin_fma(-t, np_, __builtin_fma(s, U, -bU[j]));
