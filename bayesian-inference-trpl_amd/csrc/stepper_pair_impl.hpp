@@ -83,9 +83,9 @@ __device__ __forceinline__ void update_field2(const MatPar &m, double a0, const 
         Pm[0] = first ? 0.0 : Pm[0];
     }
 #pragma unroll
-    for (int j = 0; j < NR; j++) {
-        A[j] = (0.5 * m.Lambda) * (m.DP * (Pk[j] + Pm[j]) + m.DN * (Nk[j] + Nm[j])) + a0;
-        b[j] = m.Lambda * (m.DP * (Pk[j] - Pm[j]) - m.DN * (Nk[j] - Nm[j])) - bE[j];
+    for (int j = 0; j < NR; j++) {     // (:206-208) with Lambda folded into the diffusivities: 2 fma + 2 adds each
+        A[j] = __builtin_fma(m.hLDP, Pk[j] + Pm[j], __builtin_fma(m.hLDN, Nk[j] + Nm[j], a0));
+        b[j] = __builtin_fma(m.LDP, Pk[j] - Pm[j], __builtin_fma(-m.LDN, Nk[j] - Nm[j], -bE[j]));
     }
     rcp_rows<NR>(A, rA);
     const bool act0 = act && (lane & (WS - 1)) != 0;
@@ -120,6 +120,7 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
     MatPar mp_ = {N0, P0, DN, DP, rate, sr0, srL, CN, CP, tauN, tauP, Lambda, n0p0,
                   ln == 0 ? 1.0 : 0.0, ln == WS - 1 ? 1.0 : 0.0};
     mp_.fast_constants();
+    mp_.srS = ln >= WS / 2 ? srL : sr0;
     const MatPar mp = mp_;
     const double mag = a.xld > 12 ? xs[12] : 0.0;
     const double TOL = a.TOL;
