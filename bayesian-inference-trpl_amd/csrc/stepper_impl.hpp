@@ -336,7 +336,6 @@ struct SnapSink {
 struct MatPar {
     double N0, P0, DN, DP, rate, sr0, srL, CN, CP, tauN, tauP, Lambda, n0p0;
     double mfirst = 0.0, mlast = 0.0;   // SURF_FMA only: 1.0 on the lane that owns node 0 / node L-1, else 0.0
-    double srS = 0.0;                   // SURF_FMA only: the surface velocity this lane's half of the system evaluates
     // FAST assembly only (set by fast_constants): 2 C, C n0p0 and tau_other n0p0 of each equation
     double Co2N = 0.0, Con0N = 0.0, tVn0N = 0.0, Co2P = 0.0, Con0P = 0.0, tVn0P = 0.0;
     double LDP = 0.0, LDN = 0.0, hLDP = 0.0, hLDN = 0.0;   // Lambda DP, Lambda DN and their halves (field update)
@@ -438,7 +437,7 @@ __device__ __forceinline__ void assemble(const MatPar &m, double a0, const doubl
         // one evaluation serves both surfaces: the upper half of the wave works on node L-1
         const bool hiHalf = ln >= W / 2;
         const double Ns = hiHalf ? +Nk[NR - 1] : +Nk[0], Ps = hiHalf ? +Pk[NR - 1] : +Pk[0];
-        const double sr = SURF_FMA ? +m.srS : (hiHalf ? +m.srL : +m.sr0);
+        const double sr = hiHalf ? +m.srL : +m.sr0;
         const double Vs = IS_N ? Ps : Ns, Us = IS_N ? Ns : Ps;
         const double inv = LAY == 2 ? rcp_nr1(Ns + Ps) : rcp_nr(Ns + Ps);
         const double dss = -sr * (Vs * Vs + m.n0p0) * (inv * inv);
