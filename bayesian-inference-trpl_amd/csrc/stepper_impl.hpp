@@ -469,9 +469,9 @@ __device__ __forceinline__ void update_field(const MatPar &m, double a0, const d
     if constexpr (LAY == 2) {
         double A[NR], b[NR], rA[NR];
 #pragma unroll
-        for (int j = 0; j < NR; j++) {
-            A[j] = (0.5 * m.Lambda) * (m.DP * (Pk[j] + Pm[j]) + m.DN * (Nk[j] + Nm[j])) + a0;
-            b[j] = m.Lambda * (m.DP * (Pk[j] - Pm[j]) - m.DN * (Nk[j] - Nm[j])) - bE[j];
+        for (int j = 0; j < NR; j++) {     // (:206-208) with Lambda folded into the diffusivities
+            A[j] = __builtin_fma(m.hLDP, Pk[j] + Pm[j], __builtin_fma(m.hLDN, Nk[j] + Nm[j], a0));
+            b[j] = __builtin_fma(m.LDP, Pk[j] - Pm[j], __builtin_fma(-m.LDN, Nk[j] - Nm[j], -bE[j]));
         }
         rcp_rows<NR>(A, rA);
 #pragma unroll
