@@ -1,6 +1,7 @@
 #!/bin/bash
 # PMC counter passes for the stepper kernel (separate rocprofv3 runs, kernel-trace only, as the
-# pool requires).  Usage on the GPU box: TAG=v3 bash tools/pmc_profile.sh ; results under gpurun_out/.
+# pool requires).  Usage on the GPU box: TAG=v3 [BENCH_EXTRA="--L 512 --samples-per-gpu 32768"] bash tools/pmc_profile.sh ;
+# results under gpurun_out/.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=${TAG:-v}
@@ -10,5 +11,5 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_IFETCH SQ_IFETCH_LEVEL SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_MISC SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_INST_LEVEL_LDS SQ_INSTS" \
            "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc_${TAG}_$i -- python3 $R/bench.py --steps 1 --warmup 0 --T 100 --no-cpu-baseline --no-pcr --no-full-length > $R/gpurun_out/pmc_${TAG}_$i.log 2>&1 || echo "pmc set $i failed"
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc_${TAG}_$i -- python3 $R/bench.py --steps 1 --warmup 0 --T 100 --no-cpu-baseline --no-pcr --no-full-length $BENCH_EXTRA > $R/gpurun_out/pmc_${TAG}_$i.log 2>&1 || echo "pmc set $i failed"
 done

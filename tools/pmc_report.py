@@ -2,10 +2,12 @@
 """Summarise gpurun_out/pmc_<tag>_*/ (tools/pmc_profile.sh) for the fast stepper kernel."""
 import csv, glob, sys
 tag = sys.argv[1]
+match = sys.argv[2] if len(sys.argv) > 2 else None     # substring of the kernel name (default: the L = 128 fast steppers)
 res = {}
 for d in sorted(glob.glob('gpurun_out/pmc_%s_*/*/*_counter_collection.csv' % tag)):
     for r in csv.DictReader(open(d)):
-        if 'stepper_kernel<128, false>' in r['Kernel_Name'] or 'stepper_pair_kernel' in r['Kernel_Name']:
+        name = r['Kernel_Name']
+        if (match in name) if match else ('stepper_kernel<128, false' in name or 'stepper_pair_kernel' in name):
             res[r['Counter_Name']] = res.get(r['Counter_Name'], 0) + float(r['Counter_Value'])
 for k, v in sorted(res.items()):
     print("   %-28s %.4g" % (k, v))
