@@ -318,6 +318,18 @@ def test_snapshots_nonconvergence_small_grids_and_device_entry(gpu, oracle):
                 else:
                     scale = np.abs(want[k]).max(axis=2, keepdims=True) + 1e-300
                     assert np.max(np.abs(got[k] - want[k]) / scale) < 1e-6, (L, k)
+    # PL stored every 4th step only (plT = 4): snapshots are taken on their own steps regardless
+    want = oracle.pvsim(X[:6], lens[1], Time, 128, T, ini[1], plT=4, snap_steps=[3, 8, 29])
+    for kw in ({"strict": True}, {"kernel": "pair"}):
+        got = {}
+        pl, st, it, _ = gpu.solve_pl(X[:6], lens[1], Time, 128, T, ini[1], plT=4, snap_steps=[3, 8, 29], snapshots=got, **kw)
+        assert pl.shape == (6, T // 4 + 1) and np.max(np.abs(pl / want["plI"] - 1)) < 1e-9
+        for k in ("plN", "plP"):
+            assert np.max(np.abs(got[k] - want[k]) / want[k]) < (1e-9 if "kernel" in kw else 1e-15), (kw, k)
+    # n_snap = 0 / no output arrays: plain solve
+    pl0, _, _, _ = gpu.solve_pl(X[:6], lens[1], Time, 128, T, ini[1], snap_steps=[])
+    pl1, _, _, _ = gpu.solve_pl(X[:6], lens[1], Time, 128, T, ini[1])
+    assert np.array_equal(pl0, pl1)
     # device-resident form, unordered steps, only plP requested
     dev = torch.device("cuda", 0)
     Xd = torch.from_numpy(X[:9].copy()).to(dev)
@@ -462,3 +474,42 @@ def test_bench_two_rank_rehearsal_gathers_the_single_rank_likelihoods(gpu, tmp_p
     assert line2["nonconverged_systems"] == line1["nonconverged_systems"] == 0
     a, b = np.load(p1), np.load(p2)
     assert a.shape == b.shape == (1, 4096) and np.array_equal(a, b)
+
+
+def test_rank_driver_gathers_over_rccl_on_a_one_rank_group(gpu, tmp_path):
+    """The one-process-per-GPU driver with the REAL collective backend: a child process joins a 1-rank
+    torch.distributed group on the `nccl` backend (= RCCL on ROCm), computes its shard with the fused call and
+    gathers with dist.gather_likelihoods on the device; the gathered vector equals the direct call's."""
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+import trpl_amd
+from trpl_amd import device as tdev, workloads as wl
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+S, T, L = 301, 40, 128
+ini, lens = wl.power_scan(L)
+X = torch.from_numpy(wl.samples(S, seed=71)).to(dev)
+ini_d = torch.from_numpy(ini).to(dev)
+obs = torch.full((3, T + 1), 20.0, dtype=torch.float64, device=dev)
+P = torch.zeros(S, dtype=torch.float64, device=dev)
+sse = torch.empty((3, S), dtype=torch.float64, device=dev)
+flags = trpl_amd._abi.pin_variant(0, 3 * S, L, T)
+tdev.loglik_device(X, ini_d, lens, T * 0.025, L, T, obs, [T + 1] * 3, P, sse, flags=flags)
+full = trpl_amd.dist.gather_likelihoods(P[None, :], S)
+torch.cuda.synchronize()
+assert full.is_cuda and tuple(full.shape) == (1, S) and torch.equal(full[0], P)
+np.save(%r, full.cpu().numpy())
+dist.barrier(); dist.destroy_process_group()
+print("RCCL-OK", dist.is_nccl_available())
+''' % (ROOT, str(tmp_path / "p.npy"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, TRPL_AUTOBUILD="0"))
+    assert out.returncode == 0 and "RCCL-OK True" in out.stdout, out.stderr[-2000:]
+    w = gpu.workloads
+    ini, lens = w.power_scan(128)
+    want = gpu.loglik(w.samples(301, seed=71), ini, lens, 1.0, 128, 40, [np.full(41, 20.0)] * 3)
+    assert np.array_equal(np.load(tmp_path / "p.npy")[0], want)
