@@ -138,6 +138,11 @@ def _share_torch_hip_runtime():
                 C.CDLL(path, mode=C.RTLD_GLOBAL)
             except OSError:
                 return
+    # ... and the RCCL that was built against that runtime is the one trpl_multi_create binds (by path, at its
+    # first call; nothing is loaded here)
+    rccl = os.path.join(libdir, "librccl.so")
+    if os.path.isfile(rccl):
+        os.environ.setdefault("TRPL_RCCL_LIBRARY", rccl)
 
 
 def lib():
