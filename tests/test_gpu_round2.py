@@ -513,3 +513,38 @@ print("RCCL-OK", dist.is_nccl_available())
     ini, lens = w.power_scan(128)
     want = gpu.loglik(w.samples(301, seed=71), ini, lens, 1.0, 128, 40, [np.full(41, 20.0)] * 3)
     assert np.array_equal(np.load(tmp_path / "p.npy")[0], want)
+
+
+def test_host_buffer_solve_writes_pl_straight_into_the_callers_memory(gpu):
+    """A PL block above 8 MB is written by the kernel directly into the caller's (page-locked and mapped for the
+    call) numpy buffer -- also a row-strided view of a larger array, float32 and float64 -- and equals the
+    device-resident solve bit for bit; the bytes between the rows of the view are untouched."""
+    import torch
+    w = gpu.workloads
+    ini, lens = w.power_scan(128)
+    S, T = 1024, 2200
+    Time = T * 0.025
+    X = w.samples(S, seed=81)[:, :12]
+    dev = torch.device("cuda", 0)
+    Xd = torch.from_numpy(X.copy()).to(dev)
+    ini_d = torch.from_numpy(ini[1]).to(dev)
+    for dtype, tdt in ((np.float32, torch.float32), (np.float64, torch.float64)):
+        ref = torch.empty((S, T + 1), dtype=tdt, device=dev)
+        gpu.device.solve_pl_device(Xd, lens[1], Time, 128, T, ini_d, ref)
+        torch.cuda.synchronize()
+        ref = ref.cpu().numpy()
+        plain = np.empty((S, T + 1), dtype=dtype)
+        assert plain.nbytes > (8 << 20)
+        _, st, it, sec = gpu.solve_pl(X, lens[1], Time, 128, T, ini[1], out=plain)
+        assert sec > 0 and not st.any() and np.array_equal(plain, ref)
+        big = np.full((S, T + 1 + 37), -5.0, dtype=dtype)
+        view = big[:, 5:5 + T + 1]
+        gpu.solve_pl(X, lens[1], Time, 128, T, ini[1], out=view)
+        assert np.array_equal(view, ref)
+        assert (big[:, :5] == -5.0).all() and (big[:, 5 + T + 1:] == -5.0).all()
+    # the same buffer again right away (registration is per call), and from two threads at once
+    from concurrent.futures import ThreadPoolExecutor
+    bufs = [np.empty((S, T + 1), dtype=np.float32) for _ in range(2)]
+    with ThreadPoolExecutor(2) as ex:
+        list(ex.map(lambda b: gpu.solve_pl(X, lens[1], Time, 128, T, ini[1], out=b), bufs))
+    assert np.array_equal(bufs[0], bufs[1])
