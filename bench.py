@@ -19,7 +19,8 @@ steps after the excitation need many more inner iterations than the rest, so sho
 under-state the full-length rate (3.2 iterations per step at T = 1000, 2.2 at 8000, 2.0 at 80 000):
 `--T 80000` runs the full length, `--T 1000` the transient-dominated case of the earlier profiles.
 
-At N = 1 the line also carries `full_length`: ONE extra pass at the production length T = 80 000 over the
+At N = 1 the line also carries `host_api_block` -- the reference's own call sequence (pvSim -> fastlog -> prob per
+curve, host buffers) on one reference-shaped 1024-sample block, PCIe included -- and `full_length`: ONE extra pass at the production length T = 80 000 over the
 same resident batch (event-timed, ~26 s), so that the full-length rate is measured by every driver run.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
@@ -67,6 +68,8 @@ def main():
     ap.add_argument("--tol", type=int, default=None, help="convergence exponent (default 7, the reference's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcr", action="store_true")
+    ap.add_argument("--no-host-api", action="store_true",
+                    help="skip the reference-API (host-buffer) block: pvSim -> fastlog -> prob on 1024 samples (N = 1 only)")
     ap.add_argument("--no-full-length", action="store_true",
                     help="skip the one extra pass at the reference's production length T = 80000 (N = 1 only, ~26 s)")
     ap.add_argument("--full-length-T", type=int, default=80000)
@@ -258,6 +261,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_full_length and args.full_length_T != T:
         out["full_length"] = full_length_pass(torch, tdev, trpl_amd, dev, X, ini_d, mark, lens, L, args.full_length_T, dt_ns,
                                               flags, tol, C, args.fp32)
+    if rank == 0 and world == 1 and not args.no_host_api and L == 128 and not (args.fp32 or args.mixed or args.strict):
+        out["host_api_block"] = host_api_block(trpl_amd, wl, ini, lens, L, T, dt_ns)
     if rank == 0:
         attach_traffic(out, args.traffic_profile)
     out.update(cpu_legs)
@@ -302,6 +307,37 @@ def full_length_pass(torch, tdev, trpl_amd, dev, X, ini_d, mark, lens, L, T, dt_
             "nonconverged_systems": int((status != 0).sum().item()),
             "roofline_achieved_tflops": tf, "roofline_frac": tf / peak,
             "finite_likelihoods": int(torch.isfinite(P).sum().item())}
+
+
+def host_api_block(trpl_amd, wl, ini, lens, L, T, dt_ns, S=1024):
+    """The reference's own call sequence on one reference-shaped block (parallel_bayes_gpu.py:104: sims_per_gpu =
+    1024; bayeslib.py:137-196): per curve pvSim -> fastlog -> prob through the HOST-BUFFER entry points, float32 PL
+    buffer, observations on the whole grid, PCIe and host work included -- the rate a caller gets who swaps only the
+    three callables (the fused path above is the one to use)."""
+    X = wl.samples(S)
+    Time = T * dt_ns
+    par = [float(lens[0]), Time, L, T, 1, (0,), 7, 10000]
+    vals = np.full(T + 1, -3.0)
+    mag = np.ascontiguousarray(X[:, -1])
+    pl = np.empty((S, T + 1), dtype=np.float32)
+    P = np.zeros(S)
+    trpl_amd.pvSim(pl[:8], None, None, None, X[:8, :-1], par, ini[0], init_mode="points")       # context warm-up
+    t_solve = t_log = t_prob = 0.0
+    t0 = time.perf_counter()
+    for c in range(len(lens)):
+        par[0] = float(lens[c])
+        a = time.perf_counter()
+        trpl_amd.pvSim(pl, None, None, None, X[:, :-1], par, ini[c], init_mode="points")
+        b = time.perf_counter()
+        trpl_amd.fastlog(pl, sys.float_info.min)
+        c2 = time.perf_counter()
+        trpl_amd.prob(P, pl, vals, None, mag)
+        d = time.perf_counter()
+        t_solve += b - a; t_log += c2 - b; t_prob += d - c2
+    wall = time.perf_counter() - t0
+    return {"samples": S, "curves": len(lens), "T": T, "pl_dtype": "float32", "wall_s": wall, "pvSim_s": t_solve,
+            "fastlog_s": t_log, "prob_s": t_prob, "system_timesteps_per_s": S * len(lens) * (T + 1) / wall,
+            "finite_likelihoods": int(np.isfinite(P).sum())}
 
 
 def _profile_key(path):

@@ -456,7 +456,7 @@ def test_bench_two_rank_rehearsal_gathers_the_single_rank_likelihoods(gpu, tmp_p
     """bench.py --gpus 2 --backend gloo as fresh child processes sharing this box's GPU (the N > 1 path:
     sample shards, pinned kernel variant, all-gather, max-over-ranks timing) must print one contract line
     and gather exactly the likelihood vector a single rank computes for the same 4 096 samples."""
-    common = ["--steps", "1", "--warmup", "0", "--T", "200", "--no-cpu-baseline", "--no-pcr", "--no-full-length"]
+    common = ["--steps", "1", "--warmup", "0", "--T", "200", "--no-cpu-baseline", "--no-pcr", "--no-full-length", "--no-host-api"]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", TRPL_AUTOBUILD="0")
     p1, p2 = str(tmp_path / "p1.npy"), str(tmp_path / "p2.npy")
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--samples-per-gpu", "4096",

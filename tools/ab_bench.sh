@@ -7,7 +7,7 @@ shift
 for i in $(seq $REPS); do
   for which in prev cur; do
     if [ $which = prev ]; then export TRPL_LIBRARY=$R/tools/ab/libtrpl_prev.so; else unset TRPL_LIBRARY; fi
-    v=$(timeout -k 10 300 python3 $R/bench.py --no-cpu-baseline --no-pcr --no-full-length "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.4e it/s %.4e' % (d['value'], d['inner_iterations_per_s']))")
+    v=$(timeout -k 10 300 python3 $R/bench.py --no-cpu-baseline --no-pcr --no-full-length --no-host-api "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.4e it/s %.4e' % (d['value'], d['inner_iterations_per_s']))")
     echo "$which $v"
   done
 done
