@@ -79,12 +79,14 @@ void curve_const(double length, double time_ns, int L, int64_t T, trpl::CurveCon
 }
 
 // FAST, L = 128 has two kernels: one system per wavefront (3 waves per SIMD: 12 systems per CU in
-// flight) and two systems per wavefront (2 waves per SIMD: 16 systems per CU, +25..37 % throughput once
-// the chip is kept full, but ~10 % slower per wave).  A launch's duration is set by its slowest chain of
-// systems, so the paired kernel only pays when the chip stays full for most of the launch: more systems
-// than the one-system kernel holds at once, and -- for short windows, where the first time steps' 20-900
-// inner iterations make the work per system very uneven -- at least five such fills.  Measured crossover
-// (MI355X, Power_scan): `steps` = 8000: paired wins from 4 098 systems (+9 %); 1000: from ~15 000.
+// flight) and two systems per wavefront (2 waves per SIMD: 16 systems per CU, +25..40 % throughput once
+// the chip is kept full, but ~15 % slower per wave when it is not).  A launch's duration is set by its slowest
+// chain of systems, so the paired kernel only pays when the chip stays full for most of the launch: more
+// systems than the one-system kernel holds at once, and -- for short windows, where the first time steps'
+// 20-900 inner iterations make the work per system very uneven -- at least two and a half such fills.
+// Measured crossover (MI355X, Power_scan, round-2 kernels, tools/small_launch_probe.py; pair / single time):
+//   steps = 8000:  1024 systems 1.15, 3072: 1.01, 4096: 0.91, 8192: 0.86, 12 288: 0.82
+//   steps = 1000:  4096: 0.96, 6144: 0.99, 8192: 0.92, 12 288: 0.88
 // TRPL_FLAG_KERNEL_PAIR / _SINGLE force the choice per call; the environment variable TRPL_PAIR=0 / 1
 // forces it for a whole process (measurements only; the flags win).
 bool use_pair_kernel(int64_t nsys, int64_t steps)
@@ -102,7 +104,7 @@ bool use_pair_kernel(int64_t nsys, int64_t steps)
         cus = cached_cus;
     }
     const int64_t fill = (int64_t)cus * 12;
-    return nsys > fill && (steps >= 4000 || nsys >= 5 * fill);
+    return nsys > fill && (steps >= 4000 || 2 * nsys >= 5 * fill);
 }
 
 constexpr uint32_t kVariantBits = TRPL_FLAG_KERNEL_PAIR | TRPL_FLAG_KERNEL_SINGLE;

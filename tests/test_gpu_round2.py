@@ -142,20 +142,20 @@ def test_variant_flags_are_validated(gpu):
 # ------------------------------------------------------------------ sharding invariance
 def test_sharded_batch_equals_single_launch_across_the_pair_threshold(gpu):
     """The whole batch is above the paired kernel's threshold, every shard is below it: the variant is a
-    property of the logical batch, so trpl_loglik_multi (4 shards) and a rank driver that pins its flags
+    property of the logical batch, so trpl_loglik_multi (8 shards) and a rank driver that pins its flags
     from the total (dist / bench.py) return bit for bit the single launch's likelihoods."""
     w = gpu.workloads
     S, T, Time = 5124, 40, 1.0
     lib = gpu._abi.lib()
     A = gpu._abi
     assert lib.trpl_kernel_variant(3 * S, 128, T, 0) == A.KERNEL_FAST_PAIR
-    assert lib.trpl_kernel_variant(3 * (S // 4), 128, T, 0) == A.KERNEL_FAST
+    assert lib.trpl_kernel_variant(3 * (S // 8 + 1), 128, T, 0) == A.KERNEL_FAST
     ini, lens = w.power_scan(128)
     X = w.samples(S, seed=31)
     obs = [np.full(T + 1, 20.0) - 0.01 * np.arange(T + 1)] * 3
     one, multi = {}, {}
     want = gpu.loglik(X, ini, lens, Time, 128, T, obs, info=one)
-    got = gpu.loglik(X, ini, lens, Time, 128, T, obs, info=multi, devices=[0, 0, 0, 0])
+    got = gpu.loglik(X, ini, lens, Time, 128, T, obs, info=multi, devices=[0] * 8)
     assert np.array_equal(got, want)
     for k in ("sse", "status", "iters_total"):
         assert np.array_equal(multi[k], one[k]), k
@@ -170,7 +170,7 @@ def test_sharded_batch_equals_single_launch_across_the_pair_threshold(gpu):
         assert np.array_equal(np.concatenate(parts), want)
     # without the pin the shards would run the other kernel: close (rounding), not identical -- the
     # documented reason for pinning
-    lo, hi = gpu.dist.shard_bounds(S, 4, 1)
+    lo, hi = gpu.dist.shard_bounds(S, 8, 1)
     unpinned = gpu.loglik(X[lo:hi], ini, lens, Time, 128, T, obs)
     assert np.allclose(unpinned, want[lo:hi], rtol=1e-10, atol=0)
     # a small batch stays on the one-system kernel in every shard
