@@ -387,15 +387,24 @@ def bench_pcr(torch, tdev, dev, flags, S=65536, L=128, reps=48, dtype=None, nset
     w = 8 if dtype == torch.float64 else 4
     g = torch.Generator(device=dev)
     g.manual_seed(7)
+    # The five arrays of a set are views into one allocation, each placed `skew` bytes past a multiple of the
+    # array size: operands that sit at the same offset modulo a large power of two (what five separate
+    # 64 MiB allocations give) send a wave's four loads to the same HBM channel, which costs ~6 % here
+    # (tools/pcr_layout_probe.py: 5.26 TB/s aligned, 5.56-5.58 TB/s from a 4 KiB skew on); include/trpl.h
+    # recommends the skew to callers.
+    skew = (4096 + 256) // w
+    n = S * L
     sets = []
     for _ in range(nsets):
-        ld = torch.rand((S, L), dtype=dtype, device=dev, generator=g) * 2 - 1
-        ud = torch.rand((S, L), dtype=dtype, device=dev, generator=g) * 2 - 1
-        d = torch.rand((S, L), dtype=dtype, device=dev, generator=g) * 1.5 + 2.5
-        b = torch.randn((S, L), dtype=dtype, device=dev, generator=g)
+        buf = torch.empty(5 * (n + skew), dtype=dtype, device=dev)
+        ld, d, ud, b, x = (buf[i * (n + skew): i * (n + skew) + n].view(S, L) for i in range(5))
+        ld.copy_(torch.rand((S, L), dtype=dtype, device=dev, generator=g) * 2 - 1)
+        ud.copy_(torch.rand((S, L), dtype=dtype, device=dev, generator=g) * 2 - 1)
+        d.copy_(torch.rand((S, L), dtype=dtype, device=dev, generator=g) * 1.5 + 2.5)
+        b.copy_(torch.randn((S, L), dtype=dtype, device=dev, generator=g))
         ld[:, 0] = 0
         ud[:, -1] = 0
-        sets.append((ld, d, ud, b, torch.empty_like(d)))
+        sets.append((ld, d, ud, b, x))
     for i in range(2 * nsets):
         ld, d, ud, b, x = sets[i % nsets]
         tdev.pcr_solve_device(ld, d, ud, b, x, flags=flags)
@@ -423,6 +432,7 @@ def bench_pcr(torch, tdev, dev, flags, S=65536, L=128, reps=48, dtype=None, nset
             "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "systems": S, "L": L,
             "bytes_per_launch": nbytes, "avg_launch_ms": ms, "systems_per_s": S / (ms * 1e-3),
             "operand_sets": nsets, "operand_bytes_rotated": nsets * nbytes, "launches_timed": reps,
+            "operand_skew_bytes": skew * w,
             "max_abs_residual": res}
 
 

@@ -364,7 +364,9 @@ int trpl_posterior_hist_dev(const double *x, const double *y, const double *W, i
  * it.  Default (FAST): in-lane cyclic-reduction levels, then PCR on one row per lane with
  * Newton-refined reciprocals, then back-substitution -- the same solution to rounding
  * (both are exact eliminations), not the same operation order.
- * Algorithmic traffic 5 * L * elem_bytes per system.
+ * Algorithmic traffic 5 * L * elem_bytes per system.  Placement: five arrays that sit at the same offset
+ * modulo a large power of two (separate 64 MiB allocations) send a wavefront's four loads to the same HBM
+ * channel; offsetting each array by a further 4 KiB is worth ~6 % (5.26 -> 5.57 TB/s on MI355X).
  * ------------------------------------------------------------------------------------- */
 int trpl_pcr_solve_batched_dev(const void *ld, const void *d, const void *ud, const void *b,
                                void *x, int64_t S, int32_t L, int32_t elem_bytes, uint32_t flags,
