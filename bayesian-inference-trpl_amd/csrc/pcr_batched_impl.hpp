@@ -2,44 +2,87 @@
 // operands and result in HBM ([S][L] arrays), one wavefront per system; STRICT: the elimination order
 // of pcreduce (pvSimPCR.py:42-81), FAST: cyclic reduction in-lane + PCR on one row per lane (pcr.hpp).
 // Bound: HBM bandwidth, 5*L*sizeof(T) algorithmic bytes per system (read ld, d, ud, b; write x).
-// Measured and NOT adopted (round 2, operands rotated through 1.34 GB so that nothing is served by the
-// Infinity Cache; tools/bench_pcr_ab.py): a persistent launch whose waves load system i+1 before solving
-// system i: 5.17 TB/s against 5.41 TB/s for this one-pass form (the hardware's own wave switching already
-// overlaps the loads of 16 resident waves per CU with the solves); the same with non-temporal loads: 5.48.
-// Four read streams + one write stream saturate at ~5.5 TB/s here (the guide's 6.3 TB/s is a 1:1 copy).
+// Also measured (round 2): a persistent launch whose waves load system i+1 before solving system i is SLOWER
+// than letting the hardware switch between many one-system waves (5.17 vs 5.41 TB/s); the placement of the five
+// arrays matters (include/trpl.h).
 #pragma once
 #include "stepper_f32_impl.hpp"
 
 namespace trpl {
 
+// Launch shape and load policy, measured with the operands rotated through 1.34 GB (tools/bench_pcr_ab.py, GB/s at
+// L = 128 fp64 | L = 128 fp32 | L = 256 fp64 | L = 512 fp32 | L = 512 fp64):
+//   4 waves per workgroup, 2 systems per wave (round 1)      5519 | 5382 | 5835 | 5829 | 5530
+//   1 wave per workgroup, one system per wave                5690 | 5583 | 5936 | 5929 | 5706
+//   ... + non-temporal loads                                 6467 | 6040 | 5429 | 5424 | 3854
+// Non-temporal (streaming) loads pay when every cache line is consumed by ONE load instruction -- a lane's
+// chunk of a row is at most 16 bytes -- and cost up to 2x HBM reads when a lane needs several 16-byte loads
+// per row (interleaved layout, NR * sizeof(T) > 16: the line is gone before the second instruction asks for
+// its other half).  So: one wave per workgroup everywhere, non-temporal loads only for 16-byte chunks.
+#ifndef TRPL_PCRB_WAVES
+#define TRPL_PCRB_WAVES 1       // wavefronts per workgroup
+#endif
+#ifndef TRPL_PCRB_NT
+#define TRPL_PCRB_NT -1         // -1: automatic (see above), 0: never, 1: non-temporal loads always
+#endif
+#ifndef TRPL_PCRB_CAP
+#define TRPL_PCRB_CAP 256       // grid cap: 256 * CAP workgroups, beyond that a wave loops over systems
+#endif
+
+template <bool NT, typename T> __device__ __forceinline__ T pcrb_load(const T *p)
+{
+    if constexpr (NT) return __builtin_nontemporal_load(p); else return *p;
+}
+
+// a lane's NR adjacent elements, 16 bytes per load instruction where the row allows it (global memory needs
+// dword alignment only, so the vector type is declared with the element's alignment)
+template <bool NT, typename T, int NR>
+__device__ __forceinline__ void pcrb_load_row(const T *p, T (&v)[NR])
+{
+    constexpr int PER = 16 / sizeof(T);
+    if constexpr (NR % PER == 0) {
+        typedef T vec16 __attribute__((ext_vector_type(PER), aligned(sizeof(T))));
+#pragma unroll
+        for (int k = 0; k < NR / PER; k++) {
+            vec16 t;
+            if constexpr (NT) t = __builtin_nontemporal_load(reinterpret_cast<const vec16 *>(p) + k);
+            else t = reinterpret_cast<const vec16 *>(p)[k];
+#pragma unroll
+            for (int e = 0; e < PER; e++) v[k * PER + e] = t[e];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NR; j++) v[j] = pcrb_load<NT>(p + j);
+    }
+}
+
 template <typename T, int L, bool STRICT>
-__global__ void __launch_bounds__(256) pcr_batched_kernel(const T *__restrict__ ld, const T *__restrict__ d,
+__global__ void __launch_bounds__(64 * TRPL_PCRB_WAVES) pcr_batched_kernel(const T *__restrict__ ld, const T *__restrict__ d,
                                                           const T *__restrict__ ud, const T *__restrict__ b,
                                                           T *__restrict__ x, int64_t S)
 {
     constexpr int W = L < 64 ? L : 64;
     constexpr int NR = L / W;
+    constexpr bool NT = TRPL_PCRB_NT < 0 ? (NR * sizeof(T) <= 16) : (TRPL_PCRB_NT >= 1);
     const int lane = threadIdx.x & 63;
     const int ln = lane & (W - 1);
     // exchange buffer of the solve, private to each of the 4 waves: the cyclic-reduction + PCR solver stages one
     // value per lane and array (3 x 64), the pure-PCR variants all L rows
     constexpr int XW = TRPL_CR_HYBRID != 0 ? 64 : L;
-    __shared__ __attribute__((aligned(16))) T xch_all[(!STRICT && L >= 128) ? 4 * 3 * XW : 4];
+    __shared__ __attribute__((aligned(16))) T xch_all[(!STRICT && L >= 128) ? TRPL_PCRB_WAVES * 3 * XW : 4];
     T *xch = xch_all + (threadIdx.x >> 6) * 3 * XW;
     (void)xch;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t wave = (int64_t)blockIdx.x * TRPL_PCRB_WAVES + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * TRPL_PCRB_WAVES;
     for (int64_t s = wave; s < S; s += nwaves) {
         const int64_t base = s * L;
         T vl[NR], vd[NR], vu[NR], vb[NR], vx[NR];
         if constexpr (!STRICT && L >= 128) {
             // interleaved layout: lane owns nodes NR*lane .. NR*lane+NR-1 -> 16-byte loads, fully
             // coalesced 1 KiB per wave-instruction
-#pragma unroll
-            for (int j = 0; j < NR; j++) {
-                const int64_t o = base + NR * lane + j;
-                vl[j] = ld[o]; vd[j] = d[o]; vu[j] = ud[o]; vb[j] = b[o];
-            }
+            const int64_t o = base + NR * lane;
+            pcrb_load_row<NT>(ld + o, vl); pcrb_load_row<NT>(d + o, vd);
+            pcrb_load_row<NT>(ud + o, vu); pcrb_load_row<NT>(b + o, vb);
             if constexpr (TRPL_CR_HYBRID != 0) cr_pcr_solve<T, NR>(vl, vd, vu, vb, vx, lane, xch);
             else if constexpr (sizeof(T) == 8) pcr_solve_L<NR, L>(vl, vd, vu, vb, vx, lane, xch);
             else                          f32::pcr_solve<NR, L>(vl, vd, vu, vb, vx, lane, xch);
@@ -49,7 +92,7 @@ __global__ void __launch_bounds__(256) pcr_batched_kernel(const T *__restrict__ 
 #pragma unroll
             for (int j = 0; j < NR; j++) {
                 const int64_t o = base + ln + W * j;
-                vl[j] = ld[o]; vd[j] = d[o]; vu[j] = ud[o]; vb[j] = b[o];
+                vl[j] = pcrb_load<NT>(ld + o); vd[j] = pcrb_load<NT>(d + o); vu[j] = pcrb_load<NT>(ud + o); vb[j] = pcrb_load<NT>(b + o);
             }
             tridiag_solve<STRICT, T, NR, W, L>(vl, vd, vu, vb, vx, ln);
             if (lane < W) {
@@ -65,9 +108,9 @@ hipError_t launch_pcr_batched_t(const void *ld, const void *d, const void *ud, c
                                 int L, hipStream_t stream)
 {
     if (S <= 0) return hipSuccess;
-    int64_t blocks = (S + 3) / 4;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    dim3 grid((unsigned)blocks), block(256);
+    int64_t blocks = (S + TRPL_PCRB_WAVES - 1) / TRPL_PCRB_WAVES;
+    if (blocks > 256 * (int64_t)TRPL_PCRB_CAP) blocks = 256 * (int64_t)TRPL_PCRB_CAP;
+    dim3 grid((unsigned)blocks), block(64 * TRPL_PCRB_WAVES);
     switch (L) {
 #define TRPL_CASE(LL)                                                                                      \
     case LL:                                                                                               \
