@@ -2,6 +2,7 @@
 # Same-box A/B of two builds of libtrpl_hip.so: tools/ab/libtrpl_prev.so (copy of an earlier build) against
 # the in-tree library, alternating, default bench workload.  Usage on the GPU box: bash tools/ab_bench.sh [reps] [bench args]
 R=$GRAFT_REPO_ROOT
+export TRPL_AUTOBUILD=0        # the library travels with the snapshot: never start a build under the profiler or between A/B runs
 REPS=${1:-3}
 shift
 for i in $(seq $REPS); do

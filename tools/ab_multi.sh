@@ -1,6 +1,7 @@
 #!/bin/bash
 # Same-box comparison of several library builds under tools/ab/*.so (alternating): bash tools/ab_multi.sh [reps] [bench args]
 R=$GRAFT_REPO_ROOT
+export TRPL_AUTOBUILD=0        # the library travels with the snapshot: never start a build under the profiler or between A/B runs
 REPS=${1:-2}
 shift
 for i in $(seq $REPS); do

@@ -4,6 +4,7 @@
 # results under gpurun_out/.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+export TRPL_AUTOBUILD=0        # the library travels with the snapshot: never start a build under the profiler or between A/B runs
 TAG=${TAG:-v}
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \

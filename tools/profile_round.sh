@@ -5,6 +5,7 @@
 # Everything lands under gpurun_out/<tag>/; tools/parse_rocprof.py turns it into profiles/.
 TAG=${1:-rX}
 R=$GRAFT_REPO_ROOT
+export TRPL_AUTOBUILD=0        # the library travels with the snapshot: never start a build under the profiler or between A/B runs
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
