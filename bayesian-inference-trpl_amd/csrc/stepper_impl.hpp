@@ -440,8 +440,10 @@ __device__ __forceinline__ void assemble(const MatPar &m, double a0, const doubl
         const double sr = hiHalf ? +m.srL : +m.sr0;
         const double Vs = IS_N ? Ps : Ns, Us = IS_N ? Ns : Ps;
         const double inv = LAY == 2 ? rcp_nr1(Ns + Ps) : rcp_nr(Ns + Ps);
-        const double dss = -sr * (Vs * Vs + m.n0p0) * (inv * inv);
-        const double fs = sr * (Ns * Ps - m.n0p0) * inv + dss * Us;
+        // ds_s = -sr (V^2 + n0p0) / (N+P)^2,  f_s = sr (N P - n0p0) / (N+P) + ds_s U   (:165-170), with g = sr / (N+P)
+        const double g = sr * inv;
+        const double dss = -(g * inv) * __builtin_fma(Vs, Vs, m.n0p0);
+        const double fs = __builtin_fma(g, __builtin_fma(Ns, Ps, -m.n0p0), dss * Us);
         if constexpr (SURF_FMA) {
             // branch-free: the two lane-conditional updates as four fmas with 0/1 lane masks, so that the
             // iteration body stays one basic block (the paired kernel: every wave holds surface lanes)

@@ -59,7 +59,8 @@ __device__ __forceinline__ void residual_below2(const double (&l)[NR], const dou
     double q = 0.0;
 #pragma unroll
     for (int j = 0; j < NR; j++) {
-        const double r = fabs(l[j] * cm[j] + dg[j] * c[j] + u[j] * cp[j] - b[j]);
+        // (A c - b)_j as three nested fmas (one operation less than sum-then-subtract; rounding-level difference)
+        const double r = fabs(__builtin_fma(l[j], cm[j], __builtin_fma(dg[j], c[j], __builtin_fma(u[j], cp[j], -b[j]))));
         const double qj = __builtin_fma(-TOL, fabs(b[j]), r);
         q = j == 0 ? qj : q + qj;
     }
