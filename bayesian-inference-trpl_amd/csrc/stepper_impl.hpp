@@ -82,7 +82,8 @@ __device__ __forceinline__ bool residual_below(const double (&l)[NR], const doub
 #pragma unroll
     for (int j = 0; j < NR; j++) {
         // l = 0 on row 0 and u = 0 on row L-1, so the wrapped neighbour contributes +-0
-        r[j] = fabs(l[j] * cm[j] + dg[j] * c[j] + u[j] * cp[j] - b[j]);
+        if constexpr (LAY == 0) r[j] = fabs(l[j] * cm[j] + dg[j] * c[j] + u[j] * cp[j] - b[j]);      // the reference's order
+        else r[j] = fabs(__builtin_fma(l[j], cm[j], __builtin_fma(dg[j], c[j], __builtin_fma(u[j], cp[j], -b[j]))));
         ab[j] = fabs(b[j]);
     }
     if constexpr (LAY == 2) {
@@ -339,6 +340,15 @@ struct MatPar {
     // FAST assembly only (set by fast_constants): 2 C, C n0p0 and tau_other n0p0 of each equation
     double Co2N = 0.0, Con0N = 0.0, tVn0N = 0.0, Co2P = 0.0, Con0P = 0.0, tVn0P = 0.0;
     double LDP = 0.0, LDN = 0.0, hLDP = 0.0, hLDN = 0.0;   // Lambda DP, Lambda DN and their halves (field update)
+    // SURF_FMA only: D and D/2 of each equation, zeroed on the lane that owns the system's first / last node, so
+    // that the boundary rows' stencil entries vanish without a select or an extra fma
+    double DNf = 0.0, hDNf = 0.0, DPf = 0.0, hDPf = 0.0, DNl = 0.0, hDNl = 0.0, DPl = 0.0, hDPl = 0.0;
+    __device__ __forceinline__ void boundary_constants()
+    {
+        const double kf = 1.0 - mfirst, kl = 1.0 - mlast;
+        DNf = kf * DN; hDNf = 0.5 * DNf; DPf = kf * DP; hDPf = -0.5 * DPf;
+        DNl = kl * DN; hDNl = 0.5 * DNl; DPl = kl * DP; hDPl = -0.5 * DPl;
+    }
     __device__ __forceinline__ void fast_constants()
     {
         Co2N = 2.0 * CN; Con0N = CN * n0p0; tVn0N = tauP * n0p0;
@@ -397,12 +407,16 @@ __device__ __forceinline__ void assemble(const MatPar &m, double a0, const doubl
             const double hD = IS_N ? 0.5 * D : -0.5 * D;
             const double tauO = IS_N ? m.tauN : m.tauP;
             const double Co2 = IS_N ? m.Co2N : m.Co2P, Con0 = IS_N ? m.Con0N : m.Con0P, tVn0 = IS_N ? m.tVn0N : m.tVn0P;
-            // boundary rows: with per-lane 0/1 masks (the paired kernel) x - mask * x is x or an exact 0 in one
-            // fma, instead of a two-dword select
-            auto zero_if_first = [&](double x) { return SURF_FMA ? (j == 0 ? __builtin_fma(-m.mfirst, x, x) : x) : (first ? 0.0 : x); };
-            auto zero_if_last = [&](double x) { return SURF_FMA ? (j == NR - 1 ? __builtin_fma(-m.mlast, x, x) : x) : (last ? 0.0 : x); };
-            const double u_i = zero_if_last(__builtin_fma(-hD, Ep[j], -D));
-            const double l_i = zero_if_first(__builtin_fma(hD, Ek[j], -D));
+            // boundary rows: the paired kernel carries per-lane diffusivities that are exact zeros on the lane owning
+            // the system's first / last node (hD E -+ D is then 0 - 0): no select, no extra operation
+            const double Dfj = SURF_FMA && j == 0 ? (IS_N ? m.DNf : m.DPf) : D;
+            const double hDfj = SURF_FMA && j == 0 ? (IS_N ? m.hDNf : m.hDPf) : hD;
+            const double Dlj = SURF_FMA && j == NR - 1 ? (IS_N ? m.DNl : m.DPl) : D;
+            const double hDlj = SURF_FMA && j == NR - 1 ? (IS_N ? m.hDNl : m.hDPl) : hD;
+            auto zero_if_first = [&](double x) { return SURF_FMA ? x : (first ? 0.0 : x); };
+            auto zero_if_last = [&](double x) { return SURF_FMA ? x : (last ? 0.0 : x); };
+            const double u_i = zero_if_last(__builtin_fma(-hDlj, Ep[j], -Dlj));
+            const double l_i = zero_if_first(__builtin_fma(hDfj, Ek[j], -Dfj));
             const double tp = __builtin_fma(Pk[j], m.tauN, Nk[j] * m.tauP);
             const double np_ = __builtin_fma(Nk[j], Pk[j], -m.n0p0);
             const double inv = LAY == 2 ? inv_tp[j] : rcp_nr(tp);
@@ -415,8 +429,8 @@ __device__ __forceinline__ void assemble(const MatPar &m, double a0, const doubl
             if (j >= 1 && j <= NR - 2) {            // a row that is never the system's first or last
                 dg[j] = __builtin_fma(hD, Ek[j] - Ep[j], a0 + 2.0 * D) + s;
             } else {
-                const double u_m = zero_if_first(__builtin_fma(-hD, Ek[j], -D));
-                const double l_p = zero_if_last(__builtin_fma(hD, Ep[j], -D));
+                const double u_m = zero_if_first(__builtin_fma(-hDfj, Ek[j], -Dfj));
+                const double l_p = zero_if_last(__builtin_fma(hDlj, Ep[j], -Dlj));
                 dg[j] = a0 - u_m - l_p + s;
             }
             bb[j] = __builtin_fma(-t, np_, __builtin_fma(s, U, -bU[j]));

@@ -121,6 +121,7 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
     MatPar mp_ = {N0, P0, DN, DP, rate, sr0, srL, CN, CP, tauN, tauP, Lambda, n0p0,
                   ln == 0 ? 1.0 : 0.0, ln == WS - 1 ? 1.0 : 0.0};
     mp_.fast_constants();
+    mp_.boundary_constants();
     const MatPar mp = mp_;
     const double mag = a.xld > 12 ? xs[12] : 0.0;
     const double TOL = a.TOL;
