@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
             const bool okN = residual_below<NR>(lo_, dg, up, bb, Nk, TOL, lane);
             cr_pcr_solve<float, NR>(lo_, dg, up, bb, Nk, lane, xch);
             assemble<false, NR, L>(mp, a0, Nk, Pk, Ek, Ep, bP, lo_, dg, up, bb, lane);
-            const bool okP = residual_below<NR>(lo_, dg, up, bb, Pk, TOL, lane);
+            const bool okP = okN ? residual_below<NR>(lo_, dg, up, bb, Pk, TOL, lane) : false;     // only decides if okN
             cr_pcr_solve<float, NR>(lo_, dg, up, bb, Pk, lane, xch);
             update_field<NR>(mp, a0, Nk, Pk, bE, Ek, lane);
             if (okN && okP) { it = iters + 1; break; }

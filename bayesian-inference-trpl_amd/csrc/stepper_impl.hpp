@@ -656,7 +656,9 @@ __global__ void __launch_bounds__(64, (STRICT || L > 128) ? (L > 256 ? 1 : 2) : 
             if constexpr (MIXED) {
                 okP = correct_mixed<NR>(lo_, dg, up, bb, Pk, TOL, ln, (float *)xch);
             } else {
-                okP = residual_below<LAY, NR, W>(lo_, dg, up, bb, Pk, TOL, ln);                    // :200
+                // the holes' norm decides nothing unless the electrons' has passed (:213): skipped otherwise (a
+                // wave-uniform branch; on the first iteration of a time step it practically always is)
+                okP = okN ? residual_below<LAY, NR, W>(lo_, dg, up, bb, Pk, TOL, ln) : false;       // :200
                 solve_lay<LAY, NR, W, L>(lo_, dg, up, bb, Pk, ln, xch);                                 // :202
             }
             // ---- field on edges 1..L-1 (:205-209) ----

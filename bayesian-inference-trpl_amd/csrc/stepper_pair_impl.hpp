@@ -225,7 +225,12 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
             for (int j = 0; j < NR; j++) Nk[j] = act ? x[j] : Nk[j];
             // ---- holes, with the updated electrons (:178-202) ----
             assemble<LAY, false, NR, WS, L, true>(mp, a0, Nk, Pk, Ek, Ep, bP, lo_, dg, up, bb, ln);
-            residual_below2<ISO>(lo_, dg, up, bb, Pk, TOL, lane, okPA, okPB);                      // :200
+            // the holes' norm only matters if the electrons' passed for a system that is still iterating (:213):
+            // on the first iteration of a time step it practically never has (a wave-uniform branch)
+            if (FROZEN ? ((!doneA && okNA) || (!doneB && okNB)) : (okNA || okNB))
+                residual_below2<ISO>(lo_, dg, up, bb, Pk, TOL, lane, okPA, okPB);                  // :200
+            else
+                okPA = okPB = false;
             cr_pcr_solve<double, NR, WS, ISO, XM>(lo_, dg, up, bb, x, lane, xch);                       // :202
 #pragma unroll
             for (int j = 0; j < NR; j++) Pk[j] = act ? x[j] : Pk[j];
