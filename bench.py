@@ -23,6 +23,9 @@ At N = 1 the line also carries `host_api_block` -- the reference's own call sequ
 curve, host buffers) on one reference-shaped 1024-sample block, PCIe included -- and `full_length`: ONE extra pass at the production length T = 80 000 over the
 same resident batch (event-timed, ~26 s), so that the full-length rate is measured by every driver run.
 
+`--single-process --gpus N` runs the same step with ONE process driving all N devices through
+trpl_loglik_multi_dev (RCCL ncclCommInitAll + one ncclAllGather; P left resident on every device).
+
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline      the dominant kernel (the fused time-stepper): achieved fp64 FLOP/s from the
                 device's own iteration counters (268*L flop per inner iteration)
@@ -75,6 +78,9 @@ def main():
     ap.add_argument("--full-length-T", type=int, default=80000)
     ap.add_argument("--traffic-profile", default=None,
                     help="tag of the committed profiles/<tag>_hbm_traffic.json to quote (default: highest round/version)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="ONE process drives --gpus devices (trpl_multi_* / trpl_loglik_multi_dev: RCCL ncclCommInitAll + "
+                         "one ncclAllGather, the likelihood vector resident on every device) instead of one rank per GPU")
     ap.add_argument("--dump-p", default=None, help="rank 0 saves the gathered likelihood vector of the last pass (.npy)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -82,6 +88,8 @@ def main():
                          "with host-staged collectives (ranks may share a GPU)")
     args = ap.parse_args()
 
+    if args.single_process:
+        return main_single_process(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -271,6 +279,88 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def main_single_process(args):
+    """The same step -- fused pass over 65 536 samples per GPU + the gather of the likelihoods -- with ONE process
+    driving all N devices through the C ABI's device-resident multi-GPU entry (SURVEY 8e as worded: ncclCommInitAll
+    over the node's devices, one ncclAllGather of S/N fp64 per rank, P[S] left on every device).  Inputs are
+    resident on their devices before the clock starts; a step ends when every device's stream has drained."""
+    import torch
+    import trpl_amd
+    from trpl_amd import device as tdev
+    from trpl_amd import workloads as wl
+    n = args.gpus
+    if torch.cuda.device_count() < n:
+        raise SystemExit("bench.py --single-process --gpus %d: only %d devices visible" % (n, torch.cuda.device_count()))
+    L, T, dt_ns = args.L, args.T, 0.025
+    tol = args.tol if args.tol is not None else 7
+    Time = T * dt_ns
+    ini, lens = wl.power_scan(L) if args.workload == "power_scan" else wl.twothick(L)
+    C = len(lens)
+    S_total = args.samples_per_gpu * n
+    X_host = wl.samples(S_total)
+    flags = (trpl_amd.FLAG_STRICT if args.strict else 0) | (trpl_amd.FLAG_MIXED if args.mixed else 0)
+    md = tdev.MultiDevice(list(range(n)))
+    bounds = md.shard_bounds(S_total)
+    Xs, inis, obss, Ps, sses, sts, its = [], [], [], [], [], [], []
+    for r, (lo, hi) in enumerate(bounds):
+        dev = torch.device("cuda", r)
+        with torch.cuda.device(dev):
+            ini_d = torch.from_numpy(ini).to(dev)
+            mark = torch.from_numpy((wl.MARKED_POINT * trpl_amd.UNIT_CONVERSIONS)[None, :-1].copy()).to(dev)
+            obs = torch.empty((C, T + 1), dtype=torch.float64, device=dev)
+            for c in range(C):
+                pl = torch.empty((1, T + 1), dtype=torch.float64, device=dev)
+                tdev.solve_pl_device(mark, lens[c], Time, L, T, ini_d[c].contiguous(), pl, flags=trpl_amd.FLAG_STRICT, tol=7)
+                obs[c] = torch.log10(pl[0])
+            Xs.append(torch.from_numpy(np.ascontiguousarray(X_host[lo:hi])).to(dev))
+            inis.append(ini_d); obss.append(obs)
+            Ps.append(torch.empty(S_total, dtype=torch.float64, device=dev))
+            sses.append(torch.empty((C, hi - lo), dtype=torch.float64, device=dev))
+            sts.append(torch.empty((C, hi - lo), dtype=torch.int32, device=dev))
+            its.append(torch.empty((C, hi - lo), dtype=torch.int64, device=dev))
+            torch.cuda.synchronize(dev)
+
+    def step():
+        md.loglik(Xs, inis, lens, Time, L, T, obss, [T + 1] * C, Ps, sse=sses, status=sts, iters_total=its, tol=tol, flags=flags)
+        md.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    elapsed = time.perf_counter() - t0
+    it_all = sum(int(t.sum().item()) for t in its)
+    fail_all = sum(int((t != 0).sum().item()) for t in sts)
+    full = Ps[0].cpu().numpy()
+    for r in range(1, n):                                      # the gathered vector is the same on every device
+        assert np.array_equal(Ps[r].cpu().numpy(), full)
+    assert np.isfinite(full).sum() >= S_total - fail_all
+    if args.dump_p:
+        np.save(args.dump_p, full[None, :])
+    sys_steps = S_total * C * (T + 1)
+    value = sys_steps * args.steps / elapsed
+    tf = it_all * FLOP_PER_ITER_PER_NODE * L / (elapsed / args.steps) / 1e12
+    out = {"metric": "TRPL timesteps/sec at %d nodes (system = parameter sample x excitation; fused solve + "
+                     "log-likelihood), one process driving all devices" % L,
+           "value": value, "unit": "system-timesteps/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "%s x %d samples/GPU (%d total), %d curves, L=%d nodes, T=%d steps of dt=0.025 ns, "
+                                  "tol=1e-%d, MAX=10000, fp64" % (args.workload, args.samples_per_gpu, S_total, C, L, T, tol),
+                      "samples_total": S_total, "curves": C, "L": L, "T": T,
+                      "parallelism": "single process, sample-shard x%d (trpl_loglik_multi_dev)" % n,
+                      "collective": "RCCL ncclAllGather (ncclCommInitAll), P resident on every device"},
+           "likelihoods_per_s_at_T": S_total * args.steps / elapsed, "inner_iterations_per_s": it_all * args.steps / elapsed,
+           "mean_inner_iterations_per_step": it_all / sys_steps, "nonconverged_systems": fail_all,
+           "roofline": {"kernel": "all devices' fused time-steppers", "bound": "valu-fp64", "achieved": tf,
+                        "peak": FP64_VECTOR_PEAK_TFLOPS * n, "unit": "TFLOP/s", "frac": tf / (FP64_VECTOR_PEAK_TFLOPS * n),
+                        "traffic": None,
+                        "note": "wall-clock over the whole step (solve + all-gather + unpadding) on all devices"}}
+    md.close()
+    print(json.dumps(out), flush=True)
 
 
 def full_length_pass(torch, tdev, trpl_amd, dev, X, ini_d, mark, lens, L, T, dt_ns, flags, tol, C, fp32):

@@ -474,6 +474,15 @@ def test_bench_two_rank_rehearsal_gathers_the_single_rank_likelihoods(gpu, tmp_p
     assert line2["nonconverged_systems"] == line1["nonconverged_systems"] == 0
     a, b = np.load(p1), np.load(p2)
     assert a.shape == b.shape == (1, 4096) and np.array_equal(a, b)
+    # ... and the single-process form (one process, trpl_loglik_multi_dev + RCCL) on this box's one device
+    p3 = str(tmp_path / "p3.npy")
+    r3 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--single-process", "--gpus", "1",
+                         "--samples-per-gpu", "4096", "--steps", "1", "--warmup", "0", "--T", "200", "--dump-p", p3],
+                        env=env, capture_output=True, text=True, timeout=900)
+    assert r3.returncode == 0, r3.stderr[-2000:]
+    line3 = json.loads(r3.stdout.strip().splitlines()[-1])
+    assert line3["n_gpus"] == 1 and "ncclAllGather" in line3["config"]["collective"]
+    assert np.array_equal(np.load(p3), a)
 
 
 def test_rank_driver_gathers_over_rccl_on_a_one_rank_group(gpu, tmp_path):
