@@ -146,7 +146,6 @@ int select_device(int32_t device)
 }  // namespace trpl
 
 using namespace trpl;
-#define fail api_fail
 
 namespace {
 
@@ -155,27 +154,27 @@ int launch(const trpl::StepArgs &a, uint32_t flags, hipStream_t st, int64_t step
 {
     if (int rc = check_variant_flags(flags, a.L)) return rc;
     if (flags & TRPL_FLAG_FP32) {
-        if (flags & (TRPL_FLAG_STRICT | TRPL_FLAG_MIXED)) return fail(TRPL_ERR_ARG, "TRPL_FLAG_FP32 excludes TRPL_FLAG_STRICT and TRPL_FLAG_MIXED");
-        if (a.L < 128) return fail(TRPL_ERR_UNSUPPORTED, "the fp32 stepper is built for L >= 128 (got %d)", a.L);
-        if (a.n_snap > 0) return fail(TRPL_ERR_UNSUPPORTED, "state snapshots are not available with TRPL_FLAG_FP32");
+        if (flags & (TRPL_FLAG_STRICT | TRPL_FLAG_MIXED)) return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_FP32 excludes TRPL_FLAG_STRICT and TRPL_FLAG_MIXED");
+        if (a.L < 128) return api_fail(TRPL_ERR_UNSUPPORTED, "the fp32 stepper is built for L >= 128 (got %d)", a.L);
+        if (a.n_snap > 0) return api_fail(TRPL_ERR_UNSUPPORTED, "state snapshots are not available with TRPL_FLAG_FP32");
         hipError_t e32 = trpl::launch_stepper_f32(a, st);
-        if (e32 != hipSuccess) return fail(TRPL_ERR_HIP, "fp32 stepper launch: %s", hipGetErrorString(e32));
+        if (e32 != hipSuccess) return api_fail(TRPL_ERR_HIP, "fp32 stepper launch: %s", hipGetErrorString(e32));
         return TRPL_OK;
     }
     if (flags & TRPL_FLAG_MIXED) {
-        if (flags & TRPL_FLAG_STRICT) return fail(TRPL_ERR_ARG, "TRPL_FLAG_MIXED and TRPL_FLAG_STRICT exclude each other");
-        if (a.L < 128) return fail(TRPL_ERR_UNSUPPORTED, "the mixed-precision stepper is built for L >= 128 (got %d)", a.L);
+        if (flags & TRPL_FLAG_STRICT) return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_MIXED and TRPL_FLAG_STRICT exclude each other");
+        if (a.L < 128) return api_fail(TRPL_ERR_UNSUPPORTED, "the mixed-precision stepper is built for L >= 128 (got %d)", a.L);
         hipError_t em = trpl::launch_stepper_mixed(a, st);
-        if (em != hipSuccess) return fail(TRPL_ERR_HIP, "mixed stepper launch: %s", hipGetErrorString(em));
+        if (em != hipSuccess) return api_fail(TRPL_ERR_HIP, "mixed stepper launch: %s", hipGetErrorString(em));
         return TRPL_OK;
     }
     if (pick_pair_kernel(a.S * a.C, a.L, steps, flags)) {
         hipError_t ep = trpl::launch_stepper_pair(a, st);
-        if (ep != hipSuccess) return fail(TRPL_ERR_HIP, "pair stepper launch: %s", hipGetErrorString(ep));
+        if (ep != hipSuccess) return api_fail(TRPL_ERR_HIP, "pair stepper launch: %s", hipGetErrorString(ep));
         return TRPL_OK;
     }
     hipError_t e = (flags & TRPL_FLAG_STRICT) ? trpl::launch_stepper_strict(a, st) : trpl::launch_stepper_fast(a, st);
-    if (e != hipSuccess) return fail(TRPL_ERR_HIP, "stepper launch: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return api_fail(TRPL_ERR_HIP, "stepper launch: %s", hipGetErrorString(e));
     return TRPL_OK;
 }
 
@@ -209,15 +208,15 @@ int trpl_solve_pl_snap_dev(const double *matpar, int64_t S, double length_nm, do
                            uint32_t flags, void *stream)
 {
     if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
-    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
-    if (n_snap < 0 || n_snap > trpl::kMaxSnaps) return fail(TRPL_ERR_ARG, "n_snap=%d must be in [0, %d]", n_snap, trpl::kMaxSnaps);
-    if (n_snap > 0 && !snap_steps) return fail(TRPL_ERR_ARG, "snap_steps must not be NULL when n_snap > 0");
+    if (S < 0) return api_fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (n_snap < 0 || n_snap > trpl::kMaxSnaps) return api_fail(TRPL_ERR_ARG, "n_snap=%d must be in [0, %d]", n_snap, trpl::kMaxSnaps);
+    if (n_snap > 0 && !snap_steps) return api_fail(TRPL_ERR_ARG, "snap_steps must not be NULL when n_snap > 0");
     if (S == 0) return TRPL_OK;
-    if (!matpar || !dN || !plI) return fail(TRPL_ERR_ARG, "matpar, dN and plI must not be NULL");
-    if (pl_elem_bytes != 4 && pl_elem_bytes != 8) return fail(TRPL_ERR_ARG, "pl_elem_bytes must be 4 or 8");
-    if (pl_ld < T / plT + 1) return fail(TRPL_ERR_ARG, "pl_ld=%lld < T/plT+1", (long long)pl_ld);
-    if (!(length_nm > 0)) return fail(TRPL_ERR_ARG, "length_nm must be > 0");
-    if (S > 0x7fffffffLL) return fail(TRPL_ERR_ARG, "S too large for one launch");
+    if (!matpar || !dN || !plI) return api_fail(TRPL_ERR_ARG, "matpar, dN and plI must not be NULL");
+    if (pl_elem_bytes != 4 && pl_elem_bytes != 8) return api_fail(TRPL_ERR_ARG, "pl_elem_bytes must be 4 or 8");
+    if (pl_ld < T / plT + 1) return api_fail(TRPL_ERR_ARG, "pl_ld=%lld < T/plT+1", (long long)pl_ld);
+    if (!(length_nm > 0)) return api_fail(TRPL_ERR_ARG, "length_nm must be > 0");
+    if (S > 0x7fffffffLL) return api_fail(TRPL_ERR_ARG, "S too large for one launch");
     trpl::StepArgs a;
     memset(&a, 0, sizeof a);
     a.X = matpar; a.xld = 12; a.dN = dN; a.pl = plI; a.pl_bytes = pl_elem_bytes; a.pl_ld = pl_ld;
@@ -261,14 +260,14 @@ int trpl_solve_pl_snap(const double *matpar, int64_t S, double length_nm, double
                        uint32_t flags, int32_t device, double *seconds)
 {
     if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
-    if (pl_elem_bytes != 4 && pl_elem_bytes != 8) return fail(TRPL_ERR_ARG, "pl_elem_bytes must be 4 or 8");
-    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
-    if (n_snap < 0 || n_snap > trpl::kMaxSnaps) return fail(TRPL_ERR_ARG, "n_snap=%d must be in [0, %d]", n_snap, trpl::kMaxSnaps);
+    if (pl_elem_bytes != 4 && pl_elem_bytes != 8) return api_fail(TRPL_ERR_ARG, "pl_elem_bytes must be 4 or 8");
+    if (S < 0) return api_fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (n_snap < 0 || n_snap > trpl::kMaxSnaps) return api_fail(TRPL_ERR_ARG, "n_snap=%d must be in [0, %d]", n_snap, trpl::kMaxSnaps);
     if (seconds) *seconds = 0.0;
     if (S == 0) return TRPL_OK;
-    if (!matpar || !dN || !plI) return fail(TRPL_ERR_ARG, "matpar, dN and plI must not be NULL");
+    if (!matpar || !dN || !plI) return api_fail(TRPL_ERR_ARG, "matpar, dN and plI must not be NULL");
     const int64_t ncol = T / plT + 1;
-    if (pl_ld < ncol) return fail(TRPL_ERR_ARG, "pl_ld=%lld < T/plT+1", (long long)pl_ld);
+    if (pl_ld < ncol) return api_fail(TRPL_ERR_ARG, "pl_ld=%lld < T/plT+1", (long long)pl_ld);
     if (int rc = select_device(device)) return rc;
     // A large PL matrix is written by the kernel STRAIGHT INTO the caller's buffer (pinned and mapped for
     // the duration of the call): the stores cross PCIe while the time-stepping goes on (a 1024 x 80 001 fp32
@@ -325,24 +324,24 @@ int trpl_solve_pl(const double *matpar, int64_t S, double length_nm, double time
 int trpl_log10_clamp_dev(void *x, int32_t elem_bytes, int64_t rows, int64_t cols, int64_t ld, double min,
                          void *stream)
 {
-    if (elem_bytes != 4 && elem_bytes != 8) return fail(TRPL_ERR_ARG, "elem_bytes must be 4 or 8");
-    if (rows < 0 || cols < 0 || ld < cols) return fail(TRPL_ERR_ARG, "bad shape rows=%lld cols=%lld ld=%lld",
+    if (elem_bytes != 4 && elem_bytes != 8) return api_fail(TRPL_ERR_ARG, "elem_bytes must be 4 or 8");
+    if (rows < 0 || cols < 0 || ld < cols) return api_fail(TRPL_ERR_ARG, "bad shape rows=%lld cols=%lld ld=%lld",
                                                        (long long)rows, (long long)cols, (long long)ld);
     if (rows == 0 || cols == 0) return TRPL_OK;
-    if (!x) return fail(TRPL_ERR_ARG, "x must not be NULL");
+    if (!x) return api_fail(TRPL_ERR_ARG, "x must not be NULL");
     hipError_t e = trpl::launch_log10_clamp(x, elem_bytes, rows, cols, ld, min, (hipStream_t)stream);
-    if (e != hipSuccess) return fail(TRPL_ERR_HIP, "log10_clamp launch: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return api_fail(TRPL_ERR_HIP, "log10_clamp launch: %s", hipGetErrorString(e));
     return TRPL_OK;
 }
 
 int trpl_log10_clamp(void *x, int32_t elem_bytes, int64_t rows, int64_t cols, int64_t ld, double min,
                      int32_t device, double *seconds)
 {
-    if (elem_bytes != 4 && elem_bytes != 8) return fail(TRPL_ERR_ARG, "elem_bytes must be 4 or 8");
-    if (rows < 0 || cols < 0 || ld < cols) return fail(TRPL_ERR_ARG, "bad shape");
+    if (elem_bytes != 4 && elem_bytes != 8) return api_fail(TRPL_ERR_ARG, "elem_bytes must be 4 or 8");
+    if (rows < 0 || cols < 0 || ld < cols) return api_fail(TRPL_ERR_ARG, "bad shape");
     if (seconds) *seconds = 0.0;
     if (rows == 0 || cols == 0) return TRPL_OK;
-    if (!x) return fail(TRPL_ERR_ARG, "x must not be NULL");
+    if (!x) return api_fail(TRPL_ERR_ARG, "x must not be NULL");
     if (int rc = select_device(device)) return rc;
     HostPin pin;
     CallScope cs;
@@ -365,23 +364,23 @@ int trpl_log10_clamp(void *x, int32_t elem_bytes, int64_t rows, int64_t cols, in
 int trpl_sse_accumulate_dev(double *P, const void *plI, int32_t elem_bytes, int64_t rows, int64_t n_obs,
                             int64_t ld, const double *values, const double *mag, void *stream)
 {
-    if (elem_bytes != 4 && elem_bytes != 8) return fail(TRPL_ERR_ARG, "elem_bytes must be 4 or 8");
-    if (rows < 0 || n_obs < 0 || ld < n_obs) return fail(TRPL_ERR_ARG, "bad shape");
+    if (elem_bytes != 4 && elem_bytes != 8) return api_fail(TRPL_ERR_ARG, "elem_bytes must be 4 or 8");
+    if (rows < 0 || n_obs < 0 || ld < n_obs) return api_fail(TRPL_ERR_ARG, "bad shape");
     if (rows == 0) return TRPL_OK;
-    if (!P || !mag || (n_obs && (!plI || !values))) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (!P || !mag || (n_obs && (!plI || !values))) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");
     hipError_t e = trpl::launch_sse_accumulate(P, plI, elem_bytes, rows, n_obs, ld, values, mag, (hipStream_t)stream);
-    if (e != hipSuccess) return fail(TRPL_ERR_HIP, "sse_accumulate launch: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return api_fail(TRPL_ERR_HIP, "sse_accumulate launch: %s", hipGetErrorString(e));
     return TRPL_OK;
 }
 
 int trpl_sse_accumulate(double *P, const void *plI, int32_t elem_bytes, int64_t rows, int64_t n_obs, int64_t ld,
                         const double *values, const double *mag, int32_t device, double *seconds)
 {
-    if (elem_bytes != 4 && elem_bytes != 8) return fail(TRPL_ERR_ARG, "elem_bytes must be 4 or 8");
-    if (rows < 0 || n_obs < 0 || ld < n_obs) return fail(TRPL_ERR_ARG, "bad shape");
+    if (elem_bytes != 4 && elem_bytes != 8) return api_fail(TRPL_ERR_ARG, "elem_bytes must be 4 or 8");
+    if (rows < 0 || n_obs < 0 || ld < n_obs) return api_fail(TRPL_ERR_ARG, "bad shape");
     if (seconds) *seconds = 0.0;
     if (rows == 0) return TRPL_OK;
-    if (!P || !mag || (n_obs && (!plI || !values))) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (!P || !mag || (n_obs && (!plI || !values))) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");
     if (int rc = select_device(device)) return rc;
     HostPin pin;
     CallScope cs;
@@ -416,17 +415,17 @@ int trpl_loglik_from_pl_dev(const void *plI, int32_t elem_bytes, int64_t rows, i
                             int64_t n_obs, const double *mag, const int32_t *status, double *P, double *sse,
                             uint32_t flags, void *stream)
 {
-    if (elem_bytes != 4 && elem_bytes != 8) return fail(TRPL_ERR_ARG, "elem_bytes must be 4 or 8");
-    if (rows < 0 || ncol < 1 || ld < ncol || n_obs < 0) return fail(TRPL_ERR_ARG, "bad shape");
+    if (elem_bytes != 4 && elem_bytes != 8) return api_fail(TRPL_ERR_ARG, "elem_bytes must be 4 or 8");
+    if (rows < 0 || ncol < 1 || ld < ncol || n_obs < 0) return api_fail(TRPL_ERR_ARG, "bad shape");
     const bool interp = obs_hi || obs_dx || obs_h;
-    if (interp && !(obs_hi && obs_dx && obs_h)) return fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h go together");
-    if (!interp && n_obs > ncol) return fail(TRPL_ERR_ARG, "n_obs=%lld exceeds the %lld PL columns", (long long)n_obs, (long long)ncol);
-    if (rows > 0x7fffffffLL) return fail(TRPL_ERR_ARG, "too many rows for one launch");
+    if (interp && !(obs_hi && obs_dx && obs_h)) return api_fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h go together");
+    if (!interp && n_obs > ncol) return api_fail(TRPL_ERR_ARG, "n_obs=%lld exceeds the %lld PL columns", (long long)n_obs, (long long)ncol);
+    if (rows > 0x7fffffffLL) return api_fail(TRPL_ERR_ARG, "too many rows for one launch");
     if (rows == 0) return TRPL_OK;
-    if (!plI || !mag || (n_obs && !obs) || (!P && !sse)) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (!plI || !mag || (n_obs && !obs) || (!P && !sse)) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");
     hipError_t e = trpl::launch_pl_loglik(plI, elem_bytes, rows, ld, obs, obs_hi, obs_dx, obs_h, n_obs, mag, status, P, sse, flags,
                                           (hipStream_t)stream);
-    if (e != hipSuccess) return fail(TRPL_ERR_HIP, "pl_loglik launch: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return api_fail(TRPL_ERR_HIP, "pl_loglik launch: %s", hipGetErrorString(e));
     return TRPL_OK;
 }
 
@@ -438,14 +437,14 @@ static int loglik_dev_impl(const double *X, int64_t S, int32_t C, const double *
                            int64_t *iters_total, uint32_t flags, void *stream)
 {
     if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
-    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
-    if (C < 1 || C > trpl::kMaxCurves) return fail(TRPL_ERR_ARG, "C=%d must be in [1, %d]", C, trpl::kMaxCurves);
+    if (S < 0) return api_fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (C < 1 || C > trpl::kMaxCurves) return api_fail(TRPL_ERR_ARG, "C=%d must be in [1, %d]", C, trpl::kMaxCurves);
     if (S == 0) return TRPL_OK;
-    if (!X || !lengths_nm || !dN || !obs || !n_obs || !P || !sse) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (!X || !lengths_nm || !dN || !obs || !n_obs || !P || !sse) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");
     const bool interp = obs_hi || obs_dx || obs_h;
-    if (interp && !(obs_hi && obs_dx && obs_h)) return fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h go together");
-    if (interp && plT != 1) return fail(TRPL_ERR_ARG, "off-grid observations need plT = 1");
-    if (S * (int64_t)C > 0x7fffffffLL) return fail(TRPL_ERR_ARG, "S*C too large for one launch");
+    if (interp && !(obs_hi && obs_dx && obs_h)) return api_fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h go together");
+    if (interp && plT != 1) return api_fail(TRPL_ERR_ARG, "off-grid observations need plT = 1");
+    if (S * (int64_t)C > 0x7fffffffLL) return api_fail(TRPL_ERR_ARG, "S*C too large for one launch");
     trpl::StepArgs a;
     memset(&a, 0, sizeof a);
     a.X = X; a.xld = 13; a.dN = dN; a.obs = obs; a.obs_hi = obs_hi; a.obs_dx = obs_dx; a.obs_h = obs_h;
@@ -455,16 +454,16 @@ static int loglik_dev_impl(const double *X, int64_t S, int32_t C, const double *
     a.TOL = pow(10.0, -(double)tol_exp);
     const int64_t ncol = T / plT + 1;
     for (int c = 0; c < C; c++) {
-        if (!(lengths_nm[c] > 0)) return fail(TRPL_ERR_ARG, "lengths_nm[%d] must be > 0", c);
+        if (!(lengths_nm[c] > 0)) return api_fail(TRPL_ERR_ARG, "lengths_nm[%d] must be > 0", c);
         if (n_obs[c] < 1 || n_obs[c] > obs_ld || (!interp && n_obs[c] > ncol))
-            return fail(TRPL_ERR_ARG, "n_obs[%d]=%lld out of range (obs_ld %lld, grid columns %lld)", c,
+            return api_fail(TRPL_ERR_ARG, "n_obs[%d]=%lld out of range (obs_ld %lld, grid columns %lld)", c,
                         (long long)n_obs[c], (long long)obs_ld, (long long)ncol);
         curve_const(lengths_nm[c], time_ns, L, T, a.curve[c]);
         a.curve[c].n_obs = n_obs[c];
     }
     if (int rc = launch(a, flags, (hipStream_t)stream, loglik_steps(interp, C, n_obs, plT, T))) return rc;
     hipError_t e = trpl::launch_reduce_curves(P, sse, S, C, (hipStream_t)stream);
-    if (e != hipSuccess) return fail(TRPL_ERR_HIP, "reduce_curves launch: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return api_fail(TRPL_ERR_HIP, "reduce_curves launch: %s", hipGetErrorString(e));
     return TRPL_OK;
 }
 
@@ -483,7 +482,7 @@ int trpl_loglik_obs_dev(const double *X, int64_t S, int32_t C, const double *len
                         const int64_t *n_obs, double *P, double *sse, int32_t *status, int64_t *iters_total,
                         uint32_t flags, void *stream)
 {
-    if (!obs_hi || !obs_dx || !obs_h) return fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h must not be NULL");
+    if (!obs_hi || !obs_dx || !obs_h) return api_fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h must not be NULL");
     return loglik_dev_impl(X, S, C, lengths_nm, time_ns, L, T, 1, tol_exp, max_iter, dN, obs, obs_hi, obs_dx, obs_h,
                            obs_ld, n_obs, P, sse, status, iters_total, flags, stream);
 }
@@ -495,12 +494,12 @@ static int loglik_host_impl(const double *X, int64_t S, int32_t C, const double 
                             int64_t *iters_total, uint32_t flags, int32_t device, double *seconds)
 {
     if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
-    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
-    if (C < 1 || C > trpl::kMaxCurves) return fail(TRPL_ERR_ARG, "C=%d must be in [1, %d]", C, trpl::kMaxCurves);
+    if (S < 0) return api_fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (C < 1 || C > trpl::kMaxCurves) return api_fail(TRPL_ERR_ARG, "C=%d must be in [1, %d]", C, trpl::kMaxCurves);
     if (seconds) *seconds = 0.0;
     if (S == 0) return TRPL_OK;
-    if (!X || !lengths_nm || !dN || !obs || !n_obs || !P) return fail(TRPL_ERR_ARG, "NULL pointer argument");
-    if (obs_ld < 1) return fail(TRPL_ERR_ARG, "obs_ld must be >= 1");
+    if (!X || !lengths_nm || !dN || !obs || !n_obs || !P) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (obs_ld < 1) return api_fail(TRPL_ERR_ARG, "obs_ld must be >= 1");
     if (int rc = select_device(device)) return rc;
     CallScope cs;
     HIP_TRY(cs.open());
@@ -559,7 +558,7 @@ int trpl_loglik_obs(const double *X, int64_t S, int32_t C, const double *lengths
                     const int64_t *n_obs, double *P, double *sse, int32_t *status, int64_t *iters_total,
                     uint32_t flags, int32_t device, double *seconds)
 {
-    if (!obs_hi || !obs_dx || !obs_h) return fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h must not be NULL");
+    if (!obs_hi || !obs_dx || !obs_h) return api_fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h must not be NULL");
     return loglik_host_impl(X, S, C, lengths_nm, time_ns, L, T, 1, tol_exp, max_iter, dN, obs, obs_hi, obs_dx, obs_h,
                             obs_ld, n_obs, P, sse, status, iters_total, flags, device, seconds);
 }
@@ -570,13 +569,13 @@ int64_t trpl_posterior_workspace_bytes(int32_t D) { return (int64_t)trpl::poster
 int trpl_posterior_weights_dev(const double *LL, int64_t S, double tf, double *W, double *stats, void *workspace,
                                int64_t workspace_bytes, void *stream)
 {
-    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (S < 0) return api_fail(TRPL_ERR_ARG, "S must be >= 0");
     if (S == 0) return TRPL_OK;
-    if (!LL || !W || !workspace) return fail(TRPL_ERR_ARG, "NULL pointer argument");
-    if (!(tf > 0)) return fail(TRPL_ERR_ARG, "tf must be > 0");
-    if (workspace_bytes < (int64_t)trpl::posterior_workspace_bytes(1)) return fail(TRPL_ERR_ARG, "workspace too small");
+    if (!LL || !W || !workspace) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (!(tf > 0)) return api_fail(TRPL_ERR_ARG, "tf must be > 0");
+    if (workspace_bytes < (int64_t)trpl::posterior_workspace_bytes(1)) return api_fail(TRPL_ERR_ARG, "workspace too small");
     hipError_t e = trpl::launch_posterior_weights(LL, S, tf, W, stats, (double *)workspace, (hipStream_t)stream);
-    if (e != hipSuccess) return fail(TRPL_ERR_HIP, "posterior weights launch: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return api_fail(TRPL_ERR_HIP, "posterior weights launch: %s", hipGetErrorString(e));
     return TRPL_OK;
 }
 
@@ -584,10 +583,10 @@ int trpl_posterior_weights(const double *LL, int64_t S, double tf, double *W, do
                            double *seconds)
 {
     if (seconds) *seconds = 0.0;
-    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (S < 0) return api_fail(TRPL_ERR_ARG, "S must be >= 0");
     if (S == 0) return TRPL_OK;
-    if (!LL || !W) return fail(TRPL_ERR_ARG, "NULL pointer argument");
-    if (!(tf > 0)) return fail(TRPL_ERR_ARG, "tf must be > 0");
+    if (!LL || !W) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (!(tf > 0)) return api_fail(TRPL_ERR_ARG, "tf must be > 0");
     if (int rc = select_device(device)) return rc;
     CallScope cs;
     HIP_TRY(cs.open());
@@ -609,13 +608,13 @@ int trpl_posterior_weights(const double *LL, int64_t S, double tf, double *W, do
 int trpl_posterior_moments_dev(const double *V, int64_t S, int32_t D, const double *W, const double *mean_in, double *sums,
                                double *central, void *workspace, int64_t workspace_bytes, void *stream)
 {
-    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
-    if (D < 1 || D > 16) return fail(TRPL_ERR_ARG, "D=%d must be in [1, 16]", D);
+    if (S < 0) return api_fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (D < 1 || D > 16) return api_fail(TRPL_ERR_ARG, "D=%d must be in [1, 16]", D);
     if (S == 0) return TRPL_OK;
-    if (!V || !W || !sums || !central || !workspace) return fail(TRPL_ERR_ARG, "NULL pointer argument");
-    if (workspace_bytes < (int64_t)trpl::posterior_workspace_bytes(D)) return fail(TRPL_ERR_ARG, "workspace too small");
+    if (!V || !W || !sums || !central || !workspace) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (workspace_bytes < (int64_t)trpl::posterior_workspace_bytes(D)) return api_fail(TRPL_ERR_ARG, "workspace too small");
     hipError_t e = trpl::launch_posterior_moments(V, W, S, D, mean_in, sums, central, (double *)workspace, (hipStream_t)stream);
-    if (e != hipSuccess) return fail(TRPL_ERR_HIP, "posterior moments launch: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return api_fail(TRPL_ERR_HIP, "posterior moments launch: %s", hipGetErrorString(e));
     return TRPL_OK;
 }
 
@@ -623,13 +622,13 @@ int trpl_posterior_moments(const double *V, int64_t S, int32_t D, const double *
                            double *central, int32_t device, double *seconds)
 {
     if (seconds) *seconds = 0.0;
-    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
-    if (D < 1 || D > 16) return fail(TRPL_ERR_ARG, "D=%d must be in [1, 16]", D);
-    if (!sums || !central) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (S < 0) return api_fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (D < 1 || D > 16) return api_fail(TRPL_ERR_ARG, "D=%d must be in [1, 16]", D);
+    if (!sums || !central) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");
     memset(sums, 0, sizeof(double) * (2 + D));
     memset(central, 0, sizeof(double) * D * (D + 2));
     if (S == 0) return TRPL_OK;
-    if (!V || !W) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (!V || !W) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");
     if (int rc = select_device(device)) return rc;
     CallScope cs;
     HIP_TRY(cs.open());
@@ -655,10 +654,10 @@ int trpl_posterior_moments(const double *V, int64_t S, int32_t D, const double *
 
 static int check_hist(int64_t S, double xlo, double xhi, int32_t xb, const double *y, double ylo, double yhi, int32_t yb)
 {
-    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
-    if (xb < 1 || !(xhi > xlo)) return fail(TRPL_ERR_ARG, "x axis needs bins >= 1 and hi > lo");
-    if (y && (yb < 1 || !(yhi > ylo))) return fail(TRPL_ERR_ARG, "y axis needs bins >= 1 and hi > lo");
-    if ((int64_t)xb * (y ? yb : 1) > (1 << 24)) return fail(TRPL_ERR_ARG, "too many bins");
+    if (S < 0) return api_fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (xb < 1 || !(xhi > xlo)) return api_fail(TRPL_ERR_ARG, "x axis needs bins >= 1 and hi > lo");
+    if (y && (yb < 1 || !(yhi > ylo))) return api_fail(TRPL_ERR_ARG, "y axis needs bins >= 1 and hi > lo");
+    if ((int64_t)xb * (y ? yb : 1) > (1 << 24)) return api_fail(TRPL_ERR_ARG, "too many bins");
     return TRPL_OK;
 }
 
@@ -667,9 +666,9 @@ int trpl_posterior_hist_dev(const double *x, const double *y, const double *W, i
 {
     if (int rc = check_hist(S, xlo, xhi, xbins, y, ylo, yhi, ybins)) return rc;
     if (S == 0) return TRPL_OK;
-    if (!x || !out) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (!x || !out) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");
     hipError_t e = trpl::launch_posterior_hist(x, y, W, S, xlo, xhi, xbins, ylo, yhi, ybins, out, (hipStream_t)stream);
-    if (e != hipSuccess) return fail(TRPL_ERR_HIP, "posterior histogram launch: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return api_fail(TRPL_ERR_HIP, "posterior histogram launch: %s", hipGetErrorString(e));
     return TRPL_OK;
 }
 
@@ -679,11 +678,11 @@ int trpl_posterior_hist(const double *x, const double *y, const double *W, int64
 {
     if (seconds) *seconds = 0.0;
     if (int rc = check_hist(S, xlo, xhi, xbins, y, ylo, yhi, ybins)) return rc;
-    if (!out) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (!out) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");
     const size_t nb = (size_t)xbins * (y ? ybins : 1);
     memset(out, 0, nb * 8);
     if (S == 0) return TRPL_OK;
-    if (!x) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (!x) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");
     if (int rc = select_device(device)) return rc;
     CallScope cs;
     HIP_TRY(cs.open());
@@ -707,12 +706,12 @@ int trpl_posterior_hist(const double *x, const double *y, const double *W, int64
 /* ------------------------------------------------------------------ sampler -------------- */
 static int check_box(int64_t S, int32_t ncol, const double *lo, const double *hi, const int32_t *do_log)
 {
-    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
-    if (ncol < 1 || ncol > 16) return fail(TRPL_ERR_ARG, "ncol=%d must be in [1, 16]", ncol);
-    if (!lo || !hi || !do_log) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (S < 0) return api_fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (ncol < 1 || ncol > 16) return api_fail(TRPL_ERR_ARG, "ncol=%d must be in [1, 16]", ncol);
+    if (!lo || !hi || !do_log) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");
     for (int c = 0; c < ncol; c++) {
-        if (!(lo[c] <= hi[c])) return fail(TRPL_ERR_ARG, "column %d: lo must be <= hi", c);
-        if (do_log[c] && lo[c] != hi[c] && !(lo[c] > 0)) return fail(TRPL_ERR_ARG, "column %d: log-uniform needs lo > 0", c);
+        if (!(lo[c] <= hi[c])) return api_fail(TRPL_ERR_ARG, "column %d: lo must be <= hi", c);
+        if (do_log[c] && lo[c] != hi[c] && !(lo[c] > 0)) return api_fail(TRPL_ERR_ARG, "column %d: log-uniform needs lo > 0", c);
     }
     return TRPL_OK;
 }
@@ -722,9 +721,9 @@ int trpl_sample_box_dev(uint32_t seed, int64_t S, int32_t ncol, const double *lo
 {
     if (int rc = check_box(S, ncol, lo, hi, do_log)) return rc;
     if (S == 0) return TRPL_OK;
-    if (!X) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (!X) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");
     hipError_t e = trpl::launch_sample_box(seed, S, ncol, lo, hi, do_log, flags, X, (hipStream_t)stream);
-    if (e != hipSuccess) return fail(TRPL_ERR_HIP, "sampler launch: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return api_fail(TRPL_ERR_HIP, "sampler launch: %s", hipGetErrorString(e));
     return TRPL_OK;
 }
 
@@ -734,7 +733,7 @@ int trpl_sample_box(uint32_t seed, int64_t S, int32_t ncol, const double *lo, co
     if (seconds) *seconds = 0.0;
     if (int rc = check_box(S, ncol, lo, hi, do_log)) return rc;
     if (S == 0) return TRPL_OK;
-    if (!X) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (!X) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");
     if (int rc = select_device(device)) return rc;
     CallScope cs;
     HIP_TRY(cs.open());
@@ -753,27 +752,27 @@ int trpl_sample_box(uint32_t seed, int64_t S, int32_t ncol, const double *lo, co
 int trpl_pcr_solve_batched_dev(const void *ld, const void *d, const void *ud, const void *b, void *x, int64_t S,
                                int32_t L, int32_t elem_bytes, uint32_t flags, void *stream)
 {
-    if (!pow2(L) || L < 4 || L > 512) return fail(TRPL_ERR_ARG, "L=%d must be a power of two in [4, 512]", L);
-    if (elem_bytes != 4 && elem_bytes != 8) return fail(TRPL_ERR_ARG, "elem_bytes must be 4 or 8");
-    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (!pow2(L) || L < 4 || L > 512) return api_fail(TRPL_ERR_ARG, "L=%d must be a power of two in [4, 512]", L);
+    if (elem_bytes != 4 && elem_bytes != 8) return api_fail(TRPL_ERR_ARG, "elem_bytes must be 4 or 8");
+    if (S < 0) return api_fail(TRPL_ERR_ARG, "S must be >= 0");
     if (S == 0) return TRPL_OK;
-    if (!ld || !d || !ud || !b || !x) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (!ld || !d || !ud || !b || !x) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");
     hipError_t e = (flags & TRPL_FLAG_STRICT)
                        ? trpl::launch_pcr_batched_strict(ld, d, ud, b, x, S, L, elem_bytes, (hipStream_t)stream)
                        : trpl::launch_pcr_batched_fast(ld, d, ud, b, x, S, L, elem_bytes, (hipStream_t)stream);
-    if (e != hipSuccess) return fail(TRPL_ERR_HIP, "pcr_batched launch: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return api_fail(TRPL_ERR_HIP, "pcr_batched launch: %s", hipGetErrorString(e));
     return TRPL_OK;
 }
 
 int trpl_pcr_solve_batched(const void *ld, const void *d, const void *ud, const void *b, void *x, int64_t S,
                            int32_t L, int32_t elem_bytes, uint32_t flags, int32_t device, double *seconds)
 {
-    if (!pow2(L) || L < 4 || L > 512) return fail(TRPL_ERR_ARG, "L=%d must be a power of two in [4, 512]", L);
-    if (elem_bytes != 4 && elem_bytes != 8) return fail(TRPL_ERR_ARG, "elem_bytes must be 4 or 8");
-    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (!pow2(L) || L < 4 || L > 512) return api_fail(TRPL_ERR_ARG, "L=%d must be a power of two in [4, 512]", L);
+    if (elem_bytes != 4 && elem_bytes != 8) return api_fail(TRPL_ERR_ARG, "elem_bytes must be 4 or 8");
+    if (S < 0) return api_fail(TRPL_ERR_ARG, "S must be >= 0");
     if (seconds) *seconds = 0.0;
     if (S == 0) return TRPL_OK;
-    if (!ld || !d || !ud || !b || !x) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (!ld || !d || !ud || !b || !x) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");
     if (int rc = select_device(device)) return rc;
     CallScope cs;
     HIP_TRY(cs.open());

@@ -15,7 +15,6 @@
 #include "api_util.hpp"
 
 using namespace trpl;
-#define fail api_fail
 
 namespace {
 
@@ -39,7 +38,7 @@ extern "C" {
 int trpl_shard_bounds(int64_t S, int32_t n_shards, int32_t shard, int64_t *lo, int64_t *hi)
 {
     if (S < 0 || n_shards < 1 || shard < 0 || shard >= n_shards || !lo || !hi)
-        return fail(TRPL_ERR_ARG, "shard %d of %d over S=%lld is not a valid request", shard, n_shards, (long long)S);
+        return api_fail(TRPL_ERR_ARG, "shard %d of %d over S=%lld is not a valid request", shard, n_shards, (long long)S);
     const int64_t base = S / n_shards, rem = S % n_shards;
     *lo = shard * base + (shard < rem ? shard : rem);
     *hi = *lo + base + (shard < rem ? 1 : 0);
@@ -82,29 +81,29 @@ int trpl_loglik_multi(const double *X, int64_t S, int32_t C, const double *lengt
                       uint32_t flags, const int32_t *devices, int32_t n_devices, double *seconds)
 {
     if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
-    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
-    if (C < 1 || C > trpl::kMaxCurves) return fail(TRPL_ERR_ARG, "C=%d must be in [1, %d]", C, trpl::kMaxCurves);
+    if (S < 0) return api_fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (C < 1 || C > trpl::kMaxCurves) return api_fail(TRPL_ERR_ARG, "C=%d must be in [1, %d]", C, trpl::kMaxCurves);
     if (seconds) *seconds = 0.0;
-    if (!X || !lengths_nm || !dN || !obs || !n_obs || !P) return fail(TRPL_ERR_ARG, "NULL pointer argument");
-    if (obs_ld < 1) return fail(TRPL_ERR_ARG, "obs_ld must be >= 1");
+    if (!X || !lengths_nm || !dN || !obs || !n_obs || !P) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (obs_ld < 1) return api_fail(TRPL_ERR_ARG, "obs_ld must be >= 1");
     const bool interp = obs_hi || obs_dx || obs_h;
-    if (interp && !(obs_hi && obs_dx && obs_h)) return fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h go together");
+    if (interp && !(obs_hi && obs_dx && obs_h)) return api_fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h go together");
     int visible = 0;
-    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) return fail(TRPL_ERR_NODEVICE, "no HIP device visible");
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) return api_fail(TRPL_ERR_NODEVICE, "no HIP device visible");
     if (n_devices <= 0) {
-        if (devices) return fail(TRPL_ERR_ARG, "a device list needs n_devices >= 1");
+        if (devices) return api_fail(TRPL_ERR_ARG, "a device list needs n_devices >= 1");
         n_devices = visible;
     }
-    if (n_devices > 64) return fail(TRPL_ERR_ARG, "n_devices=%d exceeds 64", n_devices);
+    if (n_devices > 64) return api_fail(TRPL_ERR_ARG, "n_devices=%d exceeds 64", n_devices);
     for (int r = 0; devices && r < n_devices; r++)
         if (devices[r] < 0 || devices[r] >= visible)
-            return fail(TRPL_ERR_ARG, "devices[%d]=%d out of range (%d visible)", r, devices[r], visible);
+            return api_fail(TRPL_ERR_ARG, "devices[%d]=%d out of range (%d visible)", r, devices[r], visible);
     if (int rc = check_variant_flags(flags, L)) return rc;
     for (int c = 0; c < C; c++)
         if (n_obs[c] < 1 || n_obs[c] > obs_ld)
-            return fail(TRPL_ERR_ARG, "n_obs[%d]=%lld out of range (obs_ld %lld)", c, (long long)n_obs[c], (long long)obs_ld);
+            return api_fail(TRPL_ERR_ARG, "n_obs[%d]=%lld out of range (obs_ld %lld)", c, (long long)n_obs[c], (long long)obs_ld);
     if (interp) {                                    // host data: the same checks as trpl_loglik_obs
-        if (plT != 1) return fail(TRPL_ERR_ARG, "off-grid observations need plT = 1");
+        if (plT != 1) return api_fail(TRPL_ERR_ARG, "off-grid observations need plT = 1");
         if (int rc = check_brackets(obs_hi, obs_dx, obs_h, C, obs_ld, n_obs, T)) return rc;
     }
     if (S == 0) return TRPL_OK;
@@ -178,7 +177,7 @@ int trpl_loglik_multi(const double *X, int64_t S, int32_t C, const double *lengt
         hipError_t e = hipSetDevice(sh[r].dev);
         if (e == hipSuccess) e = hipStreamSynchronize(sh[r].st);
         if (e != hipSuccess && rc == TRPL_OK)
-            rc = fail(TRPL_ERR_HIP, "device %d (shard %d): %s", sh[r].dev, r, hipGetErrorString(e));
+            rc = api_fail(TRPL_ERR_HIP, "device %d (shard %d): %s", sh[r].dev, r, hipGetErrorString(e));
     }
     if (seconds) *seconds = now_s() - t0;
     sh.clear();
@@ -236,7 +235,7 @@ const RcclApi *rccl_api()
 #define RCCL_TRY(expr)                                                                                          \
     do {                                                                                                        \
         ncclResult_t r_ = (expr);                                                                               \
-        if (r_ != ncclSuccess) return fail(TRPL_ERR_HIP, "%s: %s", #expr, rccl_api()->GetErrorString(r_));       \
+        if (r_ != ncclSuccess) return api_fail(TRPL_ERR_HIP, "%s: %s", #expr, rccl_api()->GetErrorString(r_));       \
     } while (0)
 
 // out[s] = gathered[r * widest + (s - lo_r)]: the all-gather moves equal counts, shards differ by one sample
@@ -264,15 +263,15 @@ struct trpl_multi {
 
 int trpl_multi_create(const int32_t *devices, int32_t n_devices, trpl_multi_t **handle)
 {
-    if (!handle) return fail(TRPL_ERR_ARG, "handle must not be NULL");
+    if (!handle) return api_fail(TRPL_ERR_ARG, "handle must not be NULL");
     *handle = nullptr;
     int visible = 0;
-    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) return fail(TRPL_ERR_NODEVICE, "no HIP device visible");
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) return api_fail(TRPL_ERR_NODEVICE, "no HIP device visible");
     if (n_devices <= 0) {
-        if (devices) return fail(TRPL_ERR_ARG, "a device list needs n_devices >= 1");
+        if (devices) return api_fail(TRPL_ERR_ARG, "a device list needs n_devices >= 1");
         n_devices = visible;
     }
-    if (n_devices > 64) return fail(TRPL_ERR_ARG, "n_devices=%d exceeds 64", n_devices);
+    if (n_devices > 64) return api_fail(TRPL_ERR_ARG, "n_devices=%d exceeds 64", n_devices);
     trpl_multi *h = new trpl_multi;
     h->n = n_devices;
     for (int r = 0; r < n_devices; r++) {
@@ -281,12 +280,12 @@ int trpl_multi_create(const int32_t *devices, int32_t n_devices, trpl_multi_t **
         for (int q = 0; q < r; q++) dup = dup || h->dev[q] == d;
         if (d < 0 || d >= visible || dup) {
             delete h;
-            return fail(TRPL_ERR_ARG, "devices[%d]=%d: out of range (%d visible) or listed twice (one RCCL rank per device)", r, d, visible);
+            return api_fail(TRPL_ERR_ARG, "devices[%d]=%d: out of range (%d visible) or listed twice (one RCCL rank per device)", r, d, visible);
         }
         h->dev.push_back(d);
     }
     const RcclApi *api = rccl_api();
-    if (!api->dl) { delete h; return fail(TRPL_ERR_UNSUPPORTED, "RCCL could not be loaded: %s", api->why); }
+    if (!api->dl) { delete h; return api_fail(TRPL_ERR_UNSUPPORTED, "RCCL could not be loaded: %s", api->why); }
     int prev = 0;
     (void)hipGetDevice(&prev);
     h->st.assign(n_devices, nullptr); h->send.assign(n_devices, nullptr); h->recv.assign(n_devices, nullptr);
@@ -315,13 +314,13 @@ int trpl_multi_device_count(const trpl_multi_t *h) { return h ? h->n : 0; }
 
 int trpl_multi_synchronize(trpl_multi_t *h)
 {
-    if (!h) return fail(TRPL_ERR_ARG, "handle must not be NULL");
+    if (!h) return api_fail(TRPL_ERR_ARG, "handle must not be NULL");
     int prev = 0, rc = TRPL_OK;
     (void)hipGetDevice(&prev);
     for (int r = 0; r < h->n; r++) {
         hipError_t e = hipSetDevice(h->dev[r]);
         if (e == hipSuccess) e = hipStreamSynchronize(h->st[r]);
-        if (e != hipSuccess && rc == TRPL_OK) rc = fail(TRPL_ERR_HIP, "device %d (rank %d): %s", h->dev[r], r, hipGetErrorString(e));
+        if (e != hipSuccess && rc == TRPL_OK) rc = api_fail(TRPL_ERR_HIP, "device %d (rank %d): %s", h->dev[r], r, hipGetErrorString(e));
     }
     (void)hipSetDevice(prev);
     return rc;
@@ -353,18 +352,18 @@ int trpl_loglik_multi_dev(trpl_multi_t *h, const double *const *X, int64_t S, in
                           double *const *P_full, double *const *sse, int32_t *const *status, int64_t *const *iters_total,
                           uint32_t flags)
 {
-    if (!h) return fail(TRPL_ERR_ARG, "handle must not be NULL");
+    if (!h) return api_fail(TRPL_ERR_ARG, "handle must not be NULL");
     if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
-    if (S < 0) return fail(TRPL_ERR_ARG, "S must be >= 0");
-    if (C < 1 || C > trpl::kMaxCurves) return fail(TRPL_ERR_ARG, "C=%d must be in [1, %d]", C, trpl::kMaxCurves);
-    if (!X || !lengths_nm || !dN || !obs || !n_obs || !P_full) return fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (S < 0) return api_fail(TRPL_ERR_ARG, "S must be >= 0");
+    if (C < 1 || C > trpl::kMaxCurves) return api_fail(TRPL_ERR_ARG, "C=%d must be in [1, %d]", C, trpl::kMaxCurves);
+    if (!X || !lengths_nm || !dN || !obs || !n_obs || !P_full) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");
     const bool interp = obs_hi || obs_dx || obs_h;
-    if (interp && !(obs_hi && obs_dx && obs_h)) return fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h go together");
-    if (interp && plT != 1) return fail(TRPL_ERR_ARG, "off-grid observations need plT = 1");
+    if (interp && !(obs_hi && obs_dx && obs_h)) return api_fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h go together");
+    if (interp && plT != 1) return api_fail(TRPL_ERR_ARG, "off-grid observations need plT = 1");
     if (int rc = check_variant_flags(flags, L)) return rc;
     for (int c = 0; c < C; c++)
         if (n_obs[c] < 1 || n_obs[c] > obs_ld)
-            return fail(TRPL_ERR_ARG, "n_obs[%d]=%lld out of range (obs_ld %lld)", c, (long long)n_obs[c], (long long)obs_ld);
+            return api_fail(TRPL_ERR_ARG, "n_obs[%d]=%lld out of range (obs_ld %lld)", c, (long long)n_obs[c], (long long)obs_ld);
     if (S == 0) return TRPL_OK;
     const int n = h->n;
     const int64_t widest = (S + n - 1) / n;
@@ -394,7 +393,7 @@ int trpl_loglik_multi_dev(trpl_multi_t *h, const double *const *X, int64_t S, in
             HIP_TRY(hipMemsetAsync(h->send[r], 0, (size_t)widest * 8, h->st[r]));       // P starts at 0; the pad stays 0
             if (nr == 0) continue;
             if (!X[r] || !dN[r] || !obs[r] || !P_full[r] || (interp && (!obs_hi[r] || !obs_dx[r] || !obs_h[r])))
-                return fail(TRPL_ERR_ARG, "NULL device pointer in the tables of rank %d", r);
+                return api_fail(TRPL_ERR_ARG, "NULL device pointer in the tables of rank %d", r);
             double *sse_r = sse ? sse[r] : nullptr;
             DevBuf tmp;                              // the fused call needs somewhere to put the per-curve sums
             if (!sse_r) { HIP_TRY(tmp.alloc((size_t)nr * C * 8, h->st[r])); sse_r = tmp.as<double>(); }
@@ -412,7 +411,7 @@ int trpl_loglik_multi_dev(trpl_multi_t *h, const double *const *X, int64_t S, in
         for (int r = 0; r < n; r++) {
             ncclResult_t e = api->AllGather(h->send[r], even ? (void *)P_full[r] : (void *)h->recv[r], (size_t)widest,
                                             ncclDouble, h->comm[r], h->st[r]);
-            if (e != ncclSuccess) { (void)api->GroupEnd(); return fail(TRPL_ERR_HIP, "ncclAllGather (rank %d): %s", r, api->GetErrorString(e)); }
+            if (e != ncclSuccess) { (void)api->GroupEnd(); return api_fail(TRPL_ERR_HIP, "ncclAllGather (rank %d): %s", r, api->GetErrorString(e)); }
         }
         RCCL_TRY(api->GroupEnd());
         if (!even)
