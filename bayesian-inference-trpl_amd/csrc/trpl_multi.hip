@@ -276,8 +276,11 @@ int trpl_multi_create(const int32_t *devices, int32_t n_devices, trpl_multi_t **
     h->n = n_devices;
     for (int r = 0; r < n_devices; r++) {
         const int d = devices ? devices[r] : r;
+        // RCCL wants one rank per device; TRPL_MULTI_ALLOW_DUP=1 lets the tests run several "ranks" on one device
+        // against a stand-in collective library (tests/mock_rccl)
+        static const bool allow_dup = getenv("TRPL_MULTI_ALLOW_DUP") && atoi(getenv("TRPL_MULTI_ALLOW_DUP"));
         bool dup = false;
-        for (int q = 0; q < r; q++) dup = dup || h->dev[q] == d;
+        for (int q = 0; q < r && !allow_dup; q++) dup = dup || h->dev[q] == d;
         if (d < 0 || d >= visible || dup) {
             delete h;
             return api_fail(TRPL_ERR_ARG, "devices[%d]=%d: out of range (%d visible) or listed twice (one RCCL rank per device)", r, d, visible);

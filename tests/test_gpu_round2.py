@@ -557,3 +557,53 @@ def test_host_buffer_solve_writes_pl_straight_into_the_callers_memory(gpu):
     with ThreadPoolExecutor(2) as ex:
         list(ex.map(lambda b: gpu.solve_pl(X, lens[1], Time, 128, T, ini[1], out=b), bufs))
     assert np.array_equal(bufs[0], bufs[1])
+
+
+def test_multi_rank_logic_with_a_stand_in_collective_library(gpu, tmp_path):
+    """The N > 1 logic of trpl_loglik_multi_dev on a one-GPU box: three and four "ranks" on device 0
+    (TRPL_MULTI_ALLOW_DUP=1) with the six RCCL entry points bound to tests/mock_rccl (stream-ordered
+    device-to-device copies) instead of librccl -- uneven shards (padded exchange + unpadding with every rank
+    index), equal shards (direct exchange), more ranks than samples, per-shard outputs.  Every rank's P[S]
+    must equal the single launch bit for bit.  RCCL itself is exercised by the one-rank tests above."""
+    so = str(tmp_path / "libmock_rccl.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O1", "-o", so,
+                           os.path.join(ROOT, "tests", "mock_rccl", "mock_rccl.cpp")])
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+import trpl_amd
+from trpl_amd import device as tdev, workloads as wl
+dev = torch.device("cuda", 0)
+ini, lens = wl.power_scan(128)
+ini_d = torch.from_numpy(ini).to(dev)
+T, Time = 40, 1.0
+obs = torch.full((3, T + 1), 20.0, dtype=torch.float64, device=dev) - 0.01 * torch.arange(T + 1, device=dev)
+for n, S in ((3, 1000), (4, 1000), (3, 999), (4, 2), (2, 5121)):
+    Xh = wl.samples(S, seed=91)
+    X = torch.from_numpy(Xh).to(dev)
+    P = torch.zeros(S, dtype=torch.float64, device=dev)
+    sse = torch.empty((3, S), dtype=torch.float64, device=dev)
+    st = torch.empty((3, S), dtype=torch.int32, device=dev)
+    it = torch.empty((3, S), dtype=torch.int64, device=dev)
+    flags = trpl_amd._abi.pin_variant(0, 3 * S, 128, T)
+    tdev.loglik_device(X, ini_d, lens, Time, 128, T, obs, [T + 1] * 3, P, sse, st, it, flags=flags)
+    torch.cuda.synchronize()
+    with tdev.MultiDevice([0] * n) as md:
+        b = md.shard_bounds(S)
+        Xs = [X[lo:hi].contiguous() for lo, hi in b]
+        Pf = [torch.full((S,), -7.0, dtype=torch.float64, device=dev) for _ in range(n)]
+        ss = [torch.empty((3, hi - lo), dtype=torch.float64, device=dev) for lo, hi in b]
+        sts = [torch.empty((3, hi - lo), dtype=torch.int32, device=dev) for lo, hi in b]
+        its = [torch.empty((3, hi - lo), dtype=torch.int64, device=dev) for lo, hi in b]
+        for _ in range(2):
+            md.loglik(Xs, [ini_d] * n, lens, Time, 128, T, [obs] * n, [T + 1] * 3, Pf, sse=ss, status=sts, iters_total=its)
+            md.synchronize()
+            for r, (lo, hi) in enumerate(b):
+                assert torch.equal(Pf[r], P), (n, S, r)
+                assert torch.equal(ss[r], sse[:, lo:hi]) and torch.equal(sts[r], st[:, lo:hi]) and torch.equal(its[r], it[:, lo:hi])
+print("MOCK-OK")
+''' % ROOT
+    env = dict(os.environ, TRPL_RCCL_LIBRARY=so, TRPL_MULTI_ALLOW_DUP="1", TRPL_AUTOBUILD="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "MOCK-OK" in out.stdout, (out.stdout[-500:], out.stderr[-2500:])
