@@ -60,6 +60,18 @@ def test_paired_kernel_reproduces_the_reference_goldens(gpu, golden):
             pl, st, it, _ = gpu.solve_pl(X12, float(lengths[c]), Time, L, T, g["ini"][c], kernel="pair")
             assert not st.any() and np.all(np.abs(it - iters) <= 0.01 * iters + 1), (name, c)
             assert np.max(np.abs(pl - want) / np.abs(want)) < 1e-9, (name, c)
+    # bayes_e2e.npz: the likelihoods bayeslib.bayes(pvSim, ...) itself produced (two experiments: on-grid and a
+    # prefix grid, float32 PL staging), through the paired kernel's fused path, and through its real-data sibling
+    g = golden("bayes_e2e")
+    T, tg, npre = int(g["T"]), g["tgrid"], int(g["npre"])
+    for obs in (list(g["obs0"]), list(g["obs1"])):
+        e = 0 if len(obs[0]) == len(tg) else 1
+        info = {}
+        P32 = gpu.loglik(g["X"], g["ini"], 2000.0, float(g["time"]), 128, T, obs, pl_f32=True, info=info, kernel="pair")
+        assert not info["status"].any()
+        assert np.max(np.abs(P32 - g["P"][e]) / np.abs(g["P"][e])) < 2e-5
+        single = gpu.loglik(g["X"], g["ini"], 2000.0, float(g["time"]), 128, T, obs, pl_f32=True, kernel="single")
+        assert np.allclose(P32, single, rtol=1e-6, atol=0)
     # an odd sample count (the last wavefront holds one system) and a single sample
     g = golden("pvsim_power")
     for n in (1, 3):
