@@ -619,3 +619,19 @@ print("MOCK-OK")
     env = dict(os.environ, TRPL_RCCL_LIBRARY=so, TRPL_MULTI_ALLOW_DUP="1", TRPL_AUTOBUILD="0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "MOCK-OK" in out.stdout, (out.stdout[-500:], out.stderr[-2500:])
+
+
+def test_strict_mode_is_bit_identical_to_the_oracle_on_hundreds_of_systems(gpu, oracle):
+    """STRICT against the pinned oracle on a wider draw than the goldens hold: 512 Power_scan samples and 128
+    Twothick samples (all six curves, the stiff 311 nm ones included) x 300 steps -- PL bit for bit (compared as
+    float64 bit patterns), per-system iteration totals and status equal."""
+    w = gpu.workloads
+    T = 300
+    Time = T * 0.025
+    for name, (ini, lens), S in (("power_scan", w.power_scan(128), 512), ("twothick", w.twothick(128), 128)):
+        X = w.samples(S, seed=101)[:, :12]
+        for c in range(len(lens)):
+            r = oracle.pvsim(X, lens[c], Time, 128, T, ini[c], nthreads=nthreads())
+            pl, st, it, _ = gpu.solve_pl(X, lens[c], Time, 128, T, ini[c], strict=True)
+            assert np.array_equal(st, r["status"]) and np.array_equal(it, r["iters_total"]), (name, c)
+            assert np.array_equal(pl.view(np.uint64), r["plI"].view(np.uint64)), (name, c)
