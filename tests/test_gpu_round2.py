@@ -635,3 +635,20 @@ def test_strict_mode_is_bit_identical_to_the_oracle_on_hundreds_of_systems(gpu, 
             pl, st, it, _ = gpu.solve_pl(X, lens[c], Time, 128, T, ini[c], strict=True)
             assert np.array_equal(st, r["status"]) and np.array_equal(it, r["iters_total"]), (name, c)
             assert np.array_equal(pl.view(np.uint64), r["plI"].view(np.uint64)), (name, c)
+
+
+def test_fast_kernels_vs_oracle_over_a_longer_window(gpu, oracle):
+    """Both FAST steppers against the oracle over 1200 steps (30 ns: well past the stiff start, deep into the
+    two-iterations-per-step regime that dominates a production run), 256 samples x 3 curves: PL to 1e-9 above the
+    floor, > 99 % of the systems with exactly the oracle's iteration total, none flagged."""
+    w = gpu.workloads
+    ini, lens = w.power_scan(128)
+    S, T = 256, 1200
+    Time = T * 0.025
+    X = w.samples(S, seed=111)[:, :12]
+    for c in range(3):
+        r = oracle.pvsim(X, lens[c], Time, 128, T, ini[c], nthreads=nthreads())
+        assert not r["status"].any()
+        for kernel in ("single", "pair"):
+            err, same = _check_pl_against(gpu, X, lens[c], Time, 128, T, ini[c], r["plI"], r["iters_total"], kernel)
+            assert same > 0.99, (c, kernel, same)
