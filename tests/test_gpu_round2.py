@@ -652,3 +652,30 @@ def test_fast_kernels_vs_oracle_over_a_longer_window(gpu, oracle):
         for kernel in ("single", "pair"):
             err, same = _check_pl_against(gpu, X, lens[c], Time, 128, T, ini[c], r["plI"], r["iters_total"], kernel)
             assert same > 0.99, (c, kernel, same)
+
+
+def test_paired_kernel_offgrid_observations_normalize_and_f32_staging_vs_oracle(gpu, oracle):
+    """The paired kernel's less-travelled emission paths against the oracle's restatement of bayeslib.simulate:
+    observation times OFF the simulation grid (per-row griddata in the reference, bayeslib.py:184-191), with
+    self-normalisation (:150-154) and with the reference's float32 PL staging (:137) -- 96 samples x 3 curves."""
+    w = gpu.workloads
+    ini, lens = w.power_scan(128)
+    S, T = 96, 160
+    Time = T * 0.025
+    X = w.samples(S, seed=121)
+    rng = np.random.default_rng(7)
+    times = [np.sort(rng.uniform(0.0, Time, 57)) for _ in range(3)]
+    obs = [np.full(57, 19.0) - 0.3 * t for t in times]
+    for normalize in (False, True):
+        for f32 in (False, True):
+            want = oracle.simulate_loglik(X, ini, lens, Time, 128, T, [(times, obs)],
+                                          pl_dtype=np.float32 if f32 else np.float64, normalize=normalize,
+                                          nthreads=nthreads())[0]
+            for kernel in ("pair", "single"):
+                info = {}
+                P = gpu.loglik(X, ini, lens, Time, 128, T, obs, times=times, pl_f32=f32, normalize=normalize,
+                               kernel=kernel, info=info)
+                assert not info["status"].any()
+                # float32 staging: one float32 ulp of log10 PL enters every residual (as in the unfused golden test)
+                gate = 2e-5 if f32 else 1e-8
+                assert np.max(np.abs(P - want) / np.abs(want)) < gate, (normalize, f32, kernel)
