@@ -18,12 +18,18 @@ namespace trpl {
 // Non-temporal (streaming) loads pay when every cache line is consumed by ONE load instruction -- a lane's
 // chunk of a row is at most 16 bytes -- and cost up to 2x HBM reads when a lane needs several 16-byte loads
 // per row (interleaved layout, NR * sizeof(T) > 16: the line is gone before the second instruction asks for
-// its other half).  So: one wave per workgroup everywhere, non-temporal loads only for 16-byte chunks.
+// its other half).  So: one wave per workgroup everywhere, non-temporal loads only where an instruction
+// consumes whole lines: directly for 16-byte chunks, through an LDS transpose for wider rows (TRPL_PCRB_STAGE).
 #ifndef TRPL_PCRB_WAVES
 #define TRPL_PCRB_WAVES 1       // wavefronts per workgroup
 #endif
 #ifndef TRPL_PCRB_NT
 #define TRPL_PCRB_NT -1         // -1: automatic (see above), 0: never, 1: non-temporal loads always
+#endif
+#ifndef TRPL_PCRB_STAGE
+#define TRPL_PCRB_STAGE 1       // rows wider than 16 bytes per lane: streamed with full-line non-temporal loads and
+                                // transposed to the interleaved layout through LDS: L = 512 fp64 5.72 -> 5.97 TB/s,
+                                // L = 256 fp64 / L = 512 fp32 +1 % (0: per-lane 16-byte loads, cached)
 #endif
 #ifndef TRPL_PCRB_CAP
 #define TRPL_PCRB_CAP 256       // grid cap: 256 * CAP workgroups, beyond that a wave loops over systems
@@ -56,6 +62,41 @@ __device__ __forceinline__ void pcrb_load_row(const T *p, T (&v)[NR])
     }
 }
 
+// A row of L elements streamed with fully coalesced 16-byte-per-lane non-temporal loads (every cache line is
+// consumed by one instruction), parked in LDS in node order and read back as the lane's NR adjacent elements.
+// A wavefront's DS instructions execute in order: no barrier.
+template <typename T, int L, int NR>
+__device__ __forceinline__ void pcrb_issue_row(const T *row, int lane, T (&stage)[NR])
+{
+    constexpr int PER = 16 / sizeof(T), CH = L / (64 * PER);        // elements per 16 bytes, chunks of 1 KiB per row
+    typedef T vec16 __attribute__((ext_vector_type(PER), aligned(sizeof(T))));
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+        const vec16 t = __builtin_nontemporal_load(reinterpret_cast<const vec16 *>(row) + k * 64 + lane);
+#pragma unroll
+        for (int e = 0; e < PER; e++) stage[k * PER + e] = t[e];
+    }
+}
+template <typename T, int L, int NR>
+__device__ __forceinline__ void pcrb_transpose_row(const T (&stage)[NR], T *buf, int lane, T (&v)[NR])
+{
+    constexpr int PER = 16 / sizeof(T), CH = L / (64 * PER);
+    typedef T vec16 __attribute__((ext_vector_type(PER), aligned(16)));
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+        vec16 t;
+#pragma unroll
+        for (int e = 0; e < PER; e++) t[e] = stage[k * PER + e];
+        reinterpret_cast<vec16 *>(buf)[k * 64 + lane] = t;
+    }
+#pragma unroll
+    for (int k = 0; k < NR / PER; k++) {
+        const vec16 t = reinterpret_cast<const vec16 *>(buf)[lane * (NR / PER) + k];
+#pragma unroll
+        for (int e = 0; e < PER; e++) v[k * PER + e] = t[e];
+    }
+}
+
 template <typename T, int L, bool STRICT>
 __global__ void __launch_bounds__(64 * TRPL_PCRB_WAVES) pcr_batched_kernel(const T *__restrict__ ld, const T *__restrict__ d,
                                                           const T *__restrict__ ud, const T *__restrict__ b,
@@ -72,6 +113,10 @@ __global__ void __launch_bounds__(64 * TRPL_PCRB_WAVES) pcr_batched_kernel(const
     __shared__ __attribute__((aligned(16))) T xch_all[(!STRICT && L >= 128) ? TRPL_PCRB_WAVES * 3 * XW : 4];
     T *xch = xch_all + (threadIdx.x >> 6) * 3 * XW;
     (void)xch;
+    constexpr bool STAGE = TRPL_PCRB_STAGE != 0 && !STRICT && L >= 128 && NR * sizeof(T) > 16;
+    __shared__ __attribute__((aligned(16))) T rowbuf_all[STAGE ? TRPL_PCRB_WAVES * L : 4];
+    T *rowbuf = rowbuf_all + (STAGE ? (threadIdx.x >> 6) * L : 0);
+    (void)rowbuf;
     const int64_t wave = (int64_t)blockIdx.x * TRPL_PCRB_WAVES + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * TRPL_PCRB_WAVES;
     for (int64_t s = wave; s < S; s += nwaves) {
@@ -80,9 +125,17 @@ __global__ void __launch_bounds__(64 * TRPL_PCRB_WAVES) pcr_batched_kernel(const
         if constexpr (!STRICT && L >= 128) {
             // interleaved layout: lane owns nodes NR*lane .. NR*lane+NR-1 -> 16-byte loads, fully
             // coalesced 1 KiB per wave-instruction
-            const int64_t o = base + NR * lane;
-            pcrb_load_row<NT>(ld + o, vl); pcrb_load_row<NT>(d + o, vd);
-            pcrb_load_row<NT>(ud + o, vu); pcrb_load_row<NT>(b + o, vb);
+            if constexpr (STAGE) {
+                T sl[NR], sd[NR], su[NR], sb[NR];              // all four rows in flight, then through LDS one by one
+                pcrb_issue_row<T, L, NR>(ld + base, lane, sl); pcrb_issue_row<T, L, NR>(d + base, lane, sd);
+                pcrb_issue_row<T, L, NR>(ud + base, lane, su); pcrb_issue_row<T, L, NR>(b + base, lane, sb);
+                pcrb_transpose_row<T, L, NR>(sl, rowbuf, lane, vl); pcrb_transpose_row<T, L, NR>(sd, rowbuf, lane, vd);
+                pcrb_transpose_row<T, L, NR>(su, rowbuf, lane, vu); pcrb_transpose_row<T, L, NR>(sb, rowbuf, lane, vb);
+            } else {
+                const int64_t o = base + NR * lane;
+                pcrb_load_row<NT>(ld + o, vl); pcrb_load_row<NT>(d + o, vd);
+                pcrb_load_row<NT>(ud + o, vu); pcrb_load_row<NT>(b + o, vb);
+            }
             if constexpr (TRPL_CR_HYBRID != 0) cr_pcr_solve<T, NR>(vl, vd, vu, vb, vx, lane, xch);
             else if constexpr (sizeof(T) == 8) pcr_solve_L<NR, L>(vl, vd, vu, vb, vx, lane, xch);
             else                          f32::pcr_solve<NR, L>(vl, vd, vu, vb, vx, lane, xch);
