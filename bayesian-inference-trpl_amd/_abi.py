@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("TRPL_LIBRARY", os.path.join(_HERE, "libtrpl_hip.so"))
 # status codes / flags (include/trpl.h)
 OK, ERR_ARG, ERR_HIP, ERR_NODEVICE, ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 FLAG_STRICT, FLAG_PL_F32, FLAG_NORMALIZE, FLAG_FP32 = 0x1, 0x2, 0x4, 0x8
-FLAG_KERNEL_PAIR, FLAG_KERNEL_SINGLE, FLAG_MIXED = 0x10, 0x20, 0x40
+FLAG_KERNEL_PAIR, FLAG_KERNEL_SINGLE, FLAG_MIXED, FLAG_SNAP_RAW = 0x10, 0x20, 0x40, 0x80
 KERNEL_FAST, KERNEL_FAST_PAIR, KERNEL_STRICT, KERNEL_FP32, KERNEL_MIXED = 0, 1, 2, 3, 4
 ABI_VERSION = 2
 MAX_SNAPS = 16
@@ -43,6 +43,10 @@ SIGNATURES = {
                            _i32, _vp, _vp, _vp, _u32, _i32, _pd],
     "trpl_solve_pl_snap_dev": [_vp, _i64, _f64, _f64, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _i64, _vp, _vp,
                                _vp, _i32, _vp, _vp, _vp, _u32, _vp],
+    "trpl_solve_pl_resume": [_vp, _i64, _f64, _f64, _i32, _i64, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _i64,
+                             _vp, _vp, _vp, _i32, _vp, _vp, _vp, _u32, _i32, _pd],
+    "trpl_solve_pl_resume_dev": [_vp, _i64, _f64, _f64, _i32, _i64, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _i32,
+                                 _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _u32, _vp],
     "trpl_log10_clamp": [_vp, _i32, _i64, _i64, _i64, _f64, _i32, _pd],
     "trpl_log10_clamp_dev": [_vp, _i32, _i64, _i64, _i64, _f64, _vp],
     "trpl_sse_accumulate": [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _vp, _i32, _pd],

@@ -26,6 +26,7 @@ namespace trpl {
 
 constexpr uint32_t kFlagPlF32 = 0x2;       // TRPL_FLAG_PL_F32
 constexpr uint32_t kFlagNormalize = 0x4;   // TRPL_FLAG_NORMALIZE
+constexpr uint32_t kFlagSnapRaw = 0x80;    // TRPL_FLAG_SNAP_RAW
 
 // ---- layout dispatch: LAY 0 = blocked/strict, 1 = blocked/fast (L < 128), 2 = interleaved/fast ----
 template <int LAY, int NR, int W>
@@ -302,14 +303,15 @@ struct SnapSink {
                                          int64_t row, bool live, NodeOf node)
     {
         const int64_t at = row * a.snap_ld + a.snap_slot[next];
+        const bool raw = (a.flags & kFlagSnapRaw) != 0;          // solver units: what a resume reads back bit for bit
         if (live) {
 #pragma unroll
             for (int j = 0; j < NR; j++) {
                 const int i = node(j);
-                if (a.snapN) a.snapN[at * L + i] = N[j] / cc.dx3;
-                if (a.snapP) a.snapP[at * L + i] = P[j] / cc.dx3;
+                if (a.snapN) a.snapN[at * L + i] = raw ? N[j] : N[j] / cc.dx3;
+                if (a.snapP) a.snapP[at * L + i] = raw ? P[j] : P[j] / cc.dx3;
                 if (a.snapE) {
-                    a.snapE[at * (L + 1) + i] = E[j] / cc.dx;
+                    a.snapE[at * (L + 1) + i] = raw ? E[j] : E[j] / cc.dx;
                     if (i == L - 1) a.snapE[at * (L + 1) + L] = 0.0;            // E_L is never written (:205)
                 }
             }
@@ -572,8 +574,33 @@ __global__ void __launch_bounds__(64, (STRICT || L > 128) ? (L > 256 ? 1 : 2) : 
     int status = 0;
     int64_t itot = 0;
 
+    int64_t t_begin = 0;
+    if constexpr (SNAP) {
+        if (a.resN != nullptr) {                   // resume at t0 >= 4 from the five levels U^{t0-4} .. U^{t0} (level m <-> t0-4+m)
+            t_begin = a.t0;
+            const int64_t r5 = sink.orow * 5;
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                const int i = node_of<LAY, NR, W>(ln, j);
+                Nk[j] = a.resN[(r5 + 4) * L + i]; Pk[j] = a.resP[(r5 + 4) * L + i]; Ek[j] = a.resE[(r5 + 4) * (L + 1) + i];
+#pragma unroll
+                for (int m = 0; m < 4; m++) {      // level t0-1-m
+                    const double n_ = a.resN[(r5 + 3 - m) * L + i], p_ = a.resP[(r5 + 3 - m) * L + i];
+                    hE[m][j] = a.resE[(r5 + 3 - m) * (L + 1) + i];
+                    if constexpr (STRICT) { hN[m][j] = n_; hP[m][j] = p_; }
+                    else {
+                        const int slot = (int)((a.t0 - 1 - m) & 3) * HSLOT;      // the ring: slot (t' mod 4) holds U^{t'}
+                        hist[slot + (0 * NR + j) * 64 + hl] = n_; hist[slot + (1 * NR + j) * 64 + hl] = p_;
+                    }
+                }
+            }
+        }
+    }
     int64_t pl_next = 0, pl_col = 0;               // next step with t % plT == 0 and its PL column t / plT (:276)
-    for (int64_t t = 0; t <= sink.t_last; t++) {   // tEvol, pvSimPCR.py:237
+    if constexpr (SNAP) {
+        if (t_begin > 0) { pl_col = (t_begin + a.plT - 1) / a.plT; pl_next = pl_col * a.plT; sink.base = pl_col; }
+    }
+    for (int64_t t = t_begin; t <= sink.t_last; t++) {   // tEvol, pvSimPCR.py:237
         if constexpr (SNAP) {                      // the state at time t, before it is stepped (:283-288)
             if (snap.due(t))
                 snap.template take<NR, L>(Nk, Pk, Ek, sink.orow, (int)threadIdx.x < W,
@@ -705,7 +732,7 @@ hipError_t launch_stepper(const StepArgs &a, hipStream_t stream)
     dim3 grid((unsigned)nsys), block(64);
     // development knob: extra dynamic LDS per workgroup lowers the number of resident waves
     static const unsigned lds_pad = getenv("TRPL_LDS_PAD") ? (unsigned)atoi(getenv("TRPL_LDS_PAD")) : 0u;
-    const bool snap = a.n_snap > 0;                // the snapshot code only exists in its own instantiation
+    const bool snap = a.n_snap > 0 || a.resN != nullptr;   // snapshot / resume code only exists in its own instantiation
     switch (a.L) {
 #define TRPL_CASE(LL) \
     case LL: \

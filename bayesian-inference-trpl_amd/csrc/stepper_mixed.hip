@@ -11,7 +11,7 @@ static hipError_t launch_stepper_mixed_impl(const StepArgs &a, hipStream_t strea
     const int64_t nsys = a.S * a.C;
     if (nsys <= 0) return hipSuccess;
     dim3 grid((unsigned)nsys), block(64);
-    const bool snap = a.n_snap > 0;
+    const bool snap = a.n_snap > 0 || a.resN != nullptr;
     switch (a.L) {
 #define TRPL_CASE(LL) \
     case LL: \

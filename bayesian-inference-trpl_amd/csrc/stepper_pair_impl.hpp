@@ -156,8 +156,30 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
     int64_t itotA = 0, itotB = 0;
     SnapSink snap(a, cc);
 
+    int64_t t_begin = 0;
+    if constexpr (SNAP) {
+        if (a.resN != nullptr) {                    // resume at t0 >= 4 (see stepper_impl.hpp)
+            t_begin = a.t0;
+            const int64_t r5 = (hi ? sinkB.orow : sinkA.orow) * 5;
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                const int i = NR * ln + j;
+                Nk[j] = a.resN[(r5 + 4) * L + i]; Pk[j] = a.resP[(r5 + 4) * L + i]; Ek[j] = a.resE[(r5 + 4) * (L + 1) + i];
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const int slot = (int)((a.t0 - 1 - m) & 3) * HSLOT;
+                    hE[m][j] = a.resE[(r5 + 3 - m) * (L + 1) + i];
+                    hist[slot + (0 * NR + j) * 64 + lane] = a.resN[(r5 + 3 - m) * L + i];
+                    hist[slot + (1 * NR + j) * 64 + lane] = a.resP[(r5 + 3 - m) * L + i];
+                }
+            }
+        }
+    }
     int64_t pl_next = 0, pl_col = 0;                // next step with t % plT == 0 and its PL column t / plT (:276)
-    for (int64_t t = 0; t <= sinkA.t_last; t++) {   // tEvol, pvSimPCR.py:237
+    if constexpr (SNAP) {
+        if (t_begin > 0) { pl_col = (t_begin + a.plT - 1) / a.plT; pl_next = pl_col * a.plT; sinkA.base = sinkB.base = pl_col; }
+    }
+    for (int64_t t = t_begin; t <= sinkA.t_last; t++) {   // tEvol, pvSimPCR.py:237
         if (deadA && deadB) break;
         if constexpr (SNAP) {                       // the state at time t, before it is stepped (:283-288)
             if (snap.due(t))
@@ -305,7 +327,7 @@ hipError_t launch_stepper_pair_t(const StepArgs &a, hipStream_t stream)
     if (a.L != pair::L) return hipErrorInvalidValue;
     const int64_t nblk = ((a.S + 1) / 2) * a.C;
     if (nblk <= 0) return hipSuccess;
-    if (a.n_snap > 0) hipLaunchKernelGGL((pair::stepper_pair_kernel<ISO, XM, true>), dim3((unsigned)nblk), dim3(64), 0, stream, a);
+    if (a.n_snap > 0 || a.resN != nullptr) hipLaunchKernelGGL((pair::stepper_pair_kernel<ISO, XM, true>), dim3((unsigned)nblk), dim3(64), 0, stream, a);
     else              hipLaunchKernelGGL((pair::stepper_pair_kernel<ISO, XM, false>), dim3((unsigned)nblk), dim3(64), 0, stream, a);
     return hipGetLastError();
 }

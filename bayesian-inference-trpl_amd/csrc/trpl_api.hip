@@ -201,36 +201,43 @@ int trpl_device_count(void)
 }
 
 /* ------------------------------------------------------------------ solve_pl ------------ */
-int trpl_solve_pl_snap_dev(const double *matpar, int64_t S, double length_nm, double time_ns, int32_t L, int64_t T,
-                           int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN, void *plI,
-                           int32_t pl_elem_bytes, int64_t pl_ld, int32_t *status, int64_t *iters_total,
-                           const int64_t *snap_steps, int32_t n_snap, double *plN, double *plP, double *plE,
-                           uint32_t flags, void *stream)
+static int solve_pl_dev_impl(const double *matpar, int64_t S, double length_nm, double time_ns, int32_t L, int64_t T,
+                             int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN, int64_t t0,
+                             const double *resN, const double *resP, const double *resE, void *plI,
+                             int32_t pl_elem_bytes, int64_t pl_ld, int32_t *status, int64_t *iters_total,
+                             const int64_t *snap_steps, int32_t n_snap, double *plN, double *plP, double *plE,
+                             uint32_t flags, void *stream)
 {
+    const bool resume = resN || resP || resE;
     if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
     if (S < 0) return api_fail(TRPL_ERR_ARG, "S must be >= 0");
     if (n_snap < 0 || n_snap > trpl::kMaxSnaps) return api_fail(TRPL_ERR_ARG, "n_snap=%d must be in [0, %d]", n_snap, trpl::kMaxSnaps);
     if (n_snap > 0 && !snap_steps) return api_fail(TRPL_ERR_ARG, "snap_steps must not be NULL when n_snap > 0");
+    if (resume && !(resN && resP && resE)) return api_fail(TRPL_ERR_ARG, "resN, resP and resE go together");
+    if (resume && (t0 < 4 || t0 > T)) return api_fail(TRPL_ERR_ARG, "t0=%lld must be in [4, T]: a resume needs five BDF levels", (long long)t0);
+    if (resume && (flags & TRPL_FLAG_FP32)) return api_fail(TRPL_ERR_UNSUPPORTED, "resume is not available with TRPL_FLAG_FP32");
     if (S == 0) return TRPL_OK;
-    if (!matpar || !dN || !plI) return api_fail(TRPL_ERR_ARG, "matpar, dN and plI must not be NULL");
+    if (!matpar || (!dN && !resume) || !plI) return api_fail(TRPL_ERR_ARG, "matpar, dN and plI must not be NULL");
     if (pl_elem_bytes != 4 && pl_elem_bytes != 8) return api_fail(TRPL_ERR_ARG, "pl_elem_bytes must be 4 or 8");
     if (pl_ld < T / plT + 1) return api_fail(TRPL_ERR_ARG, "pl_ld=%lld < T/plT+1", (long long)pl_ld);
     if (!(length_nm > 0)) return api_fail(TRPL_ERR_ARG, "length_nm must be > 0");
     if (S > 0x7fffffffLL) return api_fail(TRPL_ERR_ARG, "S too large for one launch");
     trpl::StepArgs a;
     memset(&a, 0, sizeof a);
-    a.X = matpar; a.xld = 12; a.dN = dN; a.pl = plI; a.pl_bytes = pl_elem_bytes; a.pl_ld = pl_ld;
+    a.X = matpar; a.xld = 12; a.dN = dN ? dN : matpar /* never used on a resume: the state comes from res* */;
+    a.pl = plI; a.pl_bytes = pl_elem_bytes; a.pl_ld = pl_ld;
     a.status = status; a.iters_total = iters_total;
     a.S = S; a.C = 1; a.L = L; a.T = T; a.plT = plT; a.MAX = max_iter; a.flags = flags;
     a.TOL = pow(10.0, -(double)tol_exp);                        /* pvSimPCR.py:112 */
     curve_const(length_nm, time_ns, L, T, a.curve[0]);
+    if (resume) { a.resN = resN; a.resP = resP; a.resE = resE; a.t0 = t0; }
     if (n_snap > 0 && (plN || plP || plE)) {
         // (step, slot) pairs, steps strictly ascending: the slot of a step is its FIRST position in the
-        // caller's list (Legacy/pvSim.py:122 `pT.index(t)`); steps outside [0, T] are never reached
+        // caller's list (Legacy/pvSim.py:122 `pT.index(t)`); steps outside [t0, T] are never reached
         a.snapN = plN; a.snapP = plP; a.snapE = plE; a.snap_ld = n_snap;
         for (int i = 0; i < n_snap; i++) {
             const int64_t st = snap_steps[i];
-            if (st < 0 || st > T) continue;
+            if (st < (resume ? t0 : 0) || st > T) continue;
             bool seen = false;
             for (int k = 0; k < a.n_snap; k++) seen = seen || a.snap_t[k] == (int32_t)st;
             if (seen) continue;
@@ -241,7 +248,28 @@ int trpl_solve_pl_snap_dev(const double *matpar, int64_t S, double length_nm, do
             a.snap_t[at] = (int32_t)st; a.snap_slot[at] = i;
         }
     }
-    return launch(a, flags, (hipStream_t)stream, T);
+    return launch(a, flags, (hipStream_t)stream, T - (resume ? t0 : 0));
+}
+
+int trpl_solve_pl_snap_dev(const double *matpar, int64_t S, double length_nm, double time_ns, int32_t L, int64_t T,
+                           int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN, void *plI,
+                           int32_t pl_elem_bytes, int64_t pl_ld, int32_t *status, int64_t *iters_total,
+                           const int64_t *snap_steps, int32_t n_snap, double *plN, double *plP, double *plE,
+                           uint32_t flags, void *stream)
+{
+    return solve_pl_dev_impl(matpar, S, length_nm, time_ns, L, T, plT, tol_exp, max_iter, dN, 0, nullptr, nullptr, nullptr,
+                             plI, pl_elem_bytes, pl_ld, status, iters_total, snap_steps, n_snap, plN, plP, plE, flags, stream);
+}
+
+int trpl_solve_pl_resume_dev(const double *matpar, int64_t S, double length_nm, double time_ns, int32_t L, int64_t T,
+                             int32_t plT, int32_t tol_exp, int32_t max_iter, int64_t t0, const double *resN,
+                             const double *resP, const double *resE, void *plI, int32_t pl_elem_bytes, int64_t pl_ld,
+                             int32_t *status, int64_t *iters_total, const int64_t *snap_steps, int32_t n_snap,
+                             double *plN, double *plP, double *plE, uint32_t flags, void *stream)
+{
+    if (!resN || !resP || !resE) return api_fail(TRPL_ERR_ARG, "resN, resP and resE must not be NULL");
+    return solve_pl_dev_impl(matpar, S, length_nm, time_ns, L, T, plT, tol_exp, max_iter, nullptr, t0, resN, resP, resE, plI,
+                             pl_elem_bytes, pl_ld, status, iters_total, snap_steps, n_snap, plN, plP, plE, flags, stream);
 }
 
 int trpl_solve_pl_dev(const double *matpar, int64_t S, double length_nm, double time_ns, int32_t L, int64_t T,
@@ -253,19 +281,22 @@ int trpl_solve_pl_dev(const double *matpar, int64_t S, double length_nm, double 
                                   pl_ld, status, iters_total, nullptr, 0, nullptr, nullptr, nullptr, flags, stream);
 }
 
-int trpl_solve_pl_snap(const double *matpar, int64_t S, double length_nm, double time_ns, int32_t L, int64_t T,
-                       int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN, void *plI,
-                       int32_t pl_elem_bytes, int64_t pl_ld, int32_t *status, int64_t *iters_total,
-                       const int64_t *snap_steps, int32_t n_snap, double *plN, double *plP, double *plE,
-                       uint32_t flags, int32_t device, double *seconds)
+static int solve_pl_host_impl(const double *matpar, int64_t S, double length_nm, double time_ns, int32_t L, int64_t T,
+                              int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN, int64_t t0,
+                              const double *resN, const double *resP, const double *resE, void *plI,
+                              int32_t pl_elem_bytes, int64_t pl_ld, int32_t *status, int64_t *iters_total,
+                              const int64_t *snap_steps, int32_t n_snap, double *plN, double *plP, double *plE,
+                              uint32_t flags, int32_t device, double *seconds)
 {
+    const bool resume = resN || resP || resE;
+    if (resume && !(resN && resP && resE)) return api_fail(TRPL_ERR_ARG, "resN, resP and resE go together");
     if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
     if (pl_elem_bytes != 4 && pl_elem_bytes != 8) return api_fail(TRPL_ERR_ARG, "pl_elem_bytes must be 4 or 8");
     if (S < 0) return api_fail(TRPL_ERR_ARG, "S must be >= 0");
     if (n_snap < 0 || n_snap > trpl::kMaxSnaps) return api_fail(TRPL_ERR_ARG, "n_snap=%d must be in [0, %d]", n_snap, trpl::kMaxSnaps);
     if (seconds) *seconds = 0.0;
     if (S == 0) return TRPL_OK;
-    if (!matpar || !dN || !plI) return api_fail(TRPL_ERR_ARG, "matpar, dN and plI must not be NULL");
+    if (!matpar || (!dN && !resume) || !plI) return api_fail(TRPL_ERR_ARG, "matpar, dN and plI must not be NULL");
     const int64_t ncol = T / plT + 1;
     if (pl_ld < ncol) return api_fail(TRPL_ERR_ARG, "pl_ld=%lld < T/plT+1", (long long)pl_ld);
     if (int rc = select_device(device)) return rc;
@@ -278,27 +309,38 @@ int trpl_solve_pl_snap(const double *matpar, int64_t S, double length_nm, double
     HIP_TRY(cs.open());
     const size_t span = ((size_t)(S - 1) * pl_ld + ncol) * pl_elem_bytes;
     void *pl_direct = map.map(plI, span);
-    DevBuf dm, dn, dp, ds, di, sN, sP, sE;
+    DevBuf dm, dn, dp, ds, di, sN, sP, sE, rN, rP, rE;
     HIP_TRY(dm.alloc((size_t)S * 12 * 8, cs.st));
     HIP_TRY(dn.alloc((size_t)L * 8, cs.st));
+    if (resume) {                                    // the five BDF levels of every system, solver units
+        const size_t bNP = (size_t)S * 5 * L * 8, bE = (size_t)S * 5 * (L + 1) * 8;
+        HIP_TRY(rN.alloc(bNP, cs.st)); HIP_TRY(rP.alloc(bNP, cs.st)); HIP_TRY(rE.alloc(bE, cs.st));
+        HIP_TRY(hipMemcpyAsync(rN.p, resN, bNP, hipMemcpyHostToDevice, cs.st));
+        HIP_TRY(hipMemcpyAsync(rP.p, resP, bNP, hipMemcpyHostToDevice, cs.st));
+        HIP_TRY(hipMemcpyAsync(rE.p, resE, bE, hipMemcpyHostToDevice, cs.st));
+    }
     if (!pl_direct) HIP_TRY(dp.alloc((size_t)S * ncol * pl_elem_bytes, cs.st));
     HIP_TRY(ds.alloc((size_t)S * 4, cs.st));
     HIP_TRY(di.alloc((size_t)S * 8, cs.st));
     HIP_TRY(hipMemcpyAsync(dm.p, matpar, (size_t)S * 12 * 8, hipMemcpyHostToDevice, cs.st));
-    HIP_TRY(hipMemcpyAsync(dn.p, dN, (size_t)L * 8, hipMemcpyHostToDevice, cs.st));
+    if (dN) HIP_TRY(hipMemcpyAsync(dn.p, dN, (size_t)L * 8, hipMemcpyHostToDevice, cs.st));
+    if (resume && !pl_direct)                        // the staged PL matrix starts as the caller's: columns before t0 are kept
+        HIP_TRY(hipMemcpy2DAsync(dp.p, (size_t)ncol * pl_elem_bytes, plI, (size_t)pl_ld * pl_elem_bytes,
+                                 (size_t)ncol * pl_elem_bytes, (size_t)S, hipMemcpyHostToDevice, cs.st));
     // snapshot buffers start as copies of the caller's (pvSimPCR.py:366-368): unfilled slots keep their contents
     const size_t nNP = (size_t)S * n_snap * L * 8, nE = (size_t)S * n_snap * (L + 1) * 8;
     if (n_snap > 0 && plN) { HIP_TRY(sN.alloc(nNP, cs.st)); HIP_TRY(hipMemcpyAsync(sN.p, plN, nNP, hipMemcpyHostToDevice, cs.st)); }
     if (n_snap > 0 && plP) { HIP_TRY(sP.alloc(nNP, cs.st)); HIP_TRY(hipMemcpyAsync(sP.p, plP, nNP, hipMemcpyHostToDevice, cs.st)); }
     if (n_snap > 0 && plE) { HIP_TRY(sE.alloc(nE, cs.st)); HIP_TRY(hipMemcpyAsync(sE.p, plE, nE, hipMemcpyHostToDevice, cs.st)); }
-    const double t0 = now_s();
-    if (int rc = trpl_solve_pl_snap_dev(dm.as<double>(), S, length_nm, time_ns, L, T, plT, tol_exp, max_iter,
-                                        dn.as<double>(), pl_direct ? pl_direct : dp.p, pl_elem_bytes,
-                                        pl_direct ? pl_ld : ncol, ds.as<int32_t>(), di.as<int64_t>(), snap_steps, n_snap,
-                                        sN.as<double>(), sP.as<double>(), sE.as<double>(), flags, cs.st))
+    const double tic = now_s();
+    if (int rc = solve_pl_dev_impl(dm.as<double>(), S, length_nm, time_ns, L, T, plT, tol_exp, max_iter,
+                                   dn.as<double>(), t0, rN.as<double>(), rP.as<double>(), rE.as<double>(),
+                                   pl_direct ? pl_direct : dp.p, pl_elem_bytes, pl_direct ? pl_ld : ncol,
+                                   ds.as<int32_t>(), di.as<int64_t>(), snap_steps, n_snap, sN.as<double>(), sP.as<double>(),
+                                   sE.as<double>(), flags, cs.st))
         return rc;
     HIP_TRY(hipStreamSynchronize(cs.st));
-    if (seconds) *seconds = now_s() - t0;                       /* pvSimPCR.py:378-381 */
+    if (seconds) *seconds = now_s() - tic;                      /* pvSimPCR.py:378-381 */
     if (!pl_direct)
         HIP_TRY(hipMemcpy2DAsync(plI, (size_t)pl_ld * pl_elem_bytes, dp.p, (size_t)ncol * pl_elem_bytes,
                                  (size_t)ncol * pl_elem_bytes, (size_t)S, hipMemcpyDeviceToHost, cs.st));
@@ -309,6 +351,30 @@ int trpl_solve_pl_snap(const double *matpar, int64_t S, double length_nm, double
     if (sE.p) HIP_TRY(hipMemcpyAsync(plE, sE.p, nE, hipMemcpyDeviceToHost, cs.st));
     HIP_TRY(hipStreamSynchronize(cs.st));        // the copies back have landed (and their errors surface here)
     return TRPL_OK;
+}
+
+int trpl_solve_pl_snap(const double *matpar, int64_t S, double length_nm, double time_ns, int32_t L, int64_t T,
+                       int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN, void *plI,
+                       int32_t pl_elem_bytes, int64_t pl_ld, int32_t *status, int64_t *iters_total,
+                       const int64_t *snap_steps, int32_t n_snap, double *plN, double *plP, double *plE,
+                       uint32_t flags, int32_t device, double *seconds)
+{
+    return solve_pl_host_impl(matpar, S, length_nm, time_ns, L, T, plT, tol_exp, max_iter, dN, 0, nullptr, nullptr, nullptr,
+                              plI, pl_elem_bytes, pl_ld, status, iters_total, snap_steps, n_snap, plN, plP, plE, flags,
+                              device, seconds);
+}
+
+int trpl_solve_pl_resume(const double *matpar, int64_t S, double length_nm, double time_ns, int32_t L, int64_t T,
+                         int32_t plT, int32_t tol_exp, int32_t max_iter, int64_t t0, const double *resN,
+                         const double *resP, const double *resE, void *plI, int32_t pl_elem_bytes, int64_t pl_ld,
+                         int32_t *status, int64_t *iters_total, const int64_t *snap_steps, int32_t n_snap, double *plN,
+                         double *plP, double *plE, uint32_t flags, int32_t device, double *seconds)
+{
+    if (!resN || !resP || !resE) return api_fail(TRPL_ERR_ARG, "resN, resP and resE must not be NULL");
+    if (t0 < 4 || t0 > T) return api_fail(TRPL_ERR_ARG, "t0=%lld must be in [4, T]: a resume needs five BDF levels", (long long)t0);
+    return solve_pl_host_impl(matpar, S, length_nm, time_ns, L, T, plT, tol_exp, max_iter, nullptr, t0, resN, resP, resE, plI,
+                              pl_elem_bytes, pl_ld, status, iters_total, snap_steps, n_snap, plN, plP, plE, flags, device,
+                              seconds);
 }
 
 int trpl_solve_pl(const double *matpar, int64_t S, double length_nm, double time_ns, int32_t L, int64_t T,

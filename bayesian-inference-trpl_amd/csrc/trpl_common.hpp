@@ -33,6 +33,11 @@ struct StepArgs {
     // state snapshots (solve mode only; pvSimPCR.py:283-288, Legacy/pvSim.py:121-126,:169-171): the state
     // at time step snap_t[i] goes to slot snap_slot[i] of snapN/snapP [C*S][snap_ld][L], snapE [..][L+1]
     double *snapN, *snapP, *snapE;
+    // resume (solve mode, the SNAP instantiation): the five newest levels U^{t0-4} .. U^{t0} of every system in
+    // SOLVER units as a TRPL_FLAG_SNAP_RAW snapshot of steps t0-4 .. t0 stores them: [C*S][5][L] / [..][5][L+1];
+    // the time loop then starts at t0 with the full BDF history
+    const double *resN, *resP, *resE;
+    int64_t t0;
     int64_t S;
     int64_t T;
     int64_t pl_ld;

@@ -199,6 +199,32 @@ def solve_pl_snap_device(matPar, Length, Time, L, T, dN, plI, snap_steps, plN=No
         None if plE is None else _chk(plE, torch.float64, "plE"), int(flags), _stream()))
 
 
+def solve_pl_resume_device(matPar, Length, Time, L, T, t0, resN, resP, resE, plI, snap_steps=(), plN=None, plP=None,
+                           plE=None, status=None, iters_total=None, tol=7, MAX=10000, plT=1, flags=0):
+    """trpl_solve_pl_resume_dev: continue at step t0 from the five raw time levels resN, resP (S, 5, L) and resE
+    (S, 5, L+1), f64 tensors as recorded by solve_pl_snap_device(..., snap_steps=[t0-4 .. t0], flags=FLAG_SNAP_RAW)."""
+    import torch
+    S = matPar.shape[0]
+    steps = np.ascontiguousarray(snap_steps, dtype=np.int64)
+    n = len(steps)
+    if matPar.shape[1] != 12 or tuple(plI.shape) != (S, T // plT + 1):
+        raise ValueError("shape mismatch")
+    for t, w in ((resN, L), (resP, L), (resE, L + 1)):
+        if tuple(t.shape) != (S, 5, w):
+            raise ValueError("resume tensors must be (S, 5, L) / (S, 5, L+1)")
+    for t, w in ((plN, L), (plP, L), (plE, L + 1)):
+        if t is not None and tuple(t.shape) != (S, n, w):
+            raise ValueError("snapshot tensors must be (S, len(snap_steps), L) / (.., L+1)")
+    _abi.check(_abi.lib().trpl_solve_pl_resume_dev(
+        _chk(matPar, torch.float64, "matPar"), S, float(Length), float(Time), int(L), int(T), int(plT), int(tol),
+        int(MAX), int(t0), _chk(resN, torch.float64, "resN"), _chk(resP, torch.float64, "resP"),
+        _chk(resE, torch.float64, "resE"), _chk(plI, plI.dtype, "plI"), plI.element_size(), plI.shape[1],
+        None if status is None else _chk(status, torch.int32, "status"),
+        None if iters_total is None else _chk(iters_total, torch.int64, "iters_total"), _abi.ptr(steps) if n else None, n,
+        None if plN is None else _chk(plN, torch.float64, "plN"), None if plP is None else _chk(plP, torch.float64, "plP"),
+        None if plE is None else _chk(plE, torch.float64, "plE"), int(flags), _stream()))
+
+
 class MultiDevice:
     """One process, several GPUs, results resident on every GPU (trpl_multi_* / trpl_loglik_multi_dev, SURVEY
     8e): contiguous sample shards, one RCCL all-gather of the per-sample likelihoods over xGMI.  The handle

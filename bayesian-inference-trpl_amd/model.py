@@ -12,7 +12,7 @@ def _as_f64(a):
 
 def solve_pl(matPar, Length, Time, L, T, dN, plT=1, tol=7, MAX=10000, out=None, dtype=np.float64,
              strict=False, device=0, fp32=False, kernel=None, mixed=False, snap_steps=None, plN=None, plP=None, plE=None,
-             snapshots=None):
+             snapshots=None, resume=None, snap_raw=False):
     """PL(t) for S systems of one curve.  matPar (S,12) and dN (L,) in nm/ns units.
     Returns (plI, status, iters_total, seconds).
 
@@ -20,14 +20,26 @@ def solve_pl(matPar, Length, Time, L, T, dN, plT=1, tol=7, MAX=10000, out=None, 
     snap_steps: time-step indices at which the state is recorded (the reference's pT after
     bayeslib.py:123); the snapshots are written into plN, plP (S, len(snap_steps), L) and plE
     (S, len(snap_steps), L+1) when given (float64, C-contiguous, filled in place like the reference's
-    plN_main / plP_main / plE_main), or returned in the dict `snapshots` (keys 'plN', 'plP', 'plE')."""
+    plN_main / plP_main / plE_main), or returned in the dict `snapshots` (keys 'plN', 'plP', 'plE').
+    snap_raw: snapshots in solver units (TRPL_FLAG_SNAP_RAW), the form a resume reads back bit for bit.
+    resume: (t0, N5, P5, E5) -- continue at step t0 >= 4 from the five newest time levels t0-4 .. t0 of every
+    system, arrays (S, 5, L), (S, 5, L), (S, 5, L+1) as recorded by snap_steps=checkpoint_steps(t0) with
+    snap_raw=True (trpl_solve_pl_resume; the reference's init_mode="continue", pvSimPCR.py:357-358); dN is
+    ignored, PL columns before t0 keep what `out` holds.  Pin `kernel` to repeat an uninterrupted run bit for bit
+    (the automatic choice looks at the number of steps left)."""
     matPar = _as_f64(matPar)
     if matPar.ndim != 2 or matPar.shape[1] != 12:
         raise ValueError("matPar must have shape (S, 12)")
-    dN = _as_f64(dN)
-    if dN.shape != (L,):
-        raise ValueError("excitation must have L=%d points, got %r" % (L, dN.shape))
     S = matPar.shape[0]
+    if resume is None:
+        dN = _as_f64(dN)
+        if dN.shape != (L,):
+            raise ValueError("excitation must have L=%d points, got %r" % (L, dN.shape))
+    else:
+        t0, rN, rP, rE = resume
+        rN, rP, rE = _as_f64(rN), _as_f64(rP), _as_f64(rE)
+        if rN.shape != (S, 5, L) or rP.shape != (S, 5, L) or rE.shape != (S, 5, L + 1):
+            raise ValueError("resume levels must have shapes (S, 5, L), (S, 5, L), (S, 5, L+1)")
     ncol = T // plT + 1
     if out is None:
         out = np.empty((S, ncol), dtype=dtype)
@@ -38,7 +50,7 @@ def solve_pl(matPar, Length, Time, L, T, dN, plT=1, tol=7, MAX=10000, out=None, 
     iters = np.zeros(S, dtype=np.int64)
     sec = _abi.C.c_double(0.0)
     flags = (_abi.FLAG_STRICT if strict else 0) | (_abi.FLAG_FP32 if fp32 else 0) | _abi.kernel_flag(kernel) \
-        | (_abi.FLAG_MIXED if mixed else 0)
+        | (_abi.FLAG_MIXED if mixed else 0) | (_abi.FLAG_SNAP_RAW if snap_raw else 0)
     steps = None
     n_snap = 0
     if snap_steps is not None and len(snap_steps):
@@ -54,15 +66,24 @@ def solve_pl(matPar, Length, Time, L, T, dN, plT=1, tol=7, MAX=10000, out=None, 
             if arr is not None and not (isinstance(arr, np.ndarray) and arr.dtype == np.float64 and arr.flags.c_contiguous
                                         and arr.shape == (S, n_snap, width)):
                 raise ValueError("%s must be a C-contiguous float64 array of shape (%d, %d, %d)" % (name, S, n_snap, width))
-    _abi.check(_abi.lib().trpl_solve_pl_snap(_abi.ptr(matPar), S, float(Length), float(Time), int(L), int(T), int(plT),
-                                             int(tol), int(MAX), _abi.ptr(dN), _abi.ptr(out), out.itemsize,
-                                             out.strides[0] // out.itemsize, _abi.ptr(status), _abi.ptr(iters),
-                                             _abi.ptr(steps), n_snap, _abi.ptr(plN) if n_snap else None,
-                                             _abi.ptr(plP) if n_snap else None, _abi.ptr(plE) if n_snap else None,
-                                             flags, int(device), _abi.C.byref(sec)))
+    head = (_abi.ptr(matPar), S, float(Length), float(Time), int(L), int(T), int(plT), int(tol), int(MAX))
+    tail = (_abi.ptr(out), out.itemsize, out.strides[0] // out.itemsize, _abi.ptr(status), _abi.ptr(iters),
+            _abi.ptr(steps), n_snap, _abi.ptr(plN) if n_snap else None, _abi.ptr(plP) if n_snap else None,
+            _abi.ptr(plE) if n_snap else None, flags, int(device), _abi.C.byref(sec))
+    if resume is None:
+        _abi.check(_abi.lib().trpl_solve_pl_snap(*head, _abi.ptr(dN), *tail))
+    else:
+        _abi.check(_abi.lib().trpl_solve_pl_resume(*head, int(t0), _abi.ptr(rN), _abi.ptr(rP), _abi.ptr(rE), *tail))
     if snapshots is not None:
         snapshots.update(plN=plN, plP=plP, plE=plE)
     return out, status, iters, sec.value
+
+
+def checkpoint_steps(t0):
+    """The five time steps whose raw snapshots (snap_raw=True) let a run be continued at step t0."""
+    if t0 < 4:
+        raise ValueError("a checkpoint needs five time levels: t0 >= 4")
+    return [int(t0) - 4 + m for m in range(5)]
 
 
 def _snapshot_target(arr, S, n, width):
@@ -75,7 +96,8 @@ def _snapshot_target(arr, S, n, width):
 def pvSim(plI_main, plN_main, plP_main, plE_main, matPar, simPar, iniPar, TPB=None, BPG=None,
           max_sims_per_block=1, init_mode="exp", strict=False, device=0, info=None):
     """pvSimPCR.pvSim (pvSimPCR.py:309).  TPB, BPG and max_sims_per_block (CUDA launch shape) are accepted
-    and ignored: one wavefront owns one system (or two).  plN_main / plP_main / plE_main, the reference's
+    and ignored: one wavefront owns one system (or two).  init_mode "continue" (a stub in the reference,
+    pvSimPCR.py:357-358) works here: iniPar = (t0, N5, P5, E5), see solve_pl(resume=...).  plN_main / plP_main / plE_main, the reference's
     debug outputs (recording hook pvSimPCR.py:283-288, disabled there; working form Legacy/pvSim.py:121-126,
     :169-171), are FILLED when they are float64 arrays of shape (S, len(pT), L) / (S, len(pT), L+1): the
     densities (nm^-3) and the field (nm^-1) of the state at the time steps pT = simPar[5]; anything else
@@ -93,9 +115,10 @@ def pvSim(plI_main, plN_main, plP_main, plE_main, matPar, simPar, iniPar, TPB=No
         dN = a * np.exp(-x / (l / dx))
     elif init_mode == "points":                              # :355-356
         dN = np.asarray(iniPar, dtype=np.float64)
+    elif init_mode == "continue":                            # :357-358 (`pass` there: the call then fails on dN)
+        dN = None
     else:
-        raise ValueError("init_mode %r is not supported (the reference's 'continue' is broken, "
-                         "pvSimPCR.py:357-362)" % (init_mode,))
+        raise ValueError("init_mode %r is not supported (pvSimPCR.py:359-362)" % (init_mode,))
     S = len(matPar)
     steps = None
     try:
@@ -110,6 +133,7 @@ def pvSim(plI_main, plN_main, plP_main, plE_main, matPar, simPar, iniPar, TPB=No
     want = any(v is not None for v in snaps.values())
     _, status, iters, sec = solve_pl(matPar, Length, Time, int(L), int(T), dN, plT=int(plT), tol=int(tol),
                                      MAX=int(MAX), out=plI_main, strict=strict, device=device,
+                                     resume=tuple(iniPar) if init_mode == "continue" else None,
                                      snap_steps=steps if want else None, **(snaps if want else {}))
     if info is not None:
         info["status"] = status

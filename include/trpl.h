@@ -68,6 +68,8 @@ extern "C" {
                                      iteration count (measured: tol_exp 7 too).  Measured on MI355X it is NOT faster than
                                      the fp64 stepper (a plain fp32 VALU instruction issues at the fp64 rate on CDNA4);
                                      it exists as the measured point of DESIGN.md section 7.  No reference exists for it */
+#define TRPL_FLAG_SNAP_RAW 0x80   /* trpl_solve_pl_snap / _resume: snapshots in SOLVER units (no division by dx^3 / dx), the
+                                     form trpl_solve_pl_resume reads back bit for bit */
 #define TRPL_FLAG_KERNEL_PAIR 0x10    /* run the two-systems-per-wavefront stepper whatever the launch size (L = 128,
                                         fp64, not STRICT -- anything else is TRPL_ERR_ARG) */
 #define TRPL_FLAG_KERNEL_SINGLE 0x20  /* run the one-system-per-wavefront stepper whatever the launch size */
@@ -142,6 +144,34 @@ int trpl_solve_pl_snap_dev(const double *matpar, int64_t S, double length_nm, do
                            void *plI, int32_t pl_elem_bytes, int64_t pl_ld, int32_t *status,
                            int64_t *iters_total, const int64_t *snap_steps /*host*/, int32_t n_snap,
                            double *plN, double *plP, double *plE, uint32_t flags, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * trpl_solve_pl_resume -- pvSim's init_mode = "continue" (pvSimPCR.py:357-358), which is only a stub in the
+ * reference (`pass`: dN is undefined and the call raises; the commented block :294-306 shows the intent: keep the
+ * last time levels in plN / plP / plE and start the next call from them).  Here: the time loop starts at step
+ * t0 >= 4 from the five newest BDF levels U^{t0-4} .. U^{t0} of every system,
+ *   resN, resP [S][5][L], resE [S][5][L+1] fp64 in SOLVER units, level m <-> step t0 - 4 + m,
+ * exactly what trpl_solve_pl_snap[_dev] stores for snap_steps = {t0-4, .., t0} under TRPL_FLAG_SNAP_RAW.
+ * A run of T steps and a run to t0 followed by a resume to T give the same PL columns, snapshots and status
+ * BIT FOR BIT, in every arithmetic mode (tested): a long window can be cut into segments, checkpointed and
+ * continued.  Iteration totals add up once the step at t0 is counted once: the time loop runs t = 0 .. T
+ * inclusive (pvSimPCR.py:237, the step taken at t = T is computed and dropped), so the run to t0 has taken the
+ * step that the resume takes again (a resume with T = t0 counts exactly that step).  PL columns before t0 / plT are not written (the caller's buffer keeps
+ * them); snapshot steps before t0 are ignored; iters_total counts the steps taken by this call.
+ * Not available with TRPL_FLAG_FP32.
+ * ------------------------------------------------------------------------------------- */
+int trpl_solve_pl_resume(const double *matpar, int64_t S, double length_nm, double time_ns, int32_t L,
+                         int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter, int64_t t0,
+                         const double *resN, const double *resP, const double *resE, void *plI,
+                         int32_t pl_elem_bytes, int64_t pl_ld, int32_t *status, int64_t *iters_total,
+                         const int64_t *snap_steps, int32_t n_snap, double *plN, double *plP, double *plE,
+                         uint32_t flags, int32_t device, double *seconds);
+int trpl_solve_pl_resume_dev(const double *matpar, int64_t S, double length_nm, double time_ns, int32_t L,
+                             int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter, int64_t t0,
+                             const double *resN, const double *resP, const double *resE, void *plI,
+                             int32_t pl_elem_bytes, int64_t pl_ld, int32_t *status, int64_t *iters_total,
+                             const int64_t *snap_steps /*host*/, int32_t n_snap, double *plN, double *plP,
+                             double *plE, uint32_t flags, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * trpl_log10_clamp -- replaces probs.fastlog(plI, MIN, TPB, BPG)  (probs.py:64-85):

@@ -1,0 +1,179 @@
+"""Checkpoint / continue (the reference's init_mode="continue", a stub at pvSimPCR.py:357-358 whose intent the
+commented block :294-306 shows): a window cut at step t0, checkpointed as five raw time levels and continued, gives
+the uninterrupted run bit for bit -- PL columns, later snapshots, status and iteration totals -- in every arithmetic
+mode; and the STRICT continuation is the ORACLE's uninterrupted run bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MODES = [dict(strict=True), dict(kernel="single"), dict(kernel="pair"), dict(mixed=True)]
+DT = 2.0 ** -5          # a power of two: a segment of t0 steps over t0 * DT ns has the window's time step exactly
+
+
+def _case(gpu, S, seed, L=128):
+    w = gpu.workloads
+    ini, lens = w.twothick(L)
+    return w.samples(S, seed=seed)[:, :12], lens[0], ini[0]
+
+
+def _split_run(gpu, X, length, Time, L, T, ini, t0, plT=1, late=(), **mode):
+    """(uninterrupted, continued): each (pl, status, iters, snapshots-at-late-steps)."""
+    S = len(X)
+    full_snaps = {}
+    full = gpu.solve_pl(X, length, Time, L, T, ini, plT=plT, snap_steps=list(late) or None,
+                        snapshots=full_snaps if late else None, **mode)
+    # segment 1: to t0, recording the five newest levels raw.  Same time step: Time * t0 / T.
+    ck = {}
+    pl_a, st_a, it_a, _ = gpu.solve_pl(X, length, Time * t0 / T, L, t0, ini, plT=plT,
+                                       snap_steps=gpu.checkpoint_steps(t0), snapshots=ck, snap_raw=True, **mode)
+    # segment 2: the caller's PL matrix carries the columns of segment 1
+    out = np.full((S, T // plT + 1), np.nan)
+    out[:, :pl_a.shape[1]] = pl_a
+    got_snaps = {}
+    pl_b, st_b, it_b, _ = gpu.solve_pl(X, length, Time, L, T, None, plT=plT, out=out,
+                                       resume=(t0, ck["plN"], ck["plP"], ck["plE"]), snap_steps=list(late) or None,
+                                       snapshots=got_snaps if late else None, **mode)
+    # the time loop runs t = 0 .. T inclusive (pvSimPCR.py:237: the step taken at t = T is computed and dropped), so
+    # segment 1 has already counted the step at t0 that the continuation takes again: count it alone and subtract
+    tail = np.full((S, t0 // plT + 1), np.nan)
+    _, _, it_c, _ = gpu.solve_pl(X, length, Time * t0 / T, L, t0, None, plT=plT, out=tail,
+                                 resume=(t0, ck["plN"], ck["plP"], ck["plE"]), **mode)
+    return (full[0], full[1], full[2], full_snaps), (pl_b, st_a, st_b, it_a + it_b - it_c, got_snaps)
+
+
+@pytest.mark.parametrize("mode", MODES, ids=lambda m: "-".join("%s=%s" % kv for kv in m.items()))
+@pytest.mark.parametrize("t0", [4, 57, 96])
+def test_continued_run_is_the_uninterrupted_run_bit_for_bit(gpu, mode, t0):
+    X, length, ini = _case(gpu, 9, seed=5)
+    T = 160
+    Time = T * DT
+    assert (Time * t0 / T) / t0 == Time / T                     # the two segments share dt exactly
+    late = (t0, t0 + 1, 130, T)
+    (pl, st, it, sn), (pl2, st_a, st_b, it2, sn2) = _split_run(gpu, X, length, Time, 128, T, ini, t0, late=late, **mode)
+    assert not st.any() and not st_a.any() and not st_b.any()
+    assert not np.isnan(pl2).any()
+    assert np.array_equal(pl, pl2)
+    assert np.array_equal(it, it2)
+    for k in ("plN", "plP", "plE"):
+        assert np.array_equal(sn[k], sn2[k]), k
+
+
+def test_strict_continuation_is_the_oracles_uninterrupted_run(gpu, oracle):
+    X, length, ini = _case(gpu, 5, seed=77)
+    T, Time, t0 = 120, 120 * DT, 48
+    want = oracle.pvsim(X, length, Time, 128, T, ini, snap_steps=[100])
+    _, (pl2, st_a, st_b, it2, sn2) = _split_run(gpu, X, length, Time, 128, T, ini, t0, late=(100,), strict=True)
+    assert np.array_equal(pl2, want["plI"]) and np.array_equal(it2, want["iters_total"])
+    for k in ("plN", "plP", "plE"):
+        assert np.array_equal(sn2[k], want[k]), k
+
+
+@pytest.mark.parametrize("mode", [dict(strict=True), dict(kernel="pair")], ids=["strict", "pair"])
+def test_continue_with_decimated_pl_and_an_odd_batch(gpu, mode):
+    """plT = 8 with t0 off the PL grid: the first column written by the continuation is the next multiple of plT;
+    columns before it keep the caller's values.  An odd batch leaves the paired kernel a half-empty wavefront."""
+    X, length, ini = _case(gpu, 11, seed=9)
+    T, Time, t0, plT = 256, 256 * DT, 99, 8
+    (pl, st, it, _), (pl2, _, st_b, it2, _) = _split_run(gpu, X, length, Time, 128, T, ini, t0, plT=plT, **mode)
+    assert np.array_equal(pl, pl2) and np.array_equal(it, it2) and not st_b.any()
+    # columns before ceil(t0 / plT) are not touched by the continuation
+    out = np.full((len(X), T // plT + 1), -3.0)
+    ck = {}
+    gpu.solve_pl(X, length, Time * t0 / T, 128, t0, ini, plT=plT, snap_steps=gpu.checkpoint_steps(t0), snapshots=ck,
+                 snap_raw=True, **mode)
+    gpu.solve_pl(X, length, Time, 128, T, None, plT=plT, out=out, resume=(t0, ck["plN"], ck["plP"], ck["plE"]), **mode)
+    first = -(-t0 // plT)
+    assert (out[:, :first] == -3.0).all() and np.array_equal(out[:, first:], pl[:, first:])
+
+
+def test_three_segments_chain_through_the_dropin_signature(gpu):
+    """pvSim(init_mode="continue"): iniPar carries the checkpoint; three segments equal one run."""
+    X, length, ini = _case(gpu, 6, seed=21)
+    L, T, Time = 128, 240, 240 * DT
+    S = len(X)
+    whole = np.empty((S, T + 1))
+    gpu.pvSim(whole, None, None, None, X, [length, Time, L, T, 1, None, 7, 10000], ini, init_mode="points")
+    plI = np.full((S, T + 1), np.nan)
+    cuts = [80, 160, T]
+    state = None
+    for i, t1 in enumerate(cuts):
+        # each call is told the FULL window (same dt) but stops at t1: the time-step count of the call is t1
+        seg = np.full((S, t1 + 1), np.nan)
+        seg[:, :0 if state is None else state[0] + 1] = plI[:, :0 if state is None else state[0] + 1]
+        ck = {}
+        steps = gpu.checkpoint_steps(t1)
+        if state is None:
+            gpu.solve_pl(X, length, Time * t1 / T, L, t1, ini, out=seg, snap_steps=steps, snapshots=ck, snap_raw=True)
+        else:
+            plN = np.zeros((S, 5, L)); plP = np.zeros((S, 5, L)); plE = np.zeros((S, 5, L + 1))
+            # raw snapshots need the flag, which the drop-in signature has no slot for: the last segment goes
+            # through pvSim, the middle one through solve_pl
+            if t1 == T:
+                gpu.pvSim(seg, None, None, None, X, [length, Time * t1 / T, L, t1, 1, None, 7, 10000], state,
+                          init_mode="continue")
+            else:
+                gpu.solve_pl(X, length, Time * t1 / T, L, t1, None, out=seg, resume=state, snap_steps=steps,
+                             plN=plN, plP=plP, plE=plE, snap_raw=True)
+                ck = dict(plN=plN, plP=plP, plE=plE)
+        plI[:, :t1 + 1] = seg
+        if ck:
+            state = (t1, ck["plN"], ck["plP"], ck["plE"])
+    assert np.array_equal(plI, whole)
+
+
+def test_device_resident_checkpoint_and_continue(gpu):
+    import torch
+    dv = gpu.device
+    X, length, ini = _case(gpu, 300, seed=3)
+    L, T, Time, t0 = 128, 96, 96 * DT, 40
+    S = len(X)
+    dev = torch.device("cuda:0")
+    tX = torch.from_numpy(X).to(dev); tini = torch.from_numpy(np.ascontiguousarray(ini)).to(dev)
+    fl = gpu.FLAG_KERNEL_PAIR
+    full = torch.empty((S, T + 1), dtype=torch.float64, device=dev)
+    it_full = torch.zeros(S, dtype=torch.int64, device=dev)
+    dv.solve_pl_snap_device(tX, length, Time, L, T, tini, full, [], iters_total=it_full, flags=fl)
+    cN = torch.zeros((S, 5, L), dtype=torch.float64, device=dev); cP = torch.zeros_like(cN)
+    cE = torch.zeros((S, 5, L + 1), dtype=torch.float64, device=dev)
+    first = torch.empty((S, t0 + 1), dtype=torch.float64, device=dev)
+    it_a = torch.zeros(S, dtype=torch.int64, device=dev); it_b = torch.zeros_like(it_a)
+    dv.solve_pl_snap_device(tX, length, Time * t0 / T, L, t0, tini, first, gpu.checkpoint_steps(t0), cN, cP, cE,
+                            iters_total=it_a, flags=fl | gpu.FLAG_SNAP_RAW)
+    out = torch.full((S, T + 1), float("nan"), dtype=torch.float64, device=dev)
+    out[:, :t0 + 1] = first
+    dv.solve_pl_resume_device(tX, length, Time, L, T, t0, cN, cP, cE, out, iters_total=it_b, flags=fl)
+    torch.cuda.synchronize()
+    it_c = torch.zeros_like(it_a)                               # the step at t0, counted by both segments
+    dv.solve_pl_resume_device(tX, length, Time * t0 / T, L, t0, t0, cN, cP, cE, first, iters_total=it_c, flags=fl)
+    torch.cuda.synchronize()
+    assert torch.equal(out, full) and torch.equal(it_a + it_b - it_c, it_full)
+
+
+def test_resume_arguments_are_validated(gpu):
+    X, length, ini = _case(gpu, 3, seed=1)
+    z = np.zeros((3, 5, 128)); ze = np.zeros((3, 5, 129))
+    with pytest.raises(gpu.TrplError, match="t0"):
+        gpu.solve_pl(X, length, 1.25, 128, 40, None, resume=(3, z, z, ze))
+    with pytest.raises(gpu.TrplError, match="t0"):
+        gpu.solve_pl(X, length, 1.25, 128, 40, None, resume=(41, z, z, ze))
+    with pytest.raises(gpu.TrplError, match="FP32"):
+        gpu.solve_pl(X, length, 1.25, 128, 40, None, resume=(8, z, z, ze), fp32=True)
+    with pytest.raises(ValueError, match="resume levels"):
+        gpu.solve_pl(X, length, 1.25, 128, 40, None, resume=(8, z[:, :4], z, ze))
+    with pytest.raises(ValueError):
+        gpu.checkpoint_steps(3)
+    lib, A = gpu._abi.lib(), gpu._abi
+    pl = np.zeros((3, 41))
+    rc = lib.trpl_solve_pl_resume(A.ptr(X), 3, float(length), 1.25, 128, 40, 1, 7, 100, 8, A.ptr(z), None, A.ptr(ze),
+                                  A.ptr(pl), 8, 41, None, None, None, 0, None, None, None, 0, 0, None)
+    assert rc == A.ERR_ARG
+    # t0 == T: the PL column of step T is (re)written from the checkpointed state and the loop's last step
+    # (computed and dropped, like the reference's t = T) is taken once
+    ck = {}
+    full = gpu.solve_pl(X, length, 1.25, 128, 40, ini, snap_steps=gpu.checkpoint_steps(40), snapshots=ck, snap_raw=True,
+                        kernel="single")
+    out = np.full((3, 41), -1.0)
+    _, st, it, _ = gpu.solve_pl(X, length, 1.25, 128, 40, None, out=out, resume=(40, ck["plN"], ck["plP"], ck["plE"]),
+                                kernel="single")
+    assert (out[:, :40] == -1.0).all() and np.array_equal(out[:, 40], full[0][:, 40]) and (it > 0).all()
