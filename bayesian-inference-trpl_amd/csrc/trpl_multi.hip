@@ -369,6 +369,8 @@ int trpl_loglik_multi_dev(trpl_multi_t *h, const double *const *X, int64_t S, in
             return api_fail(TRPL_ERR_ARG, "n_obs[%d]=%lld out of range (obs_ld %lld)", c, (long long)n_obs[c], (long long)obs_ld);
     if (S == 0) return TRPL_OK;
     const int n = h->n;
+    for (int r = 0; r < n; r++)                          // every rank receives the gathered vector, also one whose shard is empty
+        if (!P_full[r]) return api_fail(TRPL_ERR_ARG, "P_full[%d] must not be NULL", r);
     const int64_t widest = (S + n - 1) / n;
     const RcclApi *api = rccl_api();
     int prev = 0;
@@ -395,7 +397,7 @@ int trpl_loglik_multi_dev(trpl_multi_t *h, const double *const *X, int64_t S, in
             HIP_TRY(hipSetDevice(h->dev[r]));
             HIP_TRY(hipMemsetAsync(h->send[r], 0, (size_t)widest * 8, h->st[r]));       // P starts at 0; the pad stays 0
             if (nr == 0) continue;
-            if (!X[r] || !dN[r] || !obs[r] || !P_full[r] || (interp && (!obs_hi[r] || !obs_dx[r] || !obs_h[r])))
+            if (!X[r] || !dN[r] || !obs[r] || (interp && (!obs_hi[r] || !obs_dx[r] || !obs_h[r])))
                 return api_fail(TRPL_ERR_ARG, "NULL device pointer in the tables of rank %d", r);
             double *sse_r = sse ? sse[r] : nullptr;
             DevBuf tmp;                              // the fused call needs somewhere to put the per-curve sums
