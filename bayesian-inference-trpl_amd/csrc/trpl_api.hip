@@ -169,7 +169,13 @@ int launch(const trpl::StepArgs &a, uint32_t flags, hipStream_t st, int64_t step
         return TRPL_OK;
     }
     if (pick_pair_kernel(a.S * a.C, a.L, steps, flags)) {
+#ifdef TRPL_WITH_QUAD
+        // EXPERIMENT (`make QUAD=1` + TRPL_QUAD=1): four systems per wave instead of two, for same-box A/B
+        static const bool quad = getenv("TRPL_QUAD") && atoi(getenv("TRPL_QUAD"));
+        hipError_t ep = (quad && a.n_snap == 0 && !a.resN) ? trpl::launch_stepper_quad(a, st) : trpl::launch_stepper_pair(a, st);
+#else
         hipError_t ep = trpl::launch_stepper_pair(a, st);
+#endif
         if (ep != hipSuccess) return api_fail(TRPL_ERR_HIP, "pair stepper launch: %s", hipGetErrorString(ep));
         return TRPL_OK;
     }

@@ -64,6 +64,7 @@ hipError_t launch_stepper_f32(const StepArgs &a, hipStream_t stream);   // stepp
 hipError_t launch_stepper_mixed(const StepArgs &a, hipStream_t stream);  // stepper_mixed.hip, L >= 128
 // stepper_pair.hip: FAST, L = 128, two systems per wavefront
 hipError_t launch_stepper_pair(const StepArgs &a, hipStream_t stream);
+hipError_t launch_stepper_quad(const StepArgs &a, hipStream_t stream);   // stepper_quad.hip, L = 128, four systems per wave
 
 // likelihood.hip
 hipError_t launch_log10_clamp(void *x, int elem_bytes, int64_t rows, int64_t cols, int64_t ld, double mn,
