@@ -177,3 +177,54 @@ def test_resume_arguments_are_validated(gpu):
     _, st, it, _ = gpu.solve_pl(X, length, 1.25, 128, 40, None, out=out, resume=(40, ck["plN"], ck["plP"], ck["plE"]),
                                 kernel="single")
     assert (out[:, :40] == -1.0).all() and np.array_equal(out[:, 40], full[0][:, 40]) and (it > 0).all()
+
+
+def test_device_entry_points_can_be_captured_in_a_hip_graph(gpu):
+    """The _dev calls only enqueue kernels on the caller's stream (no allocation, no synchronisation): a fused
+    solve + likelihood step captured once in a HIP graph replays with new parameters in the same buffers and gives
+    the eager call's bits."""
+    import torch
+    dv, w = gpu.device, gpu.workloads
+    dev = torch.device("cuda:0")
+    L, T, S = 128, 64, 4096 + 3
+    ini, lens = w.power_scan(L)
+    C = len(lens)
+    Xa, Xb = w.samples(S, seed=11), w.samples(S, seed=12)
+    ini_d = torch.from_numpy(ini).to(dev)
+    mark = torch.from_numpy((w.MARKED_POINT * gpu.UNIT_CONVERSIONS)[None, :-1].copy()).to(dev)
+    obs = torch.empty((C, T + 1), dtype=torch.float64, device=dev)
+    for c in range(C):
+        pl = torch.empty((1, T + 1), dtype=torch.float64, device=dev)
+        dv.solve_pl_device(mark, lens[c], T * DT, L, T, ini_d[c].contiguous(), pl, flags=gpu.FLAG_STRICT)
+        obs[c] = torch.log10(pl[0])
+    X = torch.from_numpy(Xa).to(dev)
+    P = torch.zeros(S, dtype=torch.float64, device=dev)
+    sse = torch.empty((C, S), dtype=torch.float64, device=dev)
+    it = torch.zeros((C, S), dtype=torch.int64, device=dev)
+
+    def step():
+        P.zero_()
+        dv.loglik_device(X, ini_d, lens, T * DT, L, T, obs, [T + 1] * C, P, sse, iters_total=it, flags=gpu.FLAG_KERNEL_PAIR)
+
+    eager = {}
+    for name, Xh in (("a", Xa), ("b", Xb)):
+        X.copy_(torch.from_numpy(Xh))
+        step()
+        torch.cuda.synchronize()
+        eager[name] = (P.clone(), it.clone())
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        X.copy_(torch.from_numpy(Xa))
+        step()                                      # warm-up on the capture stream
+        side.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            step()
+    for name, Xh in (("b", Xb), ("a", Xa), ("b", Xb)):
+        X.copy_(torch.from_numpy(Xh))
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(P, eager[name][0]) and torch.equal(it, eager[name][1]), name
+    assert torch.isfinite(eager["a"][0]).all() and not torch.equal(eager["a"][0], eager["b"][0])
