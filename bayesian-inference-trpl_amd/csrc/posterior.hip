@@ -124,60 +124,88 @@ __global__ void __launch_bounds__(kThreads) moments1_partial(const double *V, co
         }
     }
 }
-// ---- moments pass 2, a tile of kTile parameters d per blockIdx.y (the columns are read once per tile):
-//      sum w (v_d - m_d)(v_e - m_e) for all e, and the third and fourth central sums of v_d;
-//      sums[0] = sum w, sums[2 + d] = sum w v_d from pass 1 ----
-constexpr int kTile = 4;
-__global__ void __launch_bounds__(kThreads) moments2_partial(const double *V, const double *W, int64_t S, int D,
-                                                             const double *sums, const double *mean_in, double *part)
+// ---- moments pass 2, ONE pass over the columns: sum w (v_d - m_d)(v_e - m_e) for e >= d (the matrix is symmetric:
+//      the partial of (d, e) is also stored as (e, d), the same bits) and the third and fourth central sums of
+//      every v_d;  sums[0] = sum w, sums[2 + d] = sum w v_d from pass 1.  DM >= D is the compiled size: columns
+//      D .. DM-1 are never loaded (their accumulators add zeros).  DM (DM + 1) / 2 + 2 DM fp64 accumulators per
+//      thread -- 117 at DM = 13 -- is one wave per SIMD, which a thread's 14 independent loads per sample make up
+//      for: the first version read every column once per tile of four rows (five reads of V in all). ----
+template <int DM>
+__global__ void __launch_bounds__(kThreads, 1) moments2_partial(const double *V, const double *W, int64_t S, int D,
+                                                                const double *sums, const double *mean_in, double *part)
 {
     __shared__ double sm[kThreads / 64];
-    const int d0 = blockIdx.y * kTile;
     const double sw = sums[0];
-    double mean[kMaxDim];
+    double mean[DM];
 #pragma unroll
-    for (int e = 0; e < kMaxDim; e++) mean[e] = e < D ? (mean_in ? mean_in[e] : sums[2 + e] / sw) : 0.0;      // np.average
-    double c[kTile][kMaxDim], m3[kTile], m4[kTile];
+    for (int e = 0; e < DM; e++) mean[e] = e < D ? (mean_in ? mean_in[e] : sums[2 + e] / sw) : 0.0;      // np.average
+    double c[DM * (DM + 1) / 2], m3[DM], m4[DM];
 #pragma unroll
-    for (int t = 0; t < kTile; t++) {
-        m3[t] = 0.0; m4[t] = 0.0;
+    for (int k = 0; k < DM * (DM + 1) / 2; k++) c[k] = 0.0;
 #pragma unroll
-        for (int e = 0; e < kMaxDim; e++) c[t][e] = 0.0;
-    }
-    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < S; i += (int64_t)gridDim.x * kThreads) {
-        const double w = W[i];
-        double xc[kMaxDim];
+    for (int d = 0; d < DM; d++) { m3[d] = 0.0; m4[d] = 0.0; }
+    // the loads of the next kAhead samples (1 + D each) are in flight while the current sample's ~3 DM^2 / 2
+    // operations run: with one wave per SIMD nothing else hides the HBM latency (no prefetch 1.8 ms, one sample
+    // ahead 0.8 ms at S = 16.7 M, D = 13)
+    constexpr int kAhead = DM <= 8 ? 1 : 2;
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    double w[kAhead + 1], x[kAhead + 1][DM];
+    auto fetch = [&](int64_t idx, int slot) {
+        w[slot] = 0.0;
 #pragma unroll
-        for (int e = 0; e < kMaxDim; e++) xc[e] = e < D ? V[(int64_t)e * S + i] - mean[e] : 0.0;
+        for (int e = 0; e < DM; e++) x[slot][e] = 0.0;
+        if (idx < S) {
+            w[slot] = W[idx];
 #pragma unroll
-        for (int t = 0; t < kTile; t++) {
-            double xd = 0.0;
+            for (int e = 0; e < DM; e++) if (e < D) x[slot][e] = V[(int64_t)e * S + idx];
+        }
+    };
 #pragma unroll
-            for (int e = 0; e < kMaxDim; e++) xd = e == d0 + t ? xc[e] : xd;
+    for (int q = 0; q < kAhead; q++) fetch(i + q * stride, q);
+    for (; i < S; i += stride) {
+        fetch(i + kAhead * stride, kAhead);
+        double xc[DM];
 #pragma unroll
-            for (int e = 0; e < kMaxDim; e++)
-                if (e < D) c[t][e] += (xd * xc[e]) * w;
+        for (int e = 0; e < DM; e++) xc[e] = e < D ? x[0][e] - mean[e] : 0.0;
+        const double w0 = w[0];
+        int k = 0;
+#pragma unroll
+        for (int d = 0; d < DM; d++) {
+            const double xd = xc[d];
+#pragma unroll
+            for (int e = d; e < DM; e++) c[k++] += (xd * xc[e]) * w0;
             const double x2 = xd * xd;
-            m3[t] += (x2 * xd) * w;
-            m4[t] += (x2 * x2) * w;
+            m3[d] += (x2 * xd) * w0;
+            m4[d] += (x2 * x2) * w0;
+        }
+#pragma unroll
+        for (int q = 0; q < kAhead; q++) {
+            w[q] = w[q + 1];
+#pragma unroll
+            for (int e = 0; e < DM; e++) x[q][e] = x[q + 1][e];
         }
     }
+    // part is [D][gridDim.x][D + 2]
+    int k = 0;
 #pragma unroll
-    for (int t = 0; t < kTile; t++) {
-        const int d = d0 + t;
-        if (d >= D) break;                                       // wave-uniform
-        double *row = part + ((int64_t)d * gridDim.x + blockIdx.x) * (D + 2);
+    for (int d = 0; d < DM; d++) {
 #pragma unroll
-        for (int e = 0; e < kMaxDim; e++) {
-            if (e < D) {
-                const double r = block_reduce<false>(c[t][e], sm);
-                if (threadIdx.x == 0) row[e] = r;
+        for (int e = d; e < DM; e++, k++) {
+            if (e < D) {                                             // wave-uniform (d <= e < D)
+                const double r = block_reduce<false>(c[k], sm);
+                if (threadIdx.x == 0) {
+                    part[((int64_t)d * gridDim.x + blockIdx.x) * (D + 2) + e] = r;
+                    part[((int64_t)e * gridDim.x + blockIdx.x) * (D + 2) + d] = r;
+                }
             }
         }
-        double r = block_reduce<false>(m3[t], sm);
-        if (threadIdx.x == 0) row[D] = r;
-        r = block_reduce<false>(m4[t], sm);
-        if (threadIdx.x == 0) row[D + 1] = r;
+        if (d < D) {
+            double r = block_reduce<false>(m3[d], sm);
+            if (threadIdx.x == 0) part[((int64_t)d * gridDim.x + blockIdx.x) * (D + 2) + D] = r;
+            r = block_reduce<false>(m4[d], sm);
+            if (threadIdx.x == 0) part[((int64_t)d * gridDim.x + blockIdx.x) * (D + 2) + D + 1] = r;
+        }
     }
 }
 
@@ -288,7 +316,10 @@ hipError_t launch_posterior_moments(const double *V, const double *W, int64_t S,
     const int nb = grid_for(S);
     hipLaunchKernelGGL(moments1_partial, dim3(nb), dim3(kThreads), 0, st, V, W, S, D, ws);
     hipLaunchKernelGGL(final_reduce, dim3(2 + D, 1), dim3(kThreads), 0, st, ws, nb, 2 + D, false, sums);
-    hipLaunchKernelGGL(moments2_partial, dim3(nb, (D + kTile - 1) / kTile), dim3(kThreads), 0, st, V, W, S, D, sums, mean_in, ws);
+    if (D <= 4)       hipLaunchKernelGGL(moments2_partial<4>, dim3(nb), dim3(kThreads), 0, st, V, W, S, D, sums, mean_in, ws);
+    else if (D <= 8)  hipLaunchKernelGGL(moments2_partial<8>, dim3(nb), dim3(kThreads), 0, st, V, W, S, D, sums, mean_in, ws);
+    else if (D <= 13) hipLaunchKernelGGL(moments2_partial<13>, dim3(nb), dim3(kThreads), 0, st, V, W, S, D, sums, mean_in, ws);
+    else              hipLaunchKernelGGL(moments2_partial<16>, dim3(nb), dim3(kThreads), 0, st, V, W, S, D, sums, mean_in, ws);
     hipLaunchKernelGGL(final_reduce, dim3(D + 2, D), dim3(kThreads), 0, st, ws, nb, D + 2, false, central);
     return hipGetLastError();
 }

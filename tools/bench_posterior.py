@@ -33,6 +33,6 @@ def timed(name, fn, nbytes, reps=10):
 
 print(f"S = {S}, D = {D}")
 timed("weights (2 reads + write + rescale)", lambda: tdev.posterior_weights_device(LL, 4e3, W, ws), 5 * 8 * S)
-timed("moments (means + 13x13 covariance)", lambda: tdev.posterior_moments_device(V, W, sums, central, ws), (D + 1) * 8 * S * (1 + (D + 3) // 4))
+timed("moments (means + 13x13 covariance)", lambda: tdev.posterior_moments_device(V, W, sums, central, ws), (D + 1) * 8 * S * 2)         # two passes (means, then centred sums), every column read once in each
 timed("hist 1-D, 64 bins", lambda: tdev.posterior_hist_device(V[0], W, -4, 4, h1), 2 * 8 * S)
 timed("hist 2-D, 64 x 64 bins", lambda: tdev.posterior_hist_device(V[0], W, -4, 4, h2, y=V[1], ylo=-4, yhi=4), 3 * 8 * S)
