@@ -228,3 +228,23 @@ def test_device_entry_points_can_be_captured_in_a_hip_graph(gpu):
         torch.cuda.synchronize()
         assert torch.equal(P, eager[name][0]) and torch.equal(it, eager[name][1]), name
     assert torch.isfinite(eager["a"][0]).all() and not torch.equal(eager["a"][0], eager["b"][0])
+
+
+def test_continue_into_a_large_host_buffer_written_in_place(gpu):
+    """A PL matrix above the direct-write threshold (8 MiB) is written by the kernel straight into the caller's mapped
+    buffer: the continuation fills the columns from t0 on and leaves the earlier ones exactly as the caller had them."""
+    X, length, ini = _case(gpu, 1100, seed=13)
+    T, t0 = 1000, 420
+    Time = T * DT
+    assert 1100 * (T + 1) * 8 > 8 << 20
+    full, st, it, _ = gpu.solve_pl(X, length, Time, 128, T, ini, kernel="pair")
+    ck = {}
+    first, *_ = gpu.solve_pl(X, length, t0 * DT, 128, t0, ini, kernel="pair", snap_steps=gpu.checkpoint_steps(t0),
+                             snapshots=ck, snap_raw=True)
+    out = np.full((1100, T + 1), -7.0)
+    out[:, :t0 + 1] = first
+    gpu.solve_pl(X, length, Time, 128, T, None, out=out, kernel="pair", resume=(t0, ck["plN"], ck["plP"], ck["plE"]))
+    assert np.array_equal(out, full) and not st.any()
+    marker = np.full((1100, T + 1), -7.0)
+    gpu.solve_pl(X, length, Time, 128, T, None, out=marker, kernel="pair", resume=(t0, ck["plN"], ck["plP"], ck["plE"]))
+    assert (marker[:, :t0] == -7.0).all() and np.array_equal(marker[:, t0:], full[:, t0:])
