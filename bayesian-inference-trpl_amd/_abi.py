@@ -16,6 +16,15 @@ LIB_PATH = os.environ.get("TRPL_LIBRARY", os.path.join(_HERE, "libtrpl_hip.so"))
 OK, ERR_ARG, ERR_HIP, ERR_NODEVICE, ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 FLAG_STRICT, FLAG_PL_F32, FLAG_NORMALIZE, FLAG_FP32 = 0x1, 0x2, 0x4, 0x8
 FLAG_KERNEL_PAIR, FLAG_KERNEL_SINGLE, FLAG_MIXED, FLAG_SNAP_RAW = 0x10, 0x20, 0x40, 0x80
+MAX_BUNDLE = 4
+
+
+def flag_bundle(m):
+    """TRPL_FLAG_BUNDLE(m): the reference's max_sims_per_block (STRICT only)."""
+    if not 1 <= int(m) <= MAX_BUNDLE:
+        raise ValueError("max_sims_per_block must be in [1, %d]" % MAX_BUNDLE)
+    return ((int(m) - 1) & 0xF) << 8
+
 KERNEL_FAST, KERNEL_FAST_PAIR, KERNEL_STRICT, KERNEL_FP32, KERNEL_MIXED = 0, 1, 2, 3, 4
 ABI_VERSION = 2
 MAX_SNAPS = 16

@@ -101,6 +101,25 @@ __device__ __forceinline__ bool residual_below(const double (&l)[NR], const doub
     }
 }
 
+// STRICT, bundled systems (max_sims_per_block > 1): the quotient itself, because shared_array_max (pvSimPCR.py:83-90)
+// treats a NaN differently in the first system of a bundle (it sticks) and in the others (`>` skips it)
+template <int NR, int W>
+__device__ __forceinline__ double residual_err_strict(const double (&l)[NR], const double (&dg)[NR], const double (&u)[NR],
+                                                      const double (&b)[NR], const double (&c)[NR], int ln)
+{
+    double cm[NR], cp[NR], r[NR], ab[NR];
+    shift_dn1<0, NR, W>(c, cm, ln);
+    shift_up1<0, NR, W>(c, cp, ln);
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        r[j] = fabs(l[j] * cm[j] + dg[j] * c[j] + u[j] * cp[j] - b[j]);      // the reference's order
+        ab[j] = fabs(b[j]);
+    }
+    const double sr = sum_nodes<0, NR, W>(r);
+    const double sb = sum_nodes<0, NR, W>(ab);
+    return sr / sb;
+}
+
 
 // MIXED arithmetic (TRPL_FLAG_MIXED): the same test as residual_below<2> and, beside it, the residual itself,
 // r = b - A c in fp64 -- the right-hand side of the correction equation A delta = r that is then solved in fp32.
@@ -160,8 +179,10 @@ struct PlSink {
     double pend = 0.0;
     int64_t base = 0;
 
-    __device__ PlSink(const StepArgs &a_, const CurveConst &cc_, int c, int64_t s, double mag_)
-        : a(a_), cc(cc_), orow((int64_t)c * a_.S + s), mag(mag_)
+    int lane_;               // lane within the wavefront (== threadIdx.x except in the multi-wave bundled kernel)
+
+    __device__ PlSink(const StepArgs &a_, const CurveConst &cc_, int c, int64_t s, double mag_, int lane = (int)threadIdx.x)
+        : a(a_), cc(cc_), orow((int64_t)c * a_.S + s), mag(mag_), lane_(lane)
     {
         want_pl = a.pl != nullptr;
         want_ll = a.sse != nullptr;
@@ -176,11 +197,14 @@ struct PlSink {
         t_last = want_pl ? a.T : (interp ? (int64_t)obs_hi[ncol_ll - 1] : (ncol_ll - 1) * a.plT);
     }
 
+    // a spare wavefront of a short bundle: computes, emits nothing (t_last stays the workgroup's)
+    __device__ void mute() { want_pl = false; want_ll = false; interp = false; ncol_ll = 0; }
+
     // plv = rate * (sum N P - L n0 p0) of the state at time t = col * plT, non-dimensional.  The steppers count
     // PL columns instead of dividing t by plT every step (a 64-bit scalar division is ~130 instructions).
     __device__ __forceinline__ void emit(int64_t col, double plv)
     {
-        if (want_pl && threadIdx.x == 0) {                                             // :281,:393
+        if (want_pl && lane_ == 0) {                                                   // :281,:393
             if (a.pl_bytes == 4) ((float *)a.pl)[orow * a.pl_ld + col] = (float)plv / (float)cc.plnorm;
             else                 ((double *)a.pl)[orow * a.pl_ld + col] = plv / cc.plnorm;
         }
@@ -270,7 +294,7 @@ struct PlSink {
     // status = 0, or 1+t of the step whose iteration hit MAX (pvSimPCR.py:269)
     __device__ __forceinline__ void finish(int status, int64_t itot)
     {
-        if (threadIdx.x != 0) return;
+        if (lane_ != 0) return;
         if (status && want_pl) {                   // undefined in the reference; NaN here
             for (int64_t tt = status - 1; tt <= a.T; tt++)
                 if (tt % a.plT == 0) {
@@ -513,17 +537,27 @@ __device__ __forceinline__ void update_field(const MatPar &m, double a0, const d
     }
 }
 
-template <int L, bool STRICT, bool SNAP = false, bool MIXED = false>
-__global__ void __launch_bounds__(64, (STRICT || L > 128) ? (L > 256 ? 1 : 2) : TRPL_FAST_WAVES) stepper_kernel(const StepArgs a)
+// BUNDLE (STRICT only): the reference's max_sims_per_block > 1 -- a.bundle consecutive samples of a curve share ONE
+// convergence test per inner iteration (pvSimPCR.py:211-216,:258-266).  One workgroup = one bundle, one wavefront per
+// system, the per-system verdicts exchanged through LDS with one barrier per iteration.
+template <int L, bool STRICT, bool SNAP = false, bool MIXED = false, bool BUNDLE = false>
+__global__ void __launch_bounds__(BUNDLE ? 64 * kMaxBundle : 64, BUNDLE ? 1 : ((STRICT || L > 128) ? (L > 256 ? 1 : 2) : TRPL_FAST_WAVES))
+stepper_kernel(const StepArgs a)
 {
     constexpr int W = L < 64 ? L : 64;
     constexpr int NR = L / W;
     constexpr int LAY = STRICT ? 0 : (L >= 128 ? 2 : 1);   // node layout / arithmetic flavour
     static_assert(!MIXED || LAY == 2, "the mixed-precision correction exists for the interleaved layout (L >= 128)");
-    const int ln = threadIdx.x & (W - 1);          // lanes >= W replicate lane (lane mod W)
+    static_assert(!BUNDLE || STRICT, "bundled convergence exists to reproduce the reference bit for bit: STRICT only");
+    const int wv = BUNDLE ? (int)(threadIdx.x >> 6) : 0;                 // which system of the bundle
+    const int lane64 = BUNDLE ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+    const int ln = lane64 & (W - 1);               // lanes >= W replicate lane (lane mod W)
     const int64_t sys = blockIdx.x;
     const int c = (int)(sys % a.C);
-    const int64_t s = sys / a.C;
+    // a short last bundle: its spare wavefronts recompute the bundle's first system, store nothing and always agree
+    const int64_t s_first = BUNDLE ? (sys / a.C) * a.bundle : sys / a.C;
+    const bool valid = !BUNDLE || s_first + wv < a.S;
+    const int64_t s = valid ? s_first + wv : s_first;
     const CurveConst &cc = a.curve[c];
 
     // ---- non-dimensional material parameters (pvSimPCR.py:327-331) ----
@@ -569,10 +603,12 @@ __global__ void __launch_bounds__(64, (STRICT || L > 128) ? (L > 256 ? 1 : 2) : 
         }
     }
 
-    PlSink sink(a, cc, c, s, mag);
+    PlSink sink(a, cc, c, s, mag, lane64);
+    if constexpr (BUNDLE) { if (!valid) sink.mute(); }
     SnapSink snap(a, cc);
     int status = 0;
     int64_t itot = 0;
+    __shared__ int agree[2][BUNDLE ? kMaxBundle : 1];     // BUNDLE: the systems' verdicts, double-buffered by iteration parity
 
     int64_t t_begin = 0;
     if constexpr (SNAP) {
@@ -603,7 +639,7 @@ __global__ void __launch_bounds__(64, (STRICT || L > 128) ? (L > 256 ? 1 : 2) : 
     for (int64_t t = t_begin; t <= sink.t_last; t++) {   // tEvol, pvSimPCR.py:237
         if constexpr (SNAP) {                      // the state at time t, before it is stepped (:283-288)
             if (snap.due(t))
-                snap.template take<NR, L>(Nk, Pk, Ek, sink.orow, (int)threadIdx.x < W,
+                snap.template take<NR, L>(Nk, Pk, Ek, sink.orow, valid && lane64 < W,
                                           [&](int j) { return node_of<LAY, NR, W>(ln, j); });
         }
         double a0, a1, a2, a3, a4, a5;             // :241-250
@@ -674,6 +710,10 @@ __global__ void __launch_bounds__(64, (STRICT || L > 128) ? (L > 256 ? 1 : 2) : 
             assemble<LAY, true, NR, W, L>(mp, a0, Nk, Pk, Ek, Ep, bN, lo_, dg, up, bb, ln);
             if constexpr (MIXED) {
                 okN = correct_mixed<NR>(lo_, dg, up, bb, Nk, TOL, ln, (float *)xch);
+            } else if constexpr (BUNDLE) {         // shared_array_max: a NaN sticks in the first system, is skipped in the others
+                const double e = residual_err_strict<NR, W>(lo_, dg, up, bb, Nk, ln);
+                okN = wv == 0 ? e < TOL : !(e >= TOL);
+                solve_lay<LAY, NR, W, L>(lo_, dg, up, bb, Nk, ln, xch);
             } else {
                 okN = residual_below<LAY, NR, W>(lo_, dg, up, bb, Nk, TOL, ln);                    // :172
                 solve_lay<LAY, NR, W, L>(lo_, dg, up, bb, Nk, ln, xch);                                 // :175
@@ -685,12 +725,28 @@ __global__ void __launch_bounds__(64, (STRICT || L > 128) ? (L > 256 ? 1 : 2) : 
             } else {
                 // the holes' norm decides nothing unless the electrons' has passed (:213): skipped otherwise (a
                 // wave-uniform branch; on the first iteration of a time step it practically always is)
-                okP = okN ? residual_below<LAY, NR, W>(lo_, dg, up, bb, Pk, TOL, ln) : false;       // :200
+                if constexpr (BUNDLE) {
+                    okP = false;
+                    if (okN) {
+                        const double e = residual_err_strict<NR, W>(lo_, dg, up, bb, Pk, ln);
+                        okP = wv == 0 ? e < TOL : !(e >= TOL);
+                    }
+                } else {
+                    okP = okN ? residual_below<LAY, NR, W>(lo_, dg, up, bb, Pk, TOL, ln) : false;   // :200
+                }
                 solve_lay<LAY, NR, W, L>(lo_, dg, up, bb, Pk, ln, xch);                                 // :202
             }
             // ---- field on edges 1..L-1 (:205-209) ----
             update_field<LAY, NR, W>(mp, a0, Nk, Pk, bE, Ek, ln);
-            if (okN && okP) { it = iters + 1; break; }                                             // :213-216
+            if constexpr (BUNDLE) {                // max over the bundle of errN and errP below TOL (:211-216)
+                if (lane64 == 0) agree[iters & 1][wv] = !valid || (okN && okP);
+                __syncthreads();
+                bool all = true;
+                for (int q = 0; q < a.bundle; q++) all = all && agree[iters & 1][q] != 0;
+                if (all) { it = iters + 1; break; }
+            } else {
+                if (okN && okP) { it = iters + 1; break; }                                         // :213-216
+            }
         }
         itot += it;
         if (it >= MAX) { status = 1 + (int)t; break; }                                     // :269-274
@@ -719,9 +775,9 @@ __global__ void __launch_bounds__(64, (STRICT || L > 128) ? (L > 256 ? 1 : 2) : 
         sink.flush_batch((int)((done + a.plT - 1) / a.plT - sink.base));
     }
     if constexpr (SNAP) {
-        if (status) snap.template fail_fill<L>(sink.orow, status, threadIdx.x, 64);
+        if (status && valid) snap.template fail_fill<L>(sink.orow, status, lane64, 64);
     }
-    sink.finish(status, itot);
+    if (valid) sink.finish(status, itot);
 }
 
 template <bool STRICT>
@@ -733,6 +789,25 @@ hipError_t launch_stepper(const StepArgs &a, hipStream_t stream)
     // development knob: extra dynamic LDS per workgroup lowers the number of resident waves
     static const unsigned lds_pad = getenv("TRPL_LDS_PAD") ? (unsigned)atoi(getenv("TRPL_LDS_PAD")) : 0u;
     const bool snap = a.n_snap > 0 || a.resN != nullptr;   // snapshot / resume code only exists in its own instantiation
+    if constexpr (STRICT) {
+        if (a.bundle > 1) {                        // one workgroup per bundle of a.bundle consecutive samples of a curve
+            if (a.bundle > kMaxBundle) return hipErrorInvalidValue;
+            grid = dim3((unsigned)(((a.S + a.bundle - 1) / a.bundle) * a.C));
+            block = dim3(64 * a.bundle);
+            switch (a.L) {
+#define TRPL_CASE(LL) \
+    case LL: \
+        if (snap) hipLaunchKernelGGL((stepper_kernel<LL, true, true, false, true>), grid, block, 0, stream, a); \
+        else      hipLaunchKernelGGL((stepper_kernel<LL, true, false, false, true>), grid, block, 0, stream, a); \
+        break;
+                TRPL_CASE(4) TRPL_CASE(8) TRPL_CASE(16) TRPL_CASE(32) TRPL_CASE(64) TRPL_CASE(128)
+                TRPL_CASE(256) TRPL_CASE(512)
+#undef TRPL_CASE
+            default: return hipErrorInvalidValue;
+            }
+            return hipGetLastError();
+        }
+    }
     switch (a.L) {
 #define TRPL_CASE(LL) \
     case LL: \

@@ -150,9 +150,14 @@ using namespace trpl;
 namespace {
 
 // steps: how many time steps the launch will take (T, or up to the last observation in likelihood mode)
-int launch(const trpl::StepArgs &a, uint32_t flags, hipStream_t st, int64_t steps)
+int launch(const trpl::StepArgs &a_in, uint32_t flags, hipStream_t st, int64_t steps)
 {
-    if (int rc = check_variant_flags(flags, a.L)) return rc;
+    if (int rc = check_variant_flags(flags, a_in.L)) return rc;
+    trpl::StepArgs a = a_in;
+    a.bundle = (int32_t)((flags >> 8) & 0xF) + 1;             // TRPL_FLAG_BUNDLE(m)
+    if (a.bundle > 1 && !(flags & TRPL_FLAG_STRICT))
+        return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_BUNDLE needs TRPL_FLAG_STRICT: only the bit-reproducible mode couples the convergence of neighbouring samples");
+    if (a.bundle > trpl::kMaxBundle) return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_BUNDLE(%d): at most %d systems per bundle", a.bundle, trpl::kMaxBundle);
     if (flags & TRPL_FLAG_FP32) {
         if (flags & (TRPL_FLAG_STRICT | TRPL_FLAG_MIXED)) return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_FP32 excludes TRPL_FLAG_STRICT and TRPL_FLAG_MIXED");
         if (a.L < 128) return api_fail(TRPL_ERR_UNSUPPORTED, "the fp32 stepper is built for L >= 128 (got %d)", a.L);

@@ -7,6 +7,8 @@ namespace trpl {
 
 constexpr int kMaxCurves = 16;
 constexpr int kMaxSnaps = 16;      // state snapshots per solve (trpl_solve_pl_snap)
+constexpr int kMaxBundle = 4;      // systems sharing one convergence test (TRPL_FLAG_BUNDLE), one wavefront each in one workgroup
+                                   // (the reference's 48 KB of shared memory hold 3 systems at L = 128, pvSimPCR.py:113-125)
 
 // Per-curve constants, computed on the host exactly as pvSim does (pvSimPCR.py:314-331,
 // :393) so that the in-kernel products X[s][i] * scales[i] round like numpy's.
@@ -50,6 +52,7 @@ struct StepArgs {
     int32_t MAX;
     int32_t pl_bytes;       // 4 or 8
     uint32_t flags;         // TRPL_FLAG_*
+    int32_t bundle;         // STRICT: the reference's max_sims_per_block, 1 .. kMaxBundle (1: every system converges alone)
     int32_t n_snap;         // number of (step, slot) pairs below, steps strictly ascending
     int32_t snap_ld;        // slots per system in the snapshot arrays
     int32_t snap_t[kMaxSnaps];

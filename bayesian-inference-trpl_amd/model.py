@@ -12,7 +12,7 @@ def _as_f64(a):
 
 def solve_pl(matPar, Length, Time, L, T, dN, plT=1, tol=7, MAX=10000, out=None, dtype=np.float64,
              strict=False, device=0, fp32=False, kernel=None, mixed=False, snap_steps=None, plN=None, plP=None, plE=None,
-             snapshots=None, resume=None, snap_raw=False):
+             snapshots=None, resume=None, snap_raw=False, bundle=1):
     """PL(t) for S systems of one curve.  matPar (S,12) and dN (L,) in nm/ns units.
     Returns (plI, status, iters_total, seconds).
 
@@ -26,7 +26,9 @@ def solve_pl(matPar, Length, Time, L, T, dN, plT=1, tol=7, MAX=10000, out=None, 
     system, arrays (S, 5, L), (S, 5, L), (S, 5, L+1) as recorded by snap_steps=checkpoint_steps(t0) with
     snap_raw=True (trpl_solve_pl_resume; the reference's init_mode="continue", pvSimPCR.py:357-358); dN is
     ignored, PL columns before t0 keep what `out` holds.  Pin `kernel` to repeat an uninterrupted run bit for bit
-    (the automatic choice looks at the number of steps left)."""
+    (the automatic choice looks at the number of steps left).
+    bundle: the reference's max_sims_per_block (strict=True only, TRPL_FLAG_BUNDLE): `bundle` consecutive samples share
+    one convergence test per inner iteration (pvSimPCR.py:211-216), bit-identical to the reference run that way."""
     matPar = _as_f64(matPar)
     if matPar.ndim != 2 or matPar.shape[1] != 12:
         raise ValueError("matPar must have shape (S, 12)")
@@ -50,7 +52,7 @@ def solve_pl(matPar, Length, Time, L, T, dN, plT=1, tol=7, MAX=10000, out=None, 
     iters = np.zeros(S, dtype=np.int64)
     sec = _abi.C.c_double(0.0)
     flags = (_abi.FLAG_STRICT if strict else 0) | (_abi.FLAG_FP32 if fp32 else 0) | _abi.kernel_flag(kernel) \
-        | (_abi.FLAG_MIXED if mixed else 0) | (_abi.FLAG_SNAP_RAW if snap_raw else 0)
+        | (_abi.FLAG_MIXED if mixed else 0) | (_abi.FLAG_SNAP_RAW if snap_raw else 0) | _abi.flag_bundle(bundle)
     steps = None
     n_snap = 0
     if snap_steps is not None and len(snap_steps):
@@ -95,8 +97,9 @@ def _snapshot_target(arr, S, n, width):
 
 def pvSim(plI_main, plN_main, plP_main, plE_main, matPar, simPar, iniPar, TPB=None, BPG=None,
           max_sims_per_block=1, init_mode="exp", strict=False, device=0, info=None):
-    """pvSimPCR.pvSim (pvSimPCR.py:309).  TPB, BPG and max_sims_per_block (CUDA launch shape) are accepted
-    and ignored: one wavefront owns one system (or two).  init_mode "continue" (a stub in the reference,
+    """pvSimPCR.pvSim (pvSimPCR.py:309).  TPB and BPG (CUDA launch shape) are accepted and ignored: one wavefront owns
+    one system (or two).  max_sims_per_block > 1 -- neighbouring samples sharing one convergence test -- is reproduced
+    bit for bit with strict=True (up to 4) and has no effect otherwise (see below).  init_mode "continue" (a stub in the reference,
     pvSimPCR.py:357-358) works here: iniPar = (t0, N5, P5, E5), see solve_pl(resume=...).  plN_main / plP_main / plE_main, the reference's
     debug outputs (recording hook pvSimPCR.py:283-288, disabled there; working form Legacy/pvSim.py:121-126,
     :169-171), are FILLED when they are float64 arrays of shape (S, len(pT), L) / (S, len(pT), L+1): the
@@ -104,10 +107,10 @@ def pvSim(plI_main, plN_main, plP_main, plE_main, matPar, simPar, iniPar, TPB=No
     (None, the dummies bayeslib passes) is ignored as before.  `info`, if a dict, receives 'status' and
     'iters_total'."""
     Length, Time, L, T, plT, pT, tol, MAX = simPar
-    if max_sims_per_block != 1:
-        # bundling couples the convergence of unrelated samples in the reference
-        # (pvSimPCR.py:213-216); the per-system result is the MSPB = 1 one
-        pass
+    # max_sims_per_block > 1 couples the convergence of neighbouring samples in the reference (pvSimPCR.py:213-216).
+    # strict=True reproduces that bit for bit (up to 4 per bundle); the FAST modes keep every sample independent of
+    # its neighbours -- the result is then the max_sims_per_block = 1 one, within the solver tolerance of the other
+    bundle = int(max_sims_per_block) if strict else 1
     dx = Length / L
     if init_mode == "exp":                                   # pvSimPCR.py:347-353
         a, l = iniPar
@@ -133,7 +136,7 @@ def pvSim(plI_main, plN_main, plP_main, plE_main, matPar, simPar, iniPar, TPB=No
     want = any(v is not None for v in snaps.values())
     _, status, iters, sec = solve_pl(matPar, Length, Time, int(L), int(T), dN, plT=int(plT), tol=int(tol),
                                      MAX=int(MAX), out=plI_main, strict=strict, device=device,
-                                     resume=tuple(iniPar) if init_mode == "continue" else None,
+                                     resume=tuple(iniPar) if init_mode == "continue" else None, bundle=bundle,
                                      snap_steps=steps if want else None, **(snaps if want else {}))
     if info is not None:
         info["status"] = status

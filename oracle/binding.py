@@ -38,6 +38,8 @@ class OracleLib:
         d.oracle_pvsim_snap.argtypes = d.oracle_pvsim.argtypes[:-1] + [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                                       C.c_void_p, C.c_int]
         d.oracle_pvsim_snap.restype = C.c_int
+        d.oracle_pvsim_bundle.argtypes = d.oracle_pvsim.argtypes[:-1] + [C.c_int, C.c_int]
+        d.oracle_pvsim_bundle.restype = C.c_int
         d.oracle_fastlog.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_long, C.c_long, C.c_double]
         d.oracle_fastlog.restype = None
         d.oracle_prob.argtypes = [_dp, C.c_void_p, C.c_int, C.c_long, C.c_long, C.c_long, _dp, _dp]
@@ -91,9 +93,10 @@ def scales(length, time_ns, L, T):
 
 
 def pvsim(mat12, length, time_ns, L, T, ini, plT=1, tol=7, MAX=10000, dtype=np.float64, nthreads=1,
-          want_step_iters=False, snap_steps=None):
+          want_step_iters=False, snap_steps=None, mspb=1):
     """pvSim(..., init_mode="points") semantics.  Returns dict(plI, status, iters_total, iters_max[, step_iters]
-    [, plN, plP, plE: the state at the time steps snap_steps, pvSimPCR.py:283-288 / Legacy/pvSim.py:121-126])."""
+    [, plN, plP, plE: the state at the time steps snap_steps, pvSimPCR.py:283-288 / Legacy/pvSim.py:121-126]).
+    mspb > 1: max_sims_per_block consecutive samples share one convergence test (pvSimPCR.py:213-216,:258-266)."""
     mat12 = _f64(mat12)
     S = mat12.shape[0]
     assert mat12.shape[1] == 12
@@ -105,6 +108,17 @@ def pvsim(mat12, length, time_ns, L, T, ini, plT=1, tol=7, MAX=10000, dtype=np.f
     itot = np.zeros(S, dtype=np.int64)
     imax = np.zeros(S, dtype=np.int32)
     steps = np.zeros((S, T + 1), dtype=np.int32) if want_step_iters else None
+    if mspb != 1:
+        assert snap_steps is None, "the bundled oracle records no snapshots"
+        rc = load().dll.oracle_pvsim_bundle(_ptr(mat12, _dp), S, float(length), float(time_ns), int(L), int(T), int(plT),
+                                            int(tol), int(MAX), _ptr(ini, _dp), _ptr(pl), pl.dtype.itemsize, ncol,
+                                            _ptr(status), _ptr(itot), _ptr(imax), _ptr(steps), int(mspb), int(nthreads))
+        if rc != 0:
+            raise ValueError("oracle_pvsim_bundle: bad arguments")
+        out = {"plI": pl, "status": status, "iters_total": itot, "iters_max": imax}
+        if want_step_iters:
+            out["step_iters"] = steps
+        return out
     snaps = np.ascontiguousarray(snap_steps if snap_steps is not None else [], dtype=np.int64)   # C long
     ns = len(snaps)
     plN, plP, plE = np.zeros((S, ns, L)), np.zeros((S, ns, L)), np.zeros((S, ns, L + 1))

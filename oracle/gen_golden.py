@@ -9,7 +9,7 @@ absent `numba`) first on sys.path, calls the reference functions, and stores *da
 
 Reference entry points exercised (file:line):
   pvSimPCR.pcreduce :42-81, pvSimPCR.norm2 :14-40          -> pcr_norm.npz
-  pvSimPCR.pvSim :309-401 (tEvol :227-306, iterate :93-225) -> pvsim_*.npz
+  pvSimPCR.pvSim :309-401 (tEvol :227-306, iterate :93-225) -> pvsim_*.npz (pvsim_bundle: max_sims_per_block 2 and 3)
   probs.fastlog :78-85, probs.prob :49-62                   -> probs.npz
   bayeslib.random_grid :18-32, bayeslib.bayes :207-252      -> bayes_e2e.npz, sampler.npz
   pvSim_fallback.pvSim_cpu_fallback :80-117 (as shipped)    -> fallback.npz
@@ -79,17 +79,19 @@ class IterRecorder:
         pvSimPCR.iterate = self.orig
 
 
-def run_pvsim(mat12, length, time_ns, L, T, ini, dtype, tol=7, MAX=10000, plT=1):
+def run_pvsim(mat12, length, time_ns, L, T, ini, dtype, tol=7, MAX=10000, plT=1, mspb=1):
+    """mspb > 1: max_sims_per_block consecutive samples share one convergence test (pvSimPCR.py:213-216,:258-266);
+    the iteration count of a bundle is recorded for each of its samples."""
     S = len(mat12)
     simPar = [length, time_ns, L, T, plT, PT, tol, MAX]
     plI = np.empty((S, T // plT + 1), dtype=dtype)
     dummyN = np.empty((S, 2, L)); dummyE = np.empty((S, 2, L + 1))
     with IterRecorder() as rec:
-        pvSimPCR.pvSim(plI, dummyN, dummyN.copy(), dummyE, mat12, simPar, ini, (1,), max(S, 1), 1,
+        pvSimPCR.pvSim(plI, dummyN, dummyN.copy(), dummyE, mat12, simPar, ini, (1,), max((S + mspb - 1) // mspb, 1), mspb,
                        init_mode="points")
     it = np.zeros((S, T + 1), dtype=np.int32)
     for p, t, r in rec.log:
-        it[p, t] = r
+        it[p:p + mspb, t] = r
     return plI, it
 
 
@@ -171,6 +173,22 @@ def case_pvsim_small():
                        init_mode="points")
     out["nc_plI"] = pl; out["nc_log"] = np.array(rec.log); out["nc_ini"] = ini_hi
     np.savez_compressed(os.path.join(OUT, "pvsim_small.npz"), X=X, **out)
+
+
+def case_pvsim_bundle():
+    """max_sims_per_block = 3 and 2 (bayes_validate.connect_to_gpu's default is 3): 7 samples = bundles of 3, 3, 1 /
+    2, 2, 2, 1; the high-power Power_scan curve and the stiff 311 nm Twothick curve."""
+    iniP = get_initpoints(EXC_POWER, {"select_obs_sets": None})
+    iniT = get_initpoints(EXC_TWO, {"select_obs_sets": None})
+    X = np.vstack([draw(6, seed=7), MARK * UNIT])
+    T = 80
+    out = {"X": X, "iniP": iniP[2], "iniT": iniT[0], "T": T, "time": T * 0.025, "L": 128, "lengthP": 2000.0, "lengthT": 311.0}
+    for m in (3, 2):
+        p, i = run_pvsim(X[:, :-1], 2000, T * 0.025, 128, T, iniP[2], np.float64, mspb=m)
+        out["plP%d" % m] = p; out["itP%d" % m] = i
+        p, i = run_pvsim(X[:, :-1], 311, T * 0.025, 128, T, iniT[0], np.float64, mspb=m)
+        out["plT%d" % m] = p; out["itT%d" % m] = i
+    np.savez_compressed(os.path.join(OUT, "pvsim_bundle.npz"), **out)
 
 
 def case_probs():
@@ -411,7 +429,7 @@ def case_posterior():
 
 
 CASES = {"posterior": case_posterior, "legacy_odeint": case_legacy_odeint, "csv_fixture": case_csv_fixture, "bayes_realdata": case_bayes_realdata, "pcr_norm": case_pcr_norm, "probs": case_probs, "sampler": case_sampler,
-         "pvsim_small": case_pvsim_small, "pvsim_power": case_pvsim_power,
+         "pvsim_small": case_pvsim_small, "pvsim_power": case_pvsim_power, "pvsim_bundle": case_pvsim_bundle,
          "pvsim_twothick": case_pvsim_twothick, "bayes_e2e": case_bayes_e2e,
          "fallback": case_fallback}
 

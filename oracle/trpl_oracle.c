@@ -127,19 +127,16 @@ static void ws_free(sysws *w) { free(w->N); }
  * indices k (current), kp (new), ko[0..3] (older).  Returns the iteration count
  * (`iters+1`, :225).
  * ---------------------------------------------------------------------------------- */
-static int iterate(sysws *w, const double *mp, const double *a, int k, int kp,
-                   const int *ko, double TOL, int MAX)
+/* iterate() in three pieces, so that max_sims_per_block > 1 (several systems sharing ONE convergence test,
+ * pvSimPCR.py:213-216) can sweep its systems in lockstep: it_begin = :128-139, it_sweep = one pass of the
+ * loop body :148-209 returning errN / errP, it_end = :218-222. */
+static void it_begin(sysws *w, const double *a, int k, const int *ko)
 {
     const int L = w->L;
-    const double N0 = mp[0], P0 = mp[1], DN = mp[2], DP = mp[3], rate = mp[4],
-                 sr0 = mp[5], srL = mp[6], CN = mp[7], CP = mp[8], tauN = mp[9],
-                 tauP = mp[10], Lambda = mp[11];
-    const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5];
-    double *Nk = w->Nk, *Pk = w->Pk, *Ek = w->Ek, *bN = w->bN, *bP = w->bP, *bE = w->bE,
-           *bb = w->bb, *A0 = w->A0, *A1 = w->A1, *A2 = w->A2, *buffer = w->buffer;
+    const double a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5];
+    double *Nk = w->Nk, *Pk = w->Pk, *Ek = w->Ek, *bN = w->bN, *bP = w->bP, *bE = w->bE, *A0 = w->A0, *A2 = w->A2;
     const double *Nh = w->N, *Ph = w->P, *Eh = w->E;
     const int LE = L + 1;
-
     for (int n = 0; n < L; n++) {                                               /* :128-135 */
         Nk[n] = Nh[k * L + n];
         Pk[n] = Ph[k * L + n];
@@ -153,11 +150,19 @@ static int iterate(sysws *w, const double *mp, const double *a, int k, int kp,
     }
     A0[L - 1] = 0;                                                              /* :138-139 */
     A2[0] = 0;
+}
+
+static void it_sweep(sysws *w, const double *mp, double a0, double *errN_out, double *errP_out)
+{
+    const int L = w->L;
+    const double N0 = mp[0], P0 = mp[1], DN = mp[2], DP = mp[3], rate = mp[4],
+                 sr0 = mp[5], srL = mp[6], CN = mp[7], CP = mp[8], tauN = mp[9],
+                 tauP = mp[10], Lambda = mp[11];
+    double *Nk = w->Nk, *Pk = w->Pk, *Ek = w->Ek, *bN = w->bN, *bP = w->bP, *bE = w->bE,
+           *bb = w->bb, *A0 = w->A0, *A1 = w->A1, *A2 = w->A2, *buffer = w->buffer;
     double errN = 0, errP = 0;
     const double n0p0 = N0 * P0;
-
-    int iters;
-    for (iters = 0; iters < MAX; iters++) {                                     /* :147 */
+    {
         /* ---- electrons ---- */
         for (int n = 1; n < L; n++) {                                           /* :148-151 */
             A0[n - 1] = DN * (-Ek[n] / 2 - 1);
@@ -214,16 +219,51 @@ static int iterate(sysws *w, const double *mp, const double *a, int k, int kp,
             bb[n] = Lambda * (DP * (Pk[n] - Pk[n - 1]) - DN * (Nk[n] - Nk[n - 1])) - bE[n];
             Ek[n] = bb[n] / A1[n];
         }
-        if (errN < TOL && errP < TOL) break;                                    /* :213-216 */
     }
+    *errN_out = errN;
+    *errP_out = errP;
+}
+
+static void it_end(sysws *w, int kp)
+{
+    const int L = w->L, LE = L + 1;
     double *Nw = w->N + kp * L, *Pw = w->P + kp * L, *Ew = w->E + kp * LE;
     for (int n = 0; n < L; n++) {                                               /* :218-222 */
-        Nw[n] = Nk[n];
-        Pw[n] = Pk[n];
-        Ew[n] = Ek[n];
+        Nw[n] = w->Nk[n];
+        Pw[n] = w->Pk[n];
+        Ew[n] = w->Ek[n];
     }
+}
+
+/* shared_array_max, pvSimPCR.py:83-90 (a NaN in arr[i > 0] is skipped by `>`, one in arr[0] sticks) */
+static double shared_array_max(const double *arr, int n)
+{
+    double m = arr[0];
+    for (int i = 1; i < n; i++)
+        if (arr[i] > m) m = arr[i];
+    return m;
+}
+
+/* iterate() for num_sims systems that share the convergence test (num_sims = 1: the plain case) */
+static int iterate_bundle(sysws *w, int num_sims, const double *mp /*[num_sims][12]*/, const double *a, int k, int kp,
+                          const int *ko, double TOL, int MAX)
+{
+    double errN[16] = {0}, errP[16] = {0};                                      /* :143-145 */
+    for (int y = 0; y < num_sims; y++) it_begin(&w[y], a, k, ko);
+    int iters;
+    for (iters = 0; iters < MAX; iters++) {                                     /* :147 */
+        for (int y = 0; y < num_sims; y++) it_sweep(&w[y], mp + 12 * y, a[0], &errN[y], &errP[y]);
+        if (shared_array_max(errN, num_sims) < TOL && shared_array_max(errP, num_sims) < TOL) break;   /* :211-216 */
+    }
+    for (int y = 0; y < num_sims; y++) it_end(&w[y], kp);
     /* Python: a loop that ran to exhaustion leaves iters = MAX-1; `return iters+1` (:225) */
     return (iters < MAX ? iters : MAX - 1) + 1;
+}
+
+static int iterate(sysws *w, const double *mp, const double *a, int k, int kp,
+                   const int *ko, double TOL, int MAX)
+{
+    return iterate_bundle(w, 1, mp, a, k, kp, ko, TOL, MAX);
 }
 
 /* BDF coefficient table, tEvol pvSimPCR.py:241-250 */
@@ -357,6 +397,86 @@ int oracle_pvsim_snap(const double *matpar, long S, double length, double time_,
         if (iters_total) iters_total[y] = itot;
         if (iters_max) iters_max[y] = imax;
         ws_free(&w);
+    }
+    return fail ? -1 : 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * oracle_pvsim_bundle -- pvSim with max_sims_per_block = mspb > 1 (pvSimPCR.py:258-266): the samples
+ * p .. min(p + mspb, S) - 1 form a bundle whose systems iterate in lockstep until the LARGEST errN and errP of
+ * the bundle are below TOL (:211-216, shared_array_max :83-90); iterate()'s return is the bundle's.  A bundle
+ * that reaches MAX is flagged as a whole (every sample gets status 1 + t and NaN from there on; the reference
+ * stops the launch, :269-274,:290-292).  Arguments as oracle_pvsim; mspb in [1, 16].
+ * ---------------------------------------------------------------------------------- */
+int oracle_pvsim_bundle(const double *matpar, long S, double length, double time_, int L, long T,
+                        int plT, int tol, int MAX, const double *inipar, void *plI, int plI_bytes,
+                        long ldp, int32_t *status, int64_t *iters_total, int32_t *iters_max,
+                        int32_t *step_iters, int mspb, int nthreads)
+{
+    if (L < 4 || (L & (L - 1)) || T < 1 || plT < 1 || (plI_bytes != 4 && plI_bytes != 8) || mspb < 1 || mspb > 16)
+        return -1;
+    double scales[12], dx3, plnorm;
+    oracle_scales(length, time_, L, T, scales, &dx3, &plnorm);
+    const double TOL = pow(10.0, -(double)tol);                                 /* :112 */
+    const long nb = (S + mspb - 1) / mspb;
+    int fail = 0;
+    (void)nthreads;
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+#endif
+    for (long b = 0; b < nb; b++) {
+        const long p = b * mspb;
+        const int ns = (int)((p + mspb <= S ? p + mspb : S) - p);               /* p_lim - p, :265 */
+        sysws w[16];
+        double mp[16 * 12];
+        int ok = 1;
+        for (int y = 0; y < ns; y++) if (ws_alloc(&w[y], L)) { ok = 0; for (int q = 0; q < y; q++) ws_free(&w[q]); break; }
+        if (!ok) { fail = 1; continue; }
+        for (int y = 0; y < ns; y++) {
+            for (int i = 0; i < 12; i++) mp[12 * y + i] = matpar[(p + y) * 12 + i] * scales[i];   /* :331 */
+            for (int n = 0; n < L; n++) {                                       /* :356-362 */
+                double dN = inipar[n] * dx3;
+                w[y].N[n] = mp[12 * y] + dN;
+                w[y].P[n] = mp[12 * y + 1] + dN;
+            }
+        }
+        int st = 0, imax = 0;
+        int64_t itot = 0;
+        long t;
+        for (t = 0; t <= T; t++) {                                              /* :237 */
+            double a[6];
+            bdf_coeffs(t, a);
+            int kp = pymod6(t + 1), k = pymod6(t);                              /* :251-256 */
+            int ko[4] = { pymod6(t - 1), pymod6(t - 2), pymod6(t - 3), pymod6(t - 4) };
+            int it = iterate_bundle(w, ns, mp, a, k, kp, ko, TOL, MAX);         /* :266 */
+            itot += it;
+            if (it > imax) imax = it;
+            if (step_iters) for (int y = 0; y < ns; y++) step_iters[(p + y) * (T + 1) + t] = it;
+            if (it >= MAX) { st = 1 + (int)t; break; }                          /* :269-274 */
+            if (t % plT == 0) {                                                 /* :276-281 */
+                for (int y = 0; y < ns; y++) {
+                    double Sum = -(double)L * (mp[12 * y] * mp[12 * y + 1]);
+                    const double *Nc = w[y].N + k * L, *Pc = w[y].P + k * L;
+                    for (int n = 0; n < L; n++) Sum += Nc[n] * Pc[n];
+                    double v = mp[12 * y + 4] * Sum;
+                    if (plI_bytes == 4) ((float *)plI)[(p + y) * ldp + t / plT] = (float)v / (float)plnorm;   /* :281,:393 */
+                    else                ((double *)plI)[(p + y) * ldp + t / plT] = v / plnorm;
+                }
+            }
+        }
+        for (int y = 0; y < ns; y++) {
+            if (st)
+                for (long tt = t; tt <= T; tt++)
+                    if (tt % plT == 0) {
+                        if (plI_bytes == 4) ((float *)plI)[(p + y) * ldp + tt / plT] = NAN;
+                        else                ((double *)plI)[(p + y) * ldp + tt / plT] = NAN;
+                    }
+            if (status) status[p + y] = st;
+            if (iters_total) iters_total[p + y] = itot;
+            if (iters_max) iters_max[p + y] = imax;
+            ws_free(&w[y]);
+        }
     }
     return fail ? -1 : 0;
 }

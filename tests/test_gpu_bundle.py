@@ -1,0 +1,74 @@
+"""max_sims_per_block > 1 (shared_array_max pvSimPCR.py:83-90): the reference lets the samples of a
+bundle iterate until the slowest has converged.  STRICT mode reproduces that bit for bit -- against what the reference
+itself produced (tests/golden/pvsim_bundle.npz) and against the oracle on larger batches; FAST modes keep samples
+independent and refuse the flag."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bundled_strict_is_the_reference_bit_for_bit(gpu, golden):
+    g = golden("pvsim_bundle")
+    X, T, Time, L = g["X"][:, :12], int(g["T"]), float(g["time"]), int(g["L"])
+    for tag, ini, length in (("P", g["iniP"], float(g["lengthP"])), ("T", g["iniT"], float(g["lengthT"]))):
+        for m in (3, 2):
+            pl, st, it, _ = gpu.solve_pl(X, length, Time, L, T, ini, strict=True, bundle=m)
+            assert np.array_equal(pl, g["pl%s%d" % (tag, m)]), (tag, m)
+            assert np.array_equal(it, g["it%s%d" % (tag, m)].sum(axis=1)), (tag, m)
+            assert not st.any()
+        # through the drop-in signature: max_sims_per_block is the 10th positional argument (bayeslib.py:144-146)
+        plI = np.empty((len(X), T + 1))
+        gpu.pvSim(plI, None, None, None, X, [length, Time, L, T, 1, None, 7, 10000], ini, (128,), 64, 3,
+                  init_mode="points", strict=True)
+        assert np.array_equal(plI, g["pl%s3" % tag])
+        # FAST: every sample on its own -- the unbundled result, within the solver tolerance of the bundled one
+        gpu.pvSim(plI, None, None, None, X, [length, Time, L, T, 1, None, 7, 10000], ini, (128,), 64, 3, init_mode="points")
+        assert not np.array_equal(plI, g["pl%s3" % tag]) and np.allclose(plI, g["pl%s3" % tag], rtol=1e-6)
+
+
+@pytest.mark.parametrize("m,L", [(2, 128), (3, 128), (4, 128), (3, 32), (2, 256)])
+def test_bundled_strict_vs_oracle_with_short_last_bundle_and_snapshots(gpu, oracle, m, L):
+    w = gpu.workloads
+    ini, lens = w.twothick(L)
+    S = 4 * m + 1                                            # a last bundle of one system
+    X = w.samples(S, seed=100 + m)[:, :12]
+    T, Time = 48, 1.2
+    want = oracle.pvsim(X, lens[0], Time, L, T, ini[0], mspb=m, nthreads=4)
+    snaps = {}
+    pl, st, it, _ = gpu.solve_pl(X, lens[0], Time, L, T, ini[0], strict=True, bundle=m, snap_steps=[0, 7, T],
+                                 snapshots=snaps)
+    assert np.array_equal(pl, want["plI"]) and np.array_equal(it, want["iters_total"]) and not st.any()
+    assert np.isfinite(snaps["plN"]).all() and (snaps["plN"][:, 1] > 0).all()
+    for b in range(0, S, m):                                 # a bundle's systems share their iteration total
+        assert (it[b:b + m] == it[b]).all()
+    # the coupling is real: unbundled totals are smaller for the faster members
+    alone = gpu.solve_pl(X, lens[0], Time, L, T, ini[0], strict=True)[2]
+    assert (alone <= it).all() and (alone < it).any()
+
+
+def test_a_bundle_that_reaches_max_iter_is_flagged_as_a_whole(gpu, oracle):
+    w = gpu.workloads
+    ini, lens = w.twothick(128)
+    X = w.samples(7, seed=3)[:, :12]
+    T, Time = 40, 1.0
+    probe = oracle.pvsim(X, lens[0], Time, 128, T, ini[0], mspb=3, want_step_iters=True)
+    cap = int(probe["step_iters"][3].max())                  # the second bundle's slowest step fails at this cap
+    want = oracle.pvsim(X, lens[0], Time, 128, T, ini[0], mspb=3, MAX=cap)
+    pl, st, it, _ = gpu.solve_pl(X, lens[0], Time, 128, T, ini[0], strict=True, bundle=3, MAX=cap)
+    assert np.array_equal(st, want["status"]) and st[3] > 0 and (st[3:6] == st[3]).all()
+    assert np.array_equal(it, want["iters_total"])
+    assert np.array_equal(np.isnan(pl), np.isnan(want["plI"])) and np.array_equal(pl[~np.isnan(pl)], want["plI"][~np.isnan(pl)])
+
+
+def test_bundle_flag_is_validated(gpu):
+    w = gpu.workloads
+    ini, lens = w.twothick(128)
+    X = w.samples(4, seed=1)[:, :12]
+    with pytest.raises(gpu.TrplError, match="STRICT"):
+        gpu.solve_pl(X, lens[0], 0.5, 128, 20, ini[0], bundle=2)
+    with pytest.raises(ValueError):
+        gpu.solve_pl(X, lens[0], 0.5, 128, 20, ini[0], strict=True, bundle=5)
+    # bundle = 1 is the plain call
+    a = gpu.solve_pl(X, lens[0], 0.5, 128, 20, ini[0], strict=True, bundle=1)[0]
+    assert np.array_equal(a, gpu.solve_pl(X, lens[0], 0.5, 128, 20, ini[0], strict=True)[0])

@@ -50,6 +50,28 @@ def test_pvsim_twothick_bit_exact(oracle, golden):
     assert g["iters"].max() > 400          # the 311 nm / high power curve stresses the iteration
 
 
+def test_pvsim_bundled_convergence_bit_exact(oracle, golden):
+    """max_sims_per_block = 3 and 2 (pvSimPCR.py:213-216,:258-266): the bundle's systems iterate until the slowest
+    has converged -- PL and the shared per-step iteration counts as the reference produced them, bundles 3+3+1 and
+    2+2+2+1, on the high-power Power_scan curve and the stiff 311 nm Twothick curve."""
+    g = golden("pvsim_bundle")
+    X, T, Time, L = g["X"][:, :12], int(g["T"]), float(g["time"]), int(g["L"])
+    for tag, ini, length in (("P", g["iniP"], float(g["lengthP"])), ("T", g["iniT"], float(g["lengthT"]))):
+        for m in (3, 2):
+            r = oracle.pvsim(X, length, Time, L, T, ini, mspb=m, want_step_iters=True, nthreads=2)
+            assert np.array_equal(r["plI"], g["pl%s%d" % (tag, m)]), (tag, m)
+            assert np.array_equal(r["step_iters"], g["it%s%d" % (tag, m)]), (tag, m)
+            assert not r["status"].any()
+        # and the bundles do change the answer: the unbundled run differs from the bundled one
+        r1 = oracle.pvsim(X, length, Time, L, T, ini)
+        assert not np.array_equal(r1["plI"], g["pl%s3" % tag]) and np.allclose(r1["plI"], g["pl%s3" % tag], rtol=1e-6)
+    # a bundle that hits MAX is flagged as a whole
+    cap = int(g["itT3"][3].max())                      # the second bundle's slowest step
+    r = oracle.pvsim(X, float(g["lengthT"]), Time, L, T, g["iniT"], mspb=3, MAX=cap)
+    assert (r["status"][3:6] == r["status"][3]).all() and r["status"][3] > 0 and np.isnan(r["plI"][3:6, -1]).all()
+    assert (r["status"][:3] == r["status"][0]).all() and r["status"][6] == 0
+
+
 def test_pvsim_small_grids_plT_and_nonconvergence(oracle, golden):
     g = golden("pvsim_small")
     X = g["X"]
