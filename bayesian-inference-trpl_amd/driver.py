@@ -278,8 +278,8 @@ def simulate(model, e_data, P, X, plI, plI_int, num_curves, sim_params, init_par
         par = list(sim_params)
         par[0] = thicknesses[ic_num]                                      # :119
         buf = np.empty((size, ncol), dtype=pl_dtype)                      # :137
-        sec = model(buf, None, None, None, X[blk:blk + size, :-1], par, init_params[ic_num], None, None, 1,
-                    init_mode="points")
+        sec = model(buf, None, None, None, X[blk:blk + size, :-1], par, init_params[ic_num], None, None,
+                    int(gpu_info.get("max_sims_per_block", 1)), init_mode="points")      # :93,:146
         return buf, sec
 
     pool = None
