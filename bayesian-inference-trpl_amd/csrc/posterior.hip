@@ -107,9 +107,10 @@ __global__ void __launch_bounds__(kThreads) moments1_partial(const double *V, co
         const double w = W[i];
         sw += w;
         sw2 += w * w;
+        // unconditional loads (a column index beyond D re-reads the last column, whose sum is never stored): no
+        // branch between the loads, all 1 + kMaxDim of a sample are in flight together
 #pragma unroll
-        for (int d = 0; d < kMaxDim; d++)
-            if (d < D) sv[d] += V[(int64_t)d * S + i] * w;
+        for (int d = 0; d < kMaxDim; d++) sv[d] += V[(int64_t)(d < D ? d : D - 1) * S + i] * w;
     }
     double *row = part + (int64_t)blockIdx.x * (2 + D);
     double r = block_reduce<false>(sw, sm);
@@ -152,14 +153,12 @@ __global__ void __launch_bounds__(kThreads, 1) moments2_partial(const double *V,
     int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     double w[kAhead + 1], x[kAhead + 1][DM];
     auto fetch = [&](int64_t idx, int slot) {
-        w[slot] = 0.0;
+        // clamped, unconditional loads (no branch between them): a sample index beyond S re-reads the last sample
+        // with weight 0, a column beyond D the last column, which xc[] then ignores
+        const int64_t at = idx < S ? idx : S - 1;
+        w[slot] = idx < S ? W[at] : 0.0;
 #pragma unroll
-        for (int e = 0; e < DM; e++) x[slot][e] = 0.0;
-        if (idx < S) {
-            w[slot] = W[idx];
-#pragma unroll
-            for (int e = 0; e < DM; e++) if (e < D) x[slot][e] = V[(int64_t)e * S + idx];
-        }
+        for (int e = 0; e < DM; e++) x[slot][e] = V[(int64_t)(e < D ? e : D - 1) * S + at];
     };
 #pragma unroll
     for (int q = 0; q < kAhead; q++) fetch(i + q * stride, q);
