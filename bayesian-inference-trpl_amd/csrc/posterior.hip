@@ -250,13 +250,15 @@ __global__ void __launch_bounds__(kThreads) hist_kernel(const double *x, const d
         __syncthreads();
     }
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < S; i += (int64_t)gridDim.x * kThreads) {
-        int k = bin_of(x[i], xlo, xhi, xb, xs, xt);
+        // all of a sample's loads first, unconditionally: a load behind a data-dependent branch waits for the
+        // previous one (the coordinates and the weight are three independent streams)
+        const double xi = x[i], yi = y ? y[i] : 0.0, w = W ? W[i] : 1.0;
+        int k = bin_of(xi, xlo, xhi, xb, xs, xt);
         if (k >= 0 && y) {
-            const int ky = bin_of(y[i], ylo, yhi, yb, ys, yt);
+            const int ky = bin_of(yi, ylo, yhi, yb, ys, yt);
             k = ky < 0 ? -1 : k * yb + ky;                      // [x bin][y bin], like np.histogram2d
         }
         if (k < 0) continue;
-        const double w = W ? W[i] : 1.0;
         if (use_lds) atomicAdd(&bins[my + k], w);
         else atomicAdd(&out[k], w);
     }
