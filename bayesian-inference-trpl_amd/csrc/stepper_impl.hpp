@@ -250,14 +250,14 @@ struct PlSink {
     // observation times, which need consecutive values in order (emit()).
     __device__ __forceinline__ void push(int64_t col, double plv)
     {
-        if ((int64_t)threadIdx.x == col - base) pend = plv;
+        if ((int64_t)lane_ == col - base) pend = plv;
         if (col - base == 63) flush_batch(64);
     }
 
     __device__ __forceinline__ void flush_batch(int n)      // columns base .. base+n-1, wave-uniform n in [0, 64]
     {
         if (n > 0) {
-            const int lane = threadIdx.x;
+            const int lane = lane_;
             const int64_t col = base + lane;
             const bool live = lane < n;
             const bool f32 = (a.flags & kFlagPlF32) != 0;
@@ -537,7 +537,7 @@ __device__ __forceinline__ void update_field(const MatPar &m, double a0, const d
     }
 }
 
-// BUNDLE (STRICT only): the reference's max_sims_per_block > 1 -- a.bundle consecutive samples of a curve share ONE
+// BUNDLE: the reference's max_sims_per_block > 1 -- a.bundle consecutive samples of a curve share ONE
 // convergence test per inner iteration (pvSimPCR.py:211-216,:258-266).  One workgroup = one bundle, one wavefront per
 // system, the per-system verdicts exchanged through LDS with one barrier per iteration.
 template <int L, bool STRICT, bool SNAP = false, bool MIXED = false, bool BUNDLE = false>
@@ -548,7 +548,7 @@ stepper_kernel(const StepArgs a)
     constexpr int NR = L / W;
     constexpr int LAY = STRICT ? 0 : (L >= 128 ? 2 : 1);   // node layout / arithmetic flavour
     static_assert(!MIXED || LAY == 2, "the mixed-precision correction exists for the interleaved layout (L >= 128)");
-    static_assert(!BUNDLE || STRICT, "bundled convergence exists to reproduce the reference bit for bit: STRICT only");
+    static_assert(!BUNDLE || (!MIXED && (STRICT || L <= 128)), "bundles: STRICT at any L, FAST up to L = 128 (LDS: one history ring per system)");
     const int wv = BUNDLE ? (int)(threadIdx.x >> 6) : 0;                 // which system of the bundle
     const int lane64 = BUNDLE ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     const int ln = lane64 & (W - 1);               // lanes >= W replicate lane (lane mod W)
@@ -582,10 +582,11 @@ stepper_kernel(const StepArgs a)
     // that ring + 3 KB PCR exchange buffer leave room for 3 waves per SIMD (12 x 11 KB <= 160 KB).
     constexpr int HSLOT = 2 * NR * 64;              // N and P; the E history stays in registers
     constexpr int XCH = LAY != 2 ? 2 : (TRPL_CR_HYBRID != 0 ? 3 * 64 : 3 * L);   // PCR exchange buffer, doubles
-    __shared__ __attribute__((aligned(16))) double lds[STRICT ? 2 : 4 * HSLOT + XCH];
-    double *hist = lds;
-    double *xch = lds + (STRICT ? 0 : 4 * HSLOT);   // PCR exchange buffer (LAY 2)
-    const int hl = threadIdx.x;                     // this lane's column of the ring
+    constexpr int LDSW = STRICT ? 2 : 4 * HSLOT + XCH;              // per wavefront
+    __shared__ __attribute__((aligned(16))) double lds[LDSW * (BUNDLE ? kMaxBundle : 1)];
+    double *hist = lds + (BUNDLE ? wv * LDSW : 0);
+    double *xch = hist + (STRICT ? 0 : 4 * HSLOT);  // PCR exchange buffer (LAY 2)
+    const int hl = lane64;                          // this lane's column of the ring
     double Nk[NR], Pk[NR], Ek[NR];
     double hN[4][NR], hP[4][NR];                    // STRICT only: levels t-1 .. t-4
     double hE[4][NR];                               // field history, registers in both modes
@@ -710,7 +711,7 @@ stepper_kernel(const StepArgs a)
             assemble<LAY, true, NR, W, L>(mp, a0, Nk, Pk, Ek, Ep, bN, lo_, dg, up, bb, ln);
             if constexpr (MIXED) {
                 okN = correct_mixed<NR>(lo_, dg, up, bb, Nk, TOL, ln, (float *)xch);
-            } else if constexpr (BUNDLE) {         // shared_array_max: a NaN sticks in the first system, is skipped in the others
+            } else if constexpr (BUNDLE && STRICT) {   // shared_array_max: a NaN sticks in the first system, is skipped in the others
                 const double e = residual_err_strict<NR, W>(lo_, dg, up, bb, Nk, ln);
                 okN = wv == 0 ? e < TOL : !(e >= TOL);
                 solve_lay<LAY, NR, W, L>(lo_, dg, up, bb, Nk, ln, xch);
@@ -725,7 +726,7 @@ stepper_kernel(const StepArgs a)
             } else {
                 // the holes' norm decides nothing unless the electrons' has passed (:213): skipped otherwise (a
                 // wave-uniform branch; on the first iteration of a time step it practically always is)
-                if constexpr (BUNDLE) {
+                if constexpr (BUNDLE && STRICT) {
                     okP = false;
                     if (okN) {
                         const double e = residual_err_strict<NR, W>(lo_, dg, up, bb, Pk, ln);
@@ -770,7 +771,7 @@ stepper_kernel(const StepArgs a)
         }
     }
 
-    if (!(STRICT || sink.interp)) {                // columns parked since the last full batch
+    if (!(STRICT || sink.interp) && valid) {       // columns parked since the last full batch
         const int64_t done = status ? (int64_t)(status - 1) : sink.t_last + 1;      // steps whose PL was emitted
         sink.flush_batch((int)((done + a.plT - 1) / a.plT - sink.base));
     }
@@ -789,24 +790,30 @@ hipError_t launch_stepper(const StepArgs &a, hipStream_t stream)
     // development knob: extra dynamic LDS per workgroup lowers the number of resident waves
     static const unsigned lds_pad = getenv("TRPL_LDS_PAD") ? (unsigned)atoi(getenv("TRPL_LDS_PAD")) : 0u;
     const bool snap = a.n_snap > 0 || a.resN != nullptr;   // snapshot / resume code only exists in its own instantiation
-    if constexpr (STRICT) {
-        if (a.bundle > 1) {                        // one workgroup per bundle of a.bundle consecutive samples of a curve
-            if (a.bundle > kMaxBundle) return hipErrorInvalidValue;
-            grid = dim3((unsigned)(((a.S + a.bundle - 1) / a.bundle) * a.C));
-            block = dim3(64 * a.bundle);
-            switch (a.L) {
+    if (a.bundle > 1) {                            // one workgroup per bundle of a.bundle consecutive samples of a curve
+        if (a.bundle > kMaxBundle || (!STRICT && a.L > 128)) return hipErrorInvalidValue;
+        grid = dim3((unsigned)(((a.S + a.bundle - 1) / a.bundle) * a.C));
+        block = dim3(64 * a.bundle);
+        switch (a.L) {
 #define TRPL_CASE(LL) \
     case LL: \
-        if (snap) hipLaunchKernelGGL((stepper_kernel<LL, true, true, false, true>), grid, block, 0, stream, a); \
-        else      hipLaunchKernelGGL((stepper_kernel<LL, true, false, false, true>), grid, block, 0, stream, a); \
+        if (snap) hipLaunchKernelGGL((stepper_kernel<LL, STRICT, true, false, true>), grid, block, 0, stream, a); \
+        else      hipLaunchKernelGGL((stepper_kernel<LL, STRICT, false, false, true>), grid, block, 0, stream, a); \
         break;
-                TRPL_CASE(4) TRPL_CASE(8) TRPL_CASE(16) TRPL_CASE(32) TRPL_CASE(64) TRPL_CASE(128)
-                TRPL_CASE(256) TRPL_CASE(512)
+            TRPL_CASE(4) TRPL_CASE(8) TRPL_CASE(16) TRPL_CASE(32) TRPL_CASE(64) TRPL_CASE(128)
 #undef TRPL_CASE
-            default: return hipErrorInvalidValue;
-            }
-            return hipGetLastError();
+#define TRPL_CASE(LL) \
+    case LL: \
+        if constexpr (STRICT) { \
+            if (snap) hipLaunchKernelGGL((stepper_kernel<LL, true, true, false, true>), grid, block, 0, stream, a); \
+            else      hipLaunchKernelGGL((stepper_kernel<LL, true, false, false, true>), grid, block, 0, stream, a); \
+        } \
+        break;
+            TRPL_CASE(256) TRPL_CASE(512)
+#undef TRPL_CASE
+        default: return hipErrorInvalidValue;
         }
+        return hipGetLastError();
     }
     switch (a.L) {
 #define TRPL_CASE(LL) \

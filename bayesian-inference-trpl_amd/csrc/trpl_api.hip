@@ -123,6 +123,7 @@ int check_variant_flags(uint32_t flags, int32_t L)
 bool pick_pair_kernel(int64_t nsys, int32_t L, int64_t steps, uint32_t flags)
 {
     if (L != 128 || (flags & (TRPL_FLAG_STRICT | TRPL_FLAG_FP32 | TRPL_FLAG_MIXED))) return false;
+    if (flags & 0xF00u) return false;                          // TRPL_FLAG_BUNDLE(m > 1): one system per wavefront, one bundle per workgroup
     if (flags & TRPL_FLAG_KERNEL_PAIR) return true;
     if (flags & TRPL_FLAG_KERNEL_SINGLE) return false;
     return use_pair_kernel(nsys, steps);
@@ -155,8 +156,10 @@ int launch(const trpl::StepArgs &a_in, uint32_t flags, hipStream_t st, int64_t s
     if (int rc = check_variant_flags(flags, a_in.L)) return rc;
     trpl::StepArgs a = a_in;
     a.bundle = (int32_t)((flags >> 8) & 0xF) + 1;             // TRPL_FLAG_BUNDLE(m)
-    if (a.bundle > 1 && !(flags & TRPL_FLAG_STRICT))
-        return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_BUNDLE needs TRPL_FLAG_STRICT: only the bit-reproducible mode couples the convergence of neighbouring samples");
+    if (a.bundle > 1 && (flags & (TRPL_FLAG_FP32 | TRPL_FLAG_MIXED | TRPL_FLAG_KERNEL_PAIR)))
+        return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_BUNDLE goes with TRPL_FLAG_STRICT or the plain fp64 one-system stepper only");
+    if (a.bundle > 1 && !(flags & TRPL_FLAG_STRICT) && a.L > 128)
+        return api_fail(TRPL_ERR_UNSUPPORTED, "TRPL_FLAG_BUNDLE without TRPL_FLAG_STRICT is built for L <= 128 (got %d)", a.L);
     if (a.bundle > trpl::kMaxBundle) return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_BUNDLE(%d): at most %d systems per bundle", a.bundle, trpl::kMaxBundle);
     if (flags & TRPL_FLAG_FP32) {
         if (flags & (TRPL_FLAG_STRICT | TRPL_FLAG_MIXED)) return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_FP32 excludes TRPL_FLAG_STRICT and TRPL_FLAG_MIXED");

@@ -99,6 +99,7 @@ int trpl_loglik_multi(const double *X, int64_t S, int32_t C, const double *lengt
         if (devices[r] < 0 || devices[r] >= visible)
             return api_fail(TRPL_ERR_ARG, "devices[%d]=%d out of range (%d visible)", r, devices[r], visible);
     if (int rc = check_variant_flags(flags, L)) return rc;
+    if (flags & 0xF00u) return api_fail(TRPL_ERR_UNSUPPORTED, "TRPL_FLAG_BUNDLE couples neighbouring samples: a sharded batch would depend on where it is cut");
     for (int c = 0; c < C; c++)
         if (n_obs[c] < 1 || n_obs[c] > obs_ld)
             return api_fail(TRPL_ERR_ARG, "n_obs[%d]=%lld out of range (obs_ld %lld)", c, (long long)n_obs[c], (long long)obs_ld);
@@ -364,6 +365,7 @@ int trpl_loglik_multi_dev(trpl_multi_t *h, const double *const *X, int64_t S, in
     if (interp && !(obs_hi && obs_dx && obs_h)) return api_fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h go together");
     if (interp && plT != 1) return api_fail(TRPL_ERR_ARG, "off-grid observations need plT = 1");
     if (int rc = check_variant_flags(flags, L)) return rc;
+    if (flags & 0xF00u) return api_fail(TRPL_ERR_UNSUPPORTED, "TRPL_FLAG_BUNDLE couples neighbouring samples: a sharded batch would depend on where it is cut");
     for (int c = 0; c < C; c++)
         if (n_obs[c] < 1 || n_obs[c] > obs_ld)
             return api_fail(TRPL_ERR_ARG, "n_obs[%d]=%lld out of range (obs_ld %lld)", c, (long long)n_obs[c], (long long)obs_ld);

@@ -27,8 +27,9 @@ def solve_pl(matPar, Length, Time, L, T, dN, plT=1, tol=7, MAX=10000, out=None, 
     snap_raw=True (trpl_solve_pl_resume; the reference's init_mode="continue", pvSimPCR.py:357-358); dN is
     ignored, PL columns before t0 keep what `out` holds.  Pin `kernel` to repeat an uninterrupted run bit for bit
     (the automatic choice looks at the number of steps left).
-    bundle: the reference's max_sims_per_block (strict=True only, TRPL_FLAG_BUNDLE): `bundle` consecutive samples share
-    one convergence test per inner iteration (pvSimPCR.py:211-216), bit-identical to the reference run that way."""
+    bundle: the reference's max_sims_per_block (TRPL_FLAG_BUNDLE, up to 4): `bundle` consecutive samples share one
+    convergence test per inner iteration (pvSimPCR.py:211-216) -- strict=True bit-identical to the reference run that
+    way, otherwise to rounding (L <= 128, one-system kernel)."""
     matPar = _as_f64(matPar)
     if matPar.ndim != 2 or matPar.shape[1] != 12:
         raise ValueError("matPar must have shape (S, 12)")
@@ -98,8 +99,8 @@ def _snapshot_target(arr, S, n, width):
 def pvSim(plI_main, plN_main, plP_main, plE_main, matPar, simPar, iniPar, TPB=None, BPG=None,
           max_sims_per_block=1, init_mode="exp", strict=False, device=0, info=None):
     """pvSimPCR.pvSim (pvSimPCR.py:309).  TPB and BPG (CUDA launch shape) are accepted and ignored: one wavefront owns
-    one system (or two).  max_sims_per_block > 1 -- neighbouring samples sharing one convergence test -- is reproduced
-    bit for bit with strict=True (up to 4) and has no effect otherwise (see below).  init_mode "continue" (a stub in the reference,
+    one system (or two).  max_sims_per_block = 2 .. 4 -- neighbouring samples sharing one convergence test -- is
+    honoured (bit for bit with strict=True).  init_mode "continue" (a stub in the reference,
     pvSimPCR.py:357-358) works here: iniPar = (t0, N5, P5, E5), see solve_pl(resume=...).  plN_main / plP_main / plE_main, the reference's
     debug outputs (recording hook pvSimPCR.py:283-288, disabled there; working form Legacy/pvSim.py:121-126,
     :169-171), are FILLED when they are float64 arrays of shape (S, len(pT), L) / (S, len(pT), L+1): the
@@ -107,10 +108,12 @@ def pvSim(plI_main, plN_main, plP_main, plE_main, matPar, simPar, iniPar, TPB=No
     (None, the dummies bayeslib passes) is ignored as before.  `info`, if a dict, receives 'status' and
     'iters_total'."""
     Length, Time, L, T, plT, pT, tol, MAX = simPar
-    # max_sims_per_block > 1 couples the convergence of neighbouring samples in the reference (pvSimPCR.py:213-216).
-    # strict=True reproduces that bit for bit (up to 4 per bundle); the FAST modes keep every sample independent of
-    # its neighbours -- the result is then the max_sims_per_block = 1 one, within the solver tolerance of the other
-    bundle = int(max_sims_per_block) if strict else 1
+    # max_sims_per_block > 1 couples the convergence of neighbouring samples in the reference (pvSimPCR.py:213-216):
+    # honoured up to 4 per bundle (strict: any L, bit for bit; otherwise L <= 128, to rounding); beyond that -- which the
+    # reference's shared memory cannot hold either -- every sample converges on its own
+    bundle = int(max_sims_per_block)
+    if not (1 <= bundle <= _abi.MAX_BUNDLE and (strict or int(L) <= 128)):
+        bundle = 1
     dx = Length / L
     if init_mode == "exp":                                   # pvSimPCR.py:347-353
         a, l = iniPar

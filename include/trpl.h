@@ -71,13 +71,15 @@ extern "C" {
 #define TRPL_FLAG_SNAP_RAW 0x80   /* trpl_solve_pl_snap / _resume: snapshots in SOLVER units (no division by dx^3 / dx), the
                                      form trpl_solve_pl_resume reads back bit for bit */
 #define TRPL_FLAG_BUNDLE(m) ((uint32_t)(((m) - 1) & 0xF) << 8)
-                                  /* with TRPL_FLAG_STRICT only: the reference's max_sims_per_block = m in [1, 4]
-                                     (pvSimPCR.py:211-216,:258-266; bayes_validate.connect_to_gpu defaults to 3, the most its shared memory holds at L = 128): the samples
-                                     p .. p+m-1 (p a multiple of m, counted inside the call's batch) iterate in lockstep until
-                                     the LARGEST residual of the bundle is below tolerance -- bit-identical to the reference
-                                     run that way (tests/golden/pvsim_bundle.npz), iteration counts and status shared by the
-                                     bundle.  The FAST modes have no such coupling (a sample's result must not depend on its
-                                     neighbours in the batch) and reject the bits */
+                                  /* the reference's max_sims_per_block = m in [1, 4] (pvSimPCR.py:211-216,:258-266;
+                                     bayes_validate.connect_to_gpu defaults to 3, the most its shared memory holds at
+                                     L = 128): the samples p .. p+m-1 (p a multiple of m, counted inside the call's batch)
+                                     iterate in lockstep until the LARGEST residual of the bundle is below tolerance;
+                                     iteration counts and status are the bundle's.  With TRPL_FLAG_STRICT bit-identical to
+                                     the reference run that way (tests/golden/pvsim_bundle.npz), any L; without it the
+                                     one-system fp64 stepper, L <= 128, to rounding (1e-9).  Not with _FP32 / _MIXED /
+                                     _KERNEL_PAIR, and not in the trpl_loglik_multi* calls (a sharded batch would depend on
+                                     where it is cut).  m = 1 (no bits set): every sample converges on its own */
 #define TRPL_FLAG_KERNEL_PAIR 0x10    /* run the two-systems-per-wavefront stepper whatever the launch size (L = 128,
                                         fp64, not STRICT -- anything else is TRPL_ERR_ARG) */
 #define TRPL_FLAG_KERNEL_SINGLE 0x20  /* run the one-system-per-wavefront stepper whatever the launch size */

@@ -1,7 +1,7 @@
 """max_sims_per_block > 1 (shared_array_max pvSimPCR.py:83-90): the reference lets the samples of a
 bundle iterate until the slowest has converged.  STRICT mode reproduces that bit for bit -- against what the reference
-itself produced (tests/golden/pvsim_bundle.npz) and against the oracle on larger batches; FAST modes keep samples
-independent and refuse the flag."""
+itself produced (tests/golden/pvsim_bundle.npz) and against the oracle on larger batches; the FAST one-system kernel
+follows the same path to rounding (L <= 128)."""
 import numpy as np
 import pytest
 
@@ -22,9 +22,16 @@ def test_bundled_strict_is_the_reference_bit_for_bit(gpu, golden):
         gpu.pvSim(plI, None, None, None, X, [length, Time, L, T, 1, None, 7, 10000], ini, (128,), 64, 3,
                   init_mode="points", strict=True)
         assert np.array_equal(plI, g["pl%s3" % tag])
-        # FAST: every sample on its own -- the unbundled result, within the solver tolerance of the bundled one
-        gpu.pvSim(plI, None, None, None, X, [length, Time, L, T, 1, None, 7, 10000], ini, (128,), 64, 3, init_mode="points")
-        assert not np.array_equal(plI, g["pl%s3" % tag]) and np.allclose(plI, g["pl%s3" % tag], rtol=1e-6)
+        # FAST arithmetic, same bundling: the reference's PL to 1e-9, its iteration counts exactly
+        info = {}
+        gpu.pvSim(plI, None, None, None, X, [length, Time, L, T, 1, None, 7, 10000], ini, (128,), 64, 3, init_mode="points",
+                  info=info)
+        assert np.max(np.abs(plI / g["pl%s3" % tag] - 1)) < 1e-9
+        assert np.array_equal(info["iters_total"], g["it%s3" % tag].sum(axis=1))
+        # every sample on its own differs from that by the solver tolerance, not by rounding
+        gpu.pvSim(plI, None, None, None, X, [length, Time, L, T, 1, None, 7, 10000], ini, (128,), 64, 1, init_mode="points")
+        d = np.max(np.abs(plI / g["pl%s3" % tag] - 1))
+        assert 1e-12 < d < 1e-5
 
 
 @pytest.mark.parametrize("m,L", [(2, 128), (3, 128), (4, 128), (3, 32), (2, 256)])
@@ -47,6 +54,26 @@ def test_bundled_strict_vs_oracle_with_short_last_bundle_and_snapshots(gpu, orac
     assert (alone <= it).all() and (alone < it).any()
 
 
+@pytest.mark.parametrize("m,L", [(2, 128), (3, 128), (4, 128), (3, 32), (4, 64)])
+def test_bundled_fast_kernel_vs_oracle(gpu, oracle, m, L):
+    w = gpu.workloads
+    ini, lens = w.twothick(L)
+    S = 5 * m + 2
+    X = w.samples(S, seed=200 + m)[:, :12]
+    T, Time = 64, 1.6
+    want = oracle.pvsim(X, lens[0], Time, L, T, ini[0], mspb=m, nthreads=4)
+    for plT in (1, 4):
+        pl, st, it, _ = gpu.solve_pl(X, lens[0], Time, L, T, ini[0], bundle=m, plT=plT)
+        assert not st.any() and np.array_equal(it, want["iters_total"])
+        assert np.max(np.abs(pl / want["plI"][:, ::plT] - 1)) < 1e-9
+    # fused likelihood through the same bundles
+    obs = [np.log10(want["plI"][0]) + 0.01]
+    info = {}
+    P = gpu.loglik(np.hstack([X, np.zeros((S, 1))]), ini[:1], lens[:1], Time, L, T, obs, info=info, bundle=m)
+    ref = -np.sum((np.log10(want["plI"]) - obs[0]) ** 2, axis=1)
+    assert np.allclose(P, ref, rtol=1e-8) and np.array_equal(info["iters_total"][0], want["iters_total"])
+
+
 def test_a_bundle_that_reaches_max_iter_is_flagged_as_a_whole(gpu, oracle):
     w = gpu.workloads
     ini, lens = w.twothick(128)
@@ -65,8 +92,13 @@ def test_bundle_flag_is_validated(gpu):
     w = gpu.workloads
     ini, lens = w.twothick(128)
     X = w.samples(4, seed=1)[:, :12]
-    with pytest.raises(gpu.TrplError, match="STRICT"):
-        gpu.solve_pl(X, lens[0], 0.5, 128, 20, ini[0], bundle=2)
+    with pytest.raises(gpu.TrplError, match="BUNDLE"):
+        gpu.solve_pl(X, lens[0], 0.5, 128, 20, ini[0], bundle=2, kernel="pair")
+    with pytest.raises(gpu.TrplError, match="BUNDLE"):
+        gpu.solve_pl(X, lens[0], 0.5, 128, 20, ini[0], bundle=2, mixed=True)
+    ini256, lens256 = w.twothick(256)
+    with pytest.raises(gpu.TrplError, match="L <= 128"):
+        gpu.solve_pl(X, lens256[0], 0.5, 256, 20, ini256[0], bundle=2)
     with pytest.raises(ValueError):
         gpu.solve_pl(X, lens[0], 0.5, 128, 20, ini[0], strict=True, bundle=5)
     # bundle = 1 is the plain call
