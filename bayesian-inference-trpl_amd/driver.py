@@ -158,8 +158,15 @@ def loglik(X, init_params, lengths, Time, L, T, obs, tol=7, MAX=10000, plT=1, P=
     return P
 
 
+def _bundle_of(gpu_info, L):
+    """gpu_info['max_sims_per_block'] (bayeslib.py:93) as a TRPL_FLAG_BUNDLE size: 2 .. 4 at L <= 128 are honoured by the
+    default arithmetic, anything else means every sample on its own (model.pvSim applies the same rule)."""
+    m = int(gpu_info.get("max_sims_per_block", 1))
+    return m if (1 <= m <= _abi.MAX_BUNDLE and int(L) <= 128 and gpu_info.get("devices") is None) else 1
+
+
 def _simulate_resident(e_data, P, X, num_curves, thicknesses, sim_params, init_params, normalize, pl_dtype, group,
-                       num_gpus, gpu_id, device, solver_time, err_sq_time, sim_t):
+                       num_gpus, gpu_id, device, solver_time, err_sq_time, sim_t, bundle=1):
     """Several experiments, fused option on: the reference's own loop order -- curves -> sample blocks ->
     experiments (bayeslib.py:117-171) -- with the block's PL matrix kept in HBM: one solve per (curve, block)
     (trpl_solve_pl_dev), then one pass over it per experiment (trpl_loglik_from_pl_dev: normalise, clamp,
@@ -201,7 +208,8 @@ def _simulate_resident(e_data, P, X, num_curves, thicknesses, sim_params, init_p
                 torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
                 tdev.solve_pl_device(mat_d, thicknesses[c], Time, L, T, ini_d[c].contiguous(), pl_d, status=st_d,
-                                     tol=sim_params[6], MAX=sim_params[7], plT=sim_params[4])
+                                     tol=sim_params[6], MAX=sim_params[7], plT=sim_params[4],
+                                     flags=_abi.flag_bundle(bundle))
                 torch.cuda.synchronize(dev)
                 t1 = time.perf_counter()
                 for e, per_curve in enumerate(staged):                        # :171
@@ -249,7 +257,8 @@ def simulate(model, e_data, P, X, plI, plI_int, num_curves, sim_params, init_par
         in_range(exp[0][c]) for exp in e_data for c in range(num_curves))
     if fused and len(e_data) > 1 and gpu_info.get("devices") is None:
         _simulate_resident(e_data, P, X, num_curves, thicknesses, sim_params, init_params, NORMALIZE, pl_dtype,
-                           group, num_gpus, gpu_id, device, solver_time, err_sq_time, sim_t)
+                           group, num_gpus, gpu_id, device, solver_time, err_sq_time, sim_t,
+                           bundle=_bundle_of(gpu_info, L))
         return
     if fused:
         # an experiment sampled exactly on the full simulation grid is compared point by point
@@ -262,7 +271,7 @@ def simulate(model, e_data, P, X, plI, plI_int, num_curves, sim_params, init_par
                 loglik(X[blk:blk + size], init_params, thicknesses, Time, L, T,
                        [exp[1][c] for c in range(num_curves)], tol=sim_params[6], MAX=sim_params[7],
                        P=P[e, blk:blk + size], pl_f32=(pl_dtype == np.float32), normalize=NORMALIZE,
-                       device=device, info=info, devices=gpu_info.get("devices"),
+                       device=device, info=info, devices=gpu_info.get("devices"), bundle=_bundle_of(gpu_info, L),
                        times=None if on_grid else [exp[0][c] for c in range(num_curves)])
                 solver_time[gpu_id] += info["seconds"]
         return

@@ -165,14 +165,15 @@ def _almost_equal(x, x0, threshold=1e-10):
 
 
 def simulate_loglik(X, ini, lengths, time_ns, L, T, e_data, tol=7, MAX=10000, sims_per_gpu=1024,
-                    pl_dtype=np.float32, normalize=False, log_pl=True, nthreads=1):
+                    pl_dtype=np.float32, normalize=False, log_pl=True, nthreads=1, mspb=1):
     """Restatement of bayeslib.simulate's GPU branch (bayeslib.py:83-205) over the oracle:
     curves -> sample blocks -> experiments; fp32 plI buffer (:137); X[:, :-1] to the model and
     X[:, -1] as the log offset (:144,:195); optional self-normalisation (:150-154); log clamp
     (:155-157); bypass or per-row scipy griddata time interpolation (:173-191); prob (:195).
 
     X (S,13) in nm/ns units; ini (C,L); lengths scalar or (C,); e_data = list of
-    (times[c], log10 values[c]) per experiment.  Returns P (n_exp, S).
+    (times[c], log10 values[c]) per experiment.  Returns P (n_exp, S).  mspb: gpu_info["max_sims_per_block"]
+    (:93,:146), bundles restart with every block of sims_per_gpu samples.
     """
     from scipy.interpolate import griddata
     X = _f64(X)
@@ -185,7 +186,7 @@ def simulate_loglik(X, ini, lengths, time_ns, L, T, e_data, tol=7, MAX=10000, si
         for blk in range(0, S, sims_per_gpu):                                  # :131
             size = min(sims_per_gpu, S - blk)
             r = pvsim(X[blk:blk + size, :-1], lengths[c], time_ns, L, T, ini[c], tol=tol, MAX=MAX,
-                      dtype=pl_dtype, nthreads=nthreads)
+                      dtype=pl_dtype, nthreads=nthreads, mspb=mspb)
             pl = r["plI"]
             if normalize:                                                      # :150-154
                 pl = (pl.T / pl.T[0]).T.astype(pl_dtype)

@@ -104,3 +104,28 @@ def test_bundle_flag_is_validated(gpu):
     # bundle = 1 is the plain call
     a = gpu.solve_pl(X, lens[0], 0.5, 128, 20, ini[0], strict=True, bundle=1)[0]
     assert np.array_equal(a, gpu.solve_pl(X, lens[0], 0.5, 128, 20, ini[0], strict=True)[0])
+
+
+def test_simulate_passes_max_sims_per_block_through_all_three_routes(gpu, oracle, golden):
+    """bayeslib.simulate hands gpu_info['max_sims_per_block'] to the model (bayeslib.py:93,:146); the bundles restart
+    with every block of sims_per_gpu samples.  The unfused drop-in loop, the fused single-launch route and the
+    PL-resident multi-experiment route all follow the oracle's restatement run the same way (float64 PL buffer)."""
+    g = golden("bayes_e2e")
+    T, tg, npre = int(g["T"]), g["tgrid"], int(g["npre"])
+    X = g["X"]
+    e_data = [([tg] * 3, list(g["obs0"]), [None] * 3), ([tg[:npre]] * 3, list(g["obs1"]), [None] * 3)]
+    flags = {"load_PL_from_file": False, "log_pl": True, "self_normalize": False}
+    want = oracle.simulate_loglik(X, g["ini"], 2000.0, float(g["time"]), 128, T, [(e[0], e[1]) for e in e_data],
+                                  pl_dtype=np.float64, sims_per_gpu=5, mspb=3, nthreads=4)
+    alone = oracle.simulate_loglik(X, g["ini"], 2000.0, float(g["time"]), 128, T, [(e[0], e[1]) for e in e_data],
+                                   pl_dtype=np.float64, sims_per_gpu=5, nthreads=4)
+    assert np.max(np.abs(want - alone) / np.abs(alone)) > 1e-9               # the bundling is visible in P
+    z = np.zeros(1)
+    for extra in ({}, {"fused": True}):
+        for n_exp in (2, 1):                                                 # 2 fused experiments: the PL-resident route
+            P = np.zeros((n_exp, len(X)))
+            sim_params = [2000.0, float(g["time"]), 128, T, 1, (0,), 7, 10000]
+            info = {"sims_per_gpu": 5, "num_gpus": 1, "max_sims_per_block": 3, "pl_dtype": np.float64, **extra}
+            gpu.simulate(gpu.pvSim, e_data[:n_exp], P, X, [None], [None], 3, sim_params, g["ini"], flags, info, 0,
+                         z.copy(), z.copy(), z.copy())
+            assert np.max(np.abs(P - want[:n_exp]) / np.abs(want[:n_exp])) < 1e-8, (extra, n_exp)
