@@ -179,3 +179,20 @@ def test_concurrent_first_imports_build_the_library_once(tmp_path):
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0 and str(dst) in o, e[-1500:]
     assert (dst / "builds.log").read_text().count("build") == 1
+
+
+def test_bundle_flag_encoding_matches_the_header():
+    """TRPL_FLAG_BUNDLE(m) = ((m - 1) & 0xF) << 8 (include/trpl.h); the binding refuses sizes the kernels do not have."""
+    import re
+    import trpl_amd
+    A = trpl_amd._abi
+    hdr = open(os.path.join(ROOT, "include", "trpl.h")).read()
+    assert re.search(r"#define TRPL_FLAG_BUNDLE\(m\) \(\(uint32_t\)\(\(\(m\) - 1\) & 0xF\) << 8\)", hdr)
+    assert [A.flag_bundle(m) for m in (1, 2, 3, 4)] == [0, 0x100, 0x200, 0x300]
+    for bad in (0, 5, 17):
+        with pytest.raises(ValueError):
+            A.flag_bundle(bad)
+    # no other flag uses bits 8-11
+    others = [A.FLAG_STRICT, A.FLAG_PL_F32, A.FLAG_NORMALIZE, A.FLAG_FP32, A.FLAG_KERNEL_PAIR, A.FLAG_KERNEL_SINGLE,
+              A.FLAG_MIXED, A.FLAG_SNAP_RAW]
+    assert all(f & 0xF00 == 0 for f in others) and len(set(others)) == len(others)
