@@ -16,17 +16,25 @@ LIB_PATH = os.environ.get("TRPL_LIBRARY", os.path.join(_HERE, "libtrpl_hip.so"))
 OK, ERR_ARG, ERR_HIP, ERR_NODEVICE, ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 FLAG_STRICT, FLAG_PL_F32, FLAG_NORMALIZE, FLAG_FP32 = 0x1, 0x2, 0x4, 0x8
 FLAG_KERNEL_PAIR, FLAG_KERNEL_SINGLE, FLAG_MIXED, FLAG_SNAP_RAW = 0x10, 0x20, 0x40, 0x80
-MAX_BUNDLE = 4
+MAX_BUNDLE = 16                 # the flag's range; the library accepts bundle_cap(L) of it
+PL_FLOOR_REL = 1e-12            # TRPL_PL_FLOOR_REL
 
 
-def flag_bundle(m):
-    """TRPL_FLAG_BUNDLE(m): the reference's max_sims_per_block (STRICT only)."""
-    if not 1 <= int(m) <= MAX_BUNDLE:
-        raise ValueError("max_sims_per_block must be in [1, %d]" % MAX_BUNDLE)
+def bundle_cap(L):
+    """Largest TRPL_FLAG_BUNDLE(m) at L nodes (one wavefront per system, one workgroup per bundle): 16 up to
+    L = 64, 4 from L = 128 on (csrc/trpl_common.hpp)."""
+    return 16 if int(L) <= 64 else 4
+
+
+def flag_bundle(m, L=None):
+    """TRPL_FLAG_BUNDLE(m): the reference's max_sims_per_block."""
+    cap = MAX_BUNDLE if L is None else bundle_cap(L)
+    if not 1 <= int(m) <= cap:
+        raise ValueError("max_sims_per_block must be in [1, %d]%s" % (cap, "" if L is None else " at L = %d" % int(L)))
     return ((int(m) - 1) & 0xF) << 8
 
 KERNEL_FAST, KERNEL_FAST_PAIR, KERNEL_STRICT, KERNEL_FP32, KERNEL_MIXED = 0, 1, 2, 3, 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_SNAPS = 16
 
 
@@ -61,22 +69,24 @@ SIGNATURES = {
     "trpl_sse_accumulate": [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _vp, _i32, _pd],
     "trpl_sse_accumulate_dev": [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp],
     "trpl_loglik": [_vp, _i64, _i32, _vp, _f64, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
-                    _vp, _u32, _i32, _pd],
+                    _vp, _vp, _u32, _i32, _pd],
     "trpl_loglik_dev": [_vp, _i64, _i32, _vp, _f64, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp,
-                        _vp, _vp, _u32, _vp],
+                        _vp, _vp, _vp, _u32, _vp],
     "trpl_loglik_obs": [_vp, _i64, _i32, _vp, _f64, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
-                        _vp, _vp, _vp, _u32, _i32, _pd],
+                        _vp, _vp, _vp, _vp, _u32, _i32, _pd],
     "trpl_loglik_obs_dev": [_vp, _i64, _i32, _vp, _f64, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp,
-                            _vp, _vp, _vp, _vp, _u32, _vp],
+                            _vp, _vp, _vp, _vp, _vp, _u32, _vp],
     "trpl_loglik_from_pl_dev": [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _u32, _vp],
     "trpl_loglik_multi": [_vp, _i64, _i32, _vp, _f64, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64,
-                          _vp, _vp, _vp, _vp, _vp, _u32, _vp, _i32, _pd],
+                          _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _i32, _pd],
     "trpl_multi_create": [_vp, _i32, _vp],
     "trpl_multi_destroy": [_vp],
     "trpl_multi_device_count": [_vp],
     "trpl_multi_synchronize": [_vp],
     "trpl_loglik_multi_dev": [_vp, _vp, _i64, _i32, _vp, _f64, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp,
-                              _i64, _vp, _vp, _vp, _vp, _vp, _u32],
+                              _i64, _vp, _vp, _vp, _vp, _vp, _vp, _u32],
+    "trpl_multi_wait_stream": [_vp, _i32, _vp],
+    "trpl_multi_release_stream": [_vp, _i32, _vp],
     "trpl_shard_bounds": [_i64, _i32, _i32, _vp, _vp],
     "trpl_shard_of": [_i64, _i32, _i64],
     "trpl_kernel_variant": [_i64, _i32, _i64, _u32],
@@ -96,10 +106,36 @@ SIGNATURES = {
 _lib = None
 
 
-def _build_if_missing():
-    """A fresh checkout has no shared object (it is git-ignored): build the HIP library in-tree with
-    the package Makefile when hipcc is present.  This is a build step, not a fallback -- the result
-    is the same gfx950 library; set TRPL_AUTOBUILD=0 to forbid it.
+def source_hash():
+    """sha256 of the concatenated sources the library is built from -- csrc/*.hip, csrc/*.hpp (byte order),
+    include/trpl.h, the Makefile: the same bytes in the same order as the Makefile's SRCFILES rule hashes."""
+    import glob
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")))
+    files += [os.path.join(os.path.dirname(_HERE), "include", "trpl.h"), os.path.join(_HERE, "Makefile")]
+    h = hashlib.sha256()
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def library_is_current():
+    """True when libtrpl_hip.so exists and was built from the sources that are here now."""
+    try:
+        with open(LIB_PATH + ".srchash") as fh:
+            return os.path.isfile(LIB_PATH) and fh.read().strip() == source_hash()
+    except OSError:
+        return False
+
+
+def _build_if_stale():
+    """A fresh checkout has no shared object (it is git-ignored), and a prebuilt one may predate an edit of
+    csrc/ or include/: build the HIP library in-tree with the package Makefile when hipcc is present.  This
+    is a build step, not a fallback -- the result is the same gfx950 library; set TRPL_AUTOBUILD=0 to forbid
+    it.  `make` decides by file times; if the hash of the sources still differs from the one recorded at the
+    last link (times not preserved by a copy), everything is rebuilt.
 
     Under torch.distributed.run every rank of a fresh checkout arrives here at once: the build is
     serialised with an exclusive lock file and re-checked under the lock, and the Makefile links under
@@ -113,17 +149,19 @@ def _build_if_missing():
     with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if not os.path.isfile(LIB_PATH):                       # another process may have built it meanwhile
-                subprocess.check_call(["make", "-s", "-j4", "-C", _HERE, "libtrpl_hip.so", "HIPCC=" + hipcc])
+            for force in ([], ["-B"]):
+                if library_is_current():                           # another process may have built it meanwhile
+                    break
+                subprocess.check_call(["make", "-s", "-j4", "-C", _HERE, "all", "HIPCC=" + hipcc] + force)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def ensure_built():
-    """Build the library if it is missing (called when the package is imported, i.e. before anything in
-    this process has touched the GPU)."""
-    if not os.path.isfile(LIB_PATH):
-        _build_if_missing()
+    """Build the library if it is missing OR older than its sources (called when the package is imported, i.e.
+    before anything in this process has touched the GPU)."""
+    if not library_is_current():
+        _build_if_stale()
 
 
 def _share_torch_hip_runtime():
@@ -163,7 +201,7 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.isfile(LIB_PATH):
-            _build_if_missing()
+            _build_if_stale()
         if not os.path.isfile(LIB_PATH):
             raise ImportError("%s not found: build it with `make -C %s` (hipcc, gfx950); "
                               "there is no CPU fallback" % (LIB_PATH, _HERE))

@@ -12,15 +12,10 @@
 
 #include "trpl_common.hpp"
 
-// Development-only ablation switches for tools/iter_bench.hip (cost breakdown of one inner
-// iteration).  Always 0 in the library build; non-zero values compute WRONG results by design.
-//   1: no LDS exchange in the PCR levels   2: reciprocals replaced by a multiply
-//   4: no wave reductions                  8: no DPP shifts
+// Build-time choices, each the measured winner of a same-box A/B; the alternatives
+// compute the same results and stay selectable for re-measurement.
 #ifndef TRPL_FAST_WAVES
 #define TRPL_FAST_WAVES 3      // waves per SIMD the fast stepper is register-budgeted for
-#endif
-#ifndef TRPL_ABLATE
-#define TRPL_ABLATE 0
 #endif
 #ifndef TRPL_CR_HYBRID
 #define TRPL_CR_HYBRID 1      // L = 128 fast solve: in-lane cyclic-reduction step + PCR on 64 unknowns
@@ -234,14 +229,14 @@ __device__ __forceinline__ void static_for(F &&f)
 template <int K, typename T>
 __device__ __forceinline__ T lane_up(T v, int lane)       // value held by lane + K (mod 64)
 {
-    if constexpr (K == 0 || (TRPL_ABLATE & 8) != 0) return v;
+    if constexpr (K == 0) return v;
     else if constexpr (K == 1) return dpp_mov<kDppWaveRol1>(v);
     else return __shfl(v, (lane + K) & 63, 64);
 }
 template <int K, typename T>
 __device__ __forceinline__ T lane_dn(T v, int lane)       // value held by lane - K (mod 64)
 {
-    if constexpr (K == 0 || (TRPL_ABLATE & 8) != 0) return v;
+    if constexpr (K == 0) return v;
     else if constexpr (K == 1) return dpp_mov<kDppWaveRor1>(v);
     else return __shfl(v, (lane - K) & 63, 64);
 }
@@ -281,7 +276,6 @@ __device__ __forceinline__ double dpp_add(double v)
 // Sum of v over the 64 lanes, returned wave-uniform (SGPRs).
 __device__ __forceinline__ double wave_sum(double v)
 {
-    if constexpr ((TRPL_ABLATE & 4) != 0) return uniform_d(v);
     v = dpp_add<0x111, 0xF>(v);          // row_shr:1
     v = dpp_add<0x112, 0xF>(v);          // row_shr:2
     v = dpp_add<0x114, 0xF>(v);          // row_shr:4

@@ -174,7 +174,6 @@ __device__ __forceinline__ void tridiag_solve(T (&ld)[NR], T (&d)[NR], T (&ud)[N
 
 __device__ __forceinline__ double rcp_nr1(double d)      // one Newton step: 2e-15 relative (measured)
 {
-    if constexpr ((TRPL_ABLATE & 2) != 0) return d * 0.999;
     const double r = __builtin_amdgcn_rcp(d);     // (a cvt + v_rcp_f32 + cvt seed measured 4 % slower)
     return __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
 }
@@ -258,9 +257,6 @@ __device__ __forceinline__ void pcr_levels_L(double (&ld)[NR], double (&d)[NR], 
             nbrB_up<double, NR, RF>(nl, l_p, lane);
             nbrB_up<double, NR, RF>(nu, u_p, lane);
             nbrB_up<double, NR, RF>(nB, B_p, lane);
-        } else if constexpr ((TRPL_ABLATE & 1) != 0) {
-#pragma unroll
-            for (int j = 0; j < NR; j++) { l_m[j] = nl[j]; u_m[j] = nu[j]; B_m[j] = nB[j]; l_p[j] = nu[j]; u_p[j] = nl[j]; B_p[j] = -nB[j]; }
         } else {
             xch_store<NR, L>(xch, 0, lane, nl);
             xch_store<NR, L>(xch, 1, lane, nu);
@@ -301,15 +297,10 @@ __device__ __forceinline__ void pcr_solve_L(double (&ld)[NR], double (&d)[NR], d
 #pragma unroll
     for (int j = 0; j < NR; j++) {
         const double c_own = low ? +ud[j] : +ld[j];
-        double d_oth, B_oth, c_oth;
-        if constexpr ((TRPL_ABLATE & 1) != 0) {
-            d_oth = d[j] * 1.5; B_oth = -B[j]; c_oth = c_own;
-        } else {
-            double lo_h, hi_h;
-            pair32(d[j], lo_h, hi_h);  d_oth = low ? hi_h : lo_h;
-            pair32(B[j], lo_h, hi_h);  B_oth = low ? hi_h : lo_h;
-            pair32(c_own, lo_h, hi_h); c_oth = low ? hi_h : lo_h;
-        }
+        double d_oth, B_oth, c_oth, lo_h, hi_h;
+        pair32(d[j], lo_h, hi_h);  d_oth = low ? hi_h : lo_h;
+        pair32(B[j], lo_h, hi_h);  B_oth = low ? hi_h : lo_h;
+        pair32(c_own, lo_h, hi_h); c_oth = low ? hi_h : lo_h;
         det[j] = d[j] * d_oth - c_own * c_oth;
         num[j] = B[j] * d_oth - c_own * B_oth;
     }
@@ -383,18 +374,6 @@ template <int N, typename T> __device__ __forceinline__ T rot32_up(T v) { return
 template <int N, typename T> __device__ __forceinline__ T rot32_dn(T v) { return swizzle<0xC000 | (1 << 10) | (N << 5)>(v); }
 template <typename T> __device__ __forceinline__ T swap16(T v) { return swizzle<(0x10 << 10) | 0x1f>(v); }   // lane ^ 16
 
-// DPP move confined to a row of 16 lanes; a lane whose source lies outside its row receives 0 (bound_ctrl).
-// row_shr:n = 0x110 + n (lane i <- i - n), row_shl:n = 0x100 + n (lane i <- i + n), row_ror:n = 0x120 + n.
-template <int CTRL>
-__device__ __forceinline__ double dpp_row(double v)
-{
-    union { double d; int i[2]; } u, r;
-    u.d = v;
-    r.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], CTRL, 0xF, 0xF, true);
-    r.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], CTRL, 0xF, 0xF, true);
-    return r.d;
-}
-
 // A voided fp64 value only has its HIGH dword cleared (one v_cndmask instead of two): what is left is
 // a denormal (|v| < 2^-1022), finite whatever the original was, and the exact-zero coefficient it
 // meets turns it into +-0.  void_value() clears both dwords where the value itself matters.
@@ -419,22 +398,15 @@ __device__ __forceinline__ T seam_last(T v, int lane)       // v arrived from la
 
 // XM (32-lane systems only) moves exchanges onto ds_swizzle rotates: bit 0 the strides >= 2 and the
 // pair step, bit 1 the stride-1 PCR level, bit 2 the stride-1 fetches of the CR levels.
-// XM = 8 (16-lane systems, one per DPP row): every exchange is a row-confined DPP move; a value from beyond the
-// system's first / last lane arrives as an exact 0, so nothing of a neighbouring system is ever read.
 template <typename T, int S, int WS = 64, bool ISO = false, int XM = 0>
 __device__ __forceinline__ void pcr64_levels(T &A, T &D, T &C, T &Bv, int lane, T *xch)
 {
-    static_assert(XM == 0 || (WS == 32 && XM < 8) || (WS == 16 && XM == 8), "swizzle rotates work on 32-lane groups, row DPP on 16");
+    static_assert(XM == 0 || (WS == 32 && XM < 8), "swizzle rotates work on 32-lane groups");
     if constexpr (S < WS / 2) {
         const T r = rcp_fast<T>(D);
         const T nA = A * r, nC = C * r, nB = Bv * r;
         T Am, Cm, Bm, Ap, Cp, Bp;
-        if constexpr ((TRPL_ABLATE & 1) != 0 && S > 1) {
-            Am = nA; Cm = nC; Bm = nB; Ap = nC; Cp = nA; Bp = -nB;
-        } else if constexpr ((XM & 8) != 0) {       // inside the system's DPP row
-            Am = dpp_row<0x110 + S>(nA); Cm = dpp_row<0x110 + S>(nC); Bm = dpp_row<0x110 + S>(nB);
-            Ap = dpp_row<0x100 + S>(nA); Cp = dpp_row<0x100 + S>(nC); Bp = dpp_row<0x100 + S>(nB);
-        } else if constexpr ((S == 1 && (XM & 2) != 0) || (S > 1 && (XM & 1) != 0)) {   // rotate inside the system's 32 lanes
+        if constexpr ((S == 1 && (XM & 2) != 0) || (S > 1 && (XM & 1) != 0)) {   // rotate inside the system's 32 lanes
             Am = rot32_dn<S>(nA); Cm = rot32_dn<S>(nC); Bm = rot32_dn<S>(nB);
             Ap = rot32_up<S>(nA); Cp = rot32_up<S>(nC); Bp = rot32_up<S>(nB);
         } else if constexpr (S == 1 && TRPL_PCR_S1_LDS == 0) {   // DPP wave rotates
@@ -486,9 +458,7 @@ __device__ __forceinline__ void cr_forward(T (&ld)[NR], T (&d)[NR], T (&ud)[NR],
         }
         // the left neighbour of row 0 is row NR-H of lane l-1
         T aL0, cL0, bL0;
-        if constexpr ((XM & 8) != 0) {
-            aL0 = dpp_row<0x111>(ld[NR - H]); cL0 = dpp_row<0x111>(ud[NR - H]); bL0 = dpp_row<0x111>(B[NR - H]);
-        } else if constexpr ((XM & 4) != 0) {
+        if constexpr ((XM & 4) != 0) {
             aL0 = rot32_dn<1>(ld[NR - H]); cL0 = rot32_dn<1>(ud[NR - H]); bL0 = rot32_dn<1>(B[NR - H]);
         } else {
             aL0 = seam_first<ISO, WS>(lane_dn<1>(ld[NR - H], lane), lane);
@@ -540,11 +510,7 @@ __device__ __forceinline__ void cr_pcr_solve(T (&ld)[NR], T (&d)[NR], T (&ud)[NR
     const bool low = (lane & (WS / 2)) == 0;       // pairs by Cramer's rule, own unknown only
     const T c_own = low ? C : A;
     T D_oth, B_oth, c_oth;
-    if constexpr ((TRPL_ABLATE & 1) != 0) {
-        D_oth = D * T(1.5); B_oth = -Bv; c_oth = c_own;
-    } else if constexpr ((XM & 8) != 0) {         // lane ^ 8 inside the row: row_ror:8
-        D_oth = dpp_row<0x128>(D); B_oth = dpp_row<0x128>(Bv); c_oth = dpp_row<0x128>(c_own);
-    } else if constexpr (WS == 64) {
+    if constexpr (WS == 64) {
         D_oth = partner32(D, low); B_oth = partner32(Bv, low); c_oth = partner32(c_own, low);
     } else if constexpr (WS == 32 && (XM & 1) != 0) {
         D_oth = swap16(D); B_oth = swap16(Bv); c_oth = swap16(c_own);
@@ -555,8 +521,7 @@ __device__ __forceinline__ void cr_pcr_solve(T (&ld)[NR], T (&d)[NR], T (&ud)[NR
     x[0] = X;
     if constexpr (TRPL_PCR_SETPRIO > 0) __builtin_amdgcn_s_setprio(0);
     T xnext;                                       // a system's last lane: times c^ = 0
-    if constexpr ((XM & 8) != 0) xnext = dpp_row<0x101>(X);
-    else if constexpr ((XM & 4) != 0) xnext = rot32_up<1>(X);
+    if constexpr ((XM & 4) != 0) xnext = rot32_up<1>(X);
     else xnext = seam_last<ISO, WS>(lane_up<1>(X, lane), lane);
     cr_backward<T, NR, NR / 2>(ld, ud, B, x, xnext);
 }

@@ -27,6 +27,21 @@ namespace trpl {
 constexpr uint32_t kFlagPlF32 = 0x2;       // TRPL_FLAG_PL_F32
 constexpr uint32_t kFlagNormalize = 0x4;   // TRPL_FLAG_NORMALIZE
 constexpr uint32_t kFlagSnapRaw = 0x80;    // TRPL_FLAG_SNAP_RAW
+constexpr double kPlFloorRel = 1e-12;      // TRPL_PL_FLOOR_REL
+
+// A flagged system's snapshot / checkpoint slots hold a quiet NaN whose payload is its status word (1 + failing step):
+// a resume that finds it in the newest level knows the system was flagged, and when, without iterating on NaNs.
+__device__ __forceinline__ double nan_status(int status)
+{
+    return __longlong_as_double(0x7FF8000000000000LL | (long long)(unsigned)status);
+}
+// status word carried by a checkpoint value (0: a finite value, the system is alive)
+__device__ __forceinline__ int status_of_checkpoint(double v, int64_t t0)
+{
+    if (v == v) return 0;
+    const int payload = (int)(__double_as_longlong(v) & 0x7FFFFFFFLL);
+    return payload ? payload : 1 + (int)t0;          // a NaN of other provenance: flagged at the resume step
+}
 
 // ---- layout dispatch: LAY 0 = blocked/strict, 1 = blocked/fast (L < 128), 2 = interleaved/fast ----
 template <int LAY, int NR, int W>
@@ -178,6 +193,11 @@ struct PlSink {
     // batched emission (FAST): lane k parks column base+k; a batch of up to 64 columns is processed at once
     double pend = 0.0;
     int64_t base = 0;
+    // the cancellation floor (include/trpl.h, floor_col): first compared column whose PL is below kPlFloorRel of the
+    // system's first emitted column -- from there on sum N P - L n0p0 is dominated by rounding in ANY arithmetic
+    double pl_floor = 0.0;
+    int32_t first_floor = -1;
+    bool floor_armed = false;
 
     int lane_;               // lane within the wavefront (== threadIdx.x except in the multi-wave bundled kernel)
 
@@ -204,6 +224,10 @@ struct PlSink {
     // PL columns instead of dividing t by plT every step (a 64-bit scalar division is ~130 instructions).
     __device__ __forceinline__ void emit(int64_t col, double plv)
     {
+        if (a.floor_col && (interp || col < ncol_ll)) {
+            if (!floor_armed) { pl_floor = kPlFloorRel * plv; floor_armed = true; }
+            if (first_floor < 0 && plv < pl_floor) first_floor = (int32_t)col;
+        }
         if (want_pl && lane_ == 0) {                                                   // :281,:393
             if (a.pl_bytes == 4) ((float *)a.pl)[orow * a.pl_ld + col] = (float)plv / (float)cc.plnorm;
             else                 ((double *)a.pl)[orow * a.pl_ld + col] = plv / cc.plnorm;
@@ -269,6 +293,13 @@ struct PlSink {
                 if (a.pl_bytes == 4) ((float *)a.pl)[orow * a.pl_ld + col] = (float)pend / (float)cc.plnorm;
                 else                 ((double *)a.pl)[orow * a.pl_ld + col] = pend / cc.plnorm;
             }
+            if (a.floor_col && base < ncol_ll) {
+                if (!floor_armed) { pl_floor = kPlFloorRel * uniform_d(pend); floor_armed = true; }   // lane 0 holds column `base`
+                if (first_floor < 0) {
+                    const uint64_t below = __builtin_amdgcn_ballot_w64(live && col < ncol_ll && pend < pl_floor);
+                    if (below) first_floor = (int32_t)(base + __builtin_ctzll(below));
+                }
+            }
             if (base < ncol_ll) {                           // bayeslib.py:150-157, probs.py:29-44
                 if (a.flags & kFlagNormalize) {
                     if (base == 0) { pl0_d = uniform_d(v); pl0_f = (float)pl0_d; }
@@ -306,6 +337,7 @@ struct PlSink {
         if (want_ll) a.sse[orow] = status ? __builtin_inf() : sse;
         if (a.status) a.status[orow] = status;
         if (a.iters_total) a.iters_total[orow] = itot;
+        if (a.floor_col) a.floor_col[orow] = first_floor;
     }
 };
 
@@ -347,13 +379,14 @@ struct SnapSink {
     template <int L>
     __device__ __forceinline__ void fail_fill(int64_t row, int status, int lane_in_sys, int lanes)
     {
+        const double mark = nan_status(status);
         for (int i = 0; i < a.n_snap; i++) {
             if ((int64_t)a.snap_t[i] < (int64_t)status - 1) continue;
             const int64_t at = row * a.snap_ld + a.snap_slot[i];
             for (int n = lane_in_sys; n <= L; n += lanes) {
-                if (n < L && a.snapN) a.snapN[at * L + n] = __builtin_nan("");
-                if (n < L && a.snapP) a.snapP[at * L + n] = __builtin_nan("");
-                if (a.snapE) a.snapE[at * (L + 1) + n] = __builtin_nan("");
+                if (n < L && a.snapN) a.snapN[at * L + n] = mark;
+                if (n < L && a.snapP) a.snapP[at * L + n] = mark;
+                if (a.snapE) a.snapE[at * (L + 1) + n] = mark;
             }
         }
     }
@@ -541,7 +574,7 @@ __device__ __forceinline__ void update_field(const MatPar &m, double a0, const d
 // convergence test per inner iteration (pvSimPCR.py:211-216,:258-266).  One workgroup = one bundle, one wavefront per
 // system, the per-system verdicts exchanged through LDS with one barrier per iteration.
 template <int L, bool STRICT, bool SNAP = false, bool MIXED = false, bool BUNDLE = false>
-__global__ void __launch_bounds__(BUNDLE ? 64 * kMaxBundle : 64, BUNDLE ? 1 : ((STRICT || L > 128) ? (L > 256 ? 1 : 2) : TRPL_FAST_WAVES))
+__global__ void __launch_bounds__(BUNDLE ? 64 * bundle_cap(L) : 64, BUNDLE ? 1 : ((STRICT || L > 128) ? (L > 256 ? 1 : 2) : TRPL_FAST_WAVES))
 stepper_kernel(const StepArgs a)
 {
     constexpr int W = L < 64 ? L : 64;
@@ -576,30 +609,32 @@ stepper_kernel(const StepArgs a)
     const int MAX = a.MAX;
 
     // ---- state U^t (registers) and the four older BDF levels U^{t-1..t-4} ----
-    // STRICT keeps the older levels in registers.  FAST keeps those of N and P in LDS as a 4-slot
-    // ring, slot (t' mod 4) holding U^{t'}: nothing is ever moved, a step reads the four slots and
-    // then overwrites the oldest with U^t (8 KB per wave for L = 128); E's stay in registers so
-    // that ring + 3 KB PCR exchange buffer leave room for 3 waves per SIMD (12 x 11 KB <= 160 KB).
+    // STRICT and the small grids (L < 128: one row per lane) keep the older levels in registers.  FAST, L >= 128
+    // keeps those of N and P in LDS as a 4-slot ring, slot (t' mod 4) holding U^{t'}: nothing is ever moved, a
+    // step reads the four slots and then overwrites the oldest with U^t (8 KB per wave for L = 128); E's stay in
+    // registers so that ring + PCR exchange buffer leave room for 3 waves per SIMD.
+    constexpr bool HREG = LAY != 2;                 // N / P history in registers
     constexpr int HSLOT = 2 * NR * 64;              // N and P; the E history stays in registers
     constexpr int XCH = LAY != 2 ? 2 : (TRPL_CR_HYBRID != 0 ? 3 * 64 : 3 * L);   // PCR exchange buffer, doubles
-    constexpr int LDSW = STRICT ? 2 : 4 * HSLOT + XCH;              // per wavefront
-    __shared__ __attribute__((aligned(16))) double lds[LDSW * (BUNDLE ? kMaxBundle : 1)];
+    constexpr int LDSW = HREG ? 2 : 4 * HSLOT + XCH;                // per wavefront
+    __shared__ __attribute__((aligned(16))) double lds[LDSW * (BUNDLE ? bundle_cap(L) : 1)];
     double *hist = lds + (BUNDLE ? wv * LDSW : 0);
-    double *xch = hist + (STRICT ? 0 : 4 * HSLOT);  // PCR exchange buffer (LAY 2)
+    double *xch = hist + (HREG ? 0 : 4 * HSLOT);    // PCR exchange buffer (LAY 2)
     const int hl = lane64;                          // this lane's column of the ring
     double Nk[NR], Pk[NR], Ek[NR];
-    double hN[4][NR], hP[4][NR];                    // STRICT only: levels t-1 .. t-4
+    double hN[4][NR], hP[4][NR];                    // HREG only: levels t-1 .. t-4
     double hE[4][NR];                               // field history, registers in both modes
 #pragma unroll
     for (int j = 0; j < NR; j++) {                 // pvSimPCR.py:356-362
-        const double dn = a.dN[(int64_t)c * L + node_of<LAY, NR, W>(ln, j)] * cc.dx3;
+        // (a resume takes its state from the checkpoint; dN is not read -- it may be NULL there)
+        const double dn = (SNAP && a.resN != nullptr) ? 0.0 : a.dN[(int64_t)c * L + node_of<LAY, NR, W>(ln, j)] * cc.dx3;
         Nk[j] = N0 + dn;
         Pk[j] = P0 + dn;
         Ek[j] = 0.0;
 #pragma unroll
         for (int m = 0; m < 4; m++) {
             hE[m][j] = 0.0;
-            if constexpr (STRICT) { hN[m][j] = 0.0; hP[m][j] = 0.0; }
+            if constexpr (HREG) { hN[m][j] = 0.0; hP[m][j] = 0.0; }
             else { hist[m * HSLOT + (0 * NR + j) * 64 + hl] = 0.0; hist[m * HSLOT + (1 * NR + j) * 64 + hl] = 0.0; }
         }
     }
@@ -609,7 +644,12 @@ stepper_kernel(const StepArgs a)
     SnapSink snap(a, cc);
     int status = 0;
     int64_t itot = 0;
-    __shared__ int agree[2][BUNDLE ? kMaxBundle : 1];     // BUNDLE: the systems' verdicts, double-buffered by iteration parity
+    // BUNDLE: the systems' verdicts, double-buffered by the parity of a counter that runs ACROSS time steps: a wave
+    // can only write buffer b again after the barrier of the iteration in between, which every wave reaches only
+    // after its reads of b (a parity that restarted with each time step had no such edge between the last
+    // iteration of one step and the first of the next)
+    __shared__ int agree[2][BUNDLE ? bundle_cap(L) : 1];
+    unsigned phase = 0;
 
     int64_t t_begin = 0;
     if constexpr (SNAP) {
@@ -624,7 +664,7 @@ stepper_kernel(const StepArgs a)
                 for (int m = 0; m < 4; m++) {      // level t0-1-m
                     const double n_ = a.resN[(r5 + 3 - m) * L + i], p_ = a.resP[(r5 + 3 - m) * L + i];
                     hE[m][j] = a.resE[(r5 + 3 - m) * (L + 1) + i];
-                    if constexpr (STRICT) { hN[m][j] = n_; hP[m][j] = p_; }
+                    if constexpr (HREG) { hN[m][j] = n_; hP[m][j] = p_; }
                     else {
                         const int slot = (int)((a.t0 - 1 - m) & 3) * HSLOT;      // the ring: slot (t' mod 4) holds U^{t'}
                         hist[slot + (0 * NR + j) * 64 + hl] = n_; hist[slot + (1 * NR + j) * 64 + hl] = p_;
@@ -636,6 +676,19 @@ stepper_kernel(const StepArgs a)
     int64_t pl_next = 0, pl_col = 0;               // next step with t % plT == 0 and its PL column t / plT (:276)
     if constexpr (SNAP) {
         if (t_begin > 0) { pl_col = (t_begin + a.plT - 1) / a.plT; pl_next = pl_col * a.plT; sink.base = pl_col; }
+        if (a.resN != nullptr) {
+            // a system that was flagged before the checkpoint (its newest level carries the status word): it keeps that
+            // status and takes no step.  In a bundle the verdict must be the workgroup's (one barrier sequence): the
+            // reference stops the whole block at the first flagged system (pvSimPCR.py:269-274), so do its partners.
+            int st0 = status_of_checkpoint(a.resN[(sink.orow * 5 + 4) * L], a.t0);
+            if constexpr (BUNDLE) {
+                if (lane64 == 0) agree[0][wv] = valid ? st0 : 0;
+                __syncthreads();
+                for (int q = 0; q < a.bundle; q++) if (st0 == 0) st0 = agree[0][q];
+                __syncthreads();
+            }
+            if (st0) { status = st0; t_begin = sink.t_last + 1; }
+        }
     }
     for (int64_t t = t_begin; t <= sink.t_last; t++) {   // tEvol, pvSimPCR.py:237
         if constexpr (SNAP) {                      // the state at time t, before it is stepped (:283-288)
@@ -679,8 +732,8 @@ stepper_kernel(const StepArgs a)
 
         // ---------------- iterate, pvSimPCR.py:93-225 ----------------
         double bN[NR], bP[NR], bE[NR];
-        double cN[NR], cP[NR], cE[NR];             // STRICT only: U^t, to enter the history after the step
-        if constexpr (STRICT) {
+        double cN[NR], cP[NR], cE[NR];             // cN, cP HREG only: U^t, to enter the history after the step
+        if constexpr (HREG) {
 #pragma unroll
             for (int j = 0; j < NR; j++) {         // :128-135
                 cN[j] = Nk[j]; cP[j] = Pk[j]; cE[j] = Ek[j];
@@ -740,10 +793,11 @@ stepper_kernel(const StepArgs a)
             // ---- field on edges 1..L-1 (:205-209) ----
             update_field<LAY, NR, W>(mp, a0, Nk, Pk, bE, Ek, ln);
             if constexpr (BUNDLE) {                // max over the bundle of errN and errP below TOL (:211-216)
-                if (lane64 == 0) agree[iters & 1][wv] = !valid || (okN && okP);
+                if (lane64 == 0) agree[phase & 1][wv] = !valid || (okN && okP);
                 __syncthreads();
                 bool all = true;
-                for (int q = 0; q < a.bundle; q++) all = all && agree[iters & 1][q] != 0;
+                for (int q = 0; q < a.bundle; q++) all = all && agree[phase & 1][q] != 0;
+                phase++;
                 if (all) { it = iters + 1; break; }
             } else {
                 if (okN && okP) { it = iters + 1; break; }                                         // :213-216
@@ -764,10 +818,10 @@ stepper_kernel(const StepArgs a)
 #pragma unroll
             for (int m = 3; m >= 1; m--) {
                 hE[m][j] = hE[m - 1][j];
-                if constexpr (STRICT) { hN[m][j] = hN[m - 1][j]; hP[m][j] = hP[m - 1][j]; }
+                if constexpr (HREG) { hN[m][j] = hN[m - 1][j]; hP[m][j] = hP[m - 1][j]; }
             }
             hE[0][j] = cE[j];
-            if constexpr (STRICT) { hN[0][j] = cN[j]; hP[0][j] = cP[j]; }
+            if constexpr (HREG) { hN[0][j] = cN[j]; hP[0][j] = cP[j]; }
         }
     }
 
@@ -791,7 +845,7 @@ hipError_t launch_stepper(const StepArgs &a, hipStream_t stream)
     static const unsigned lds_pad = getenv("TRPL_LDS_PAD") ? (unsigned)atoi(getenv("TRPL_LDS_PAD")) : 0u;
     const bool snap = a.n_snap > 0 || a.resN != nullptr;   // snapshot / resume code only exists in its own instantiation
     if (a.bundle > 1) {                            // one workgroup per bundle of a.bundle consecutive samples of a curve
-        if (a.bundle > kMaxBundle || (!STRICT && a.L > 128)) return hipErrorInvalidValue;
+        if (a.bundle > bundle_cap(a.L) || (!STRICT && a.L > 128)) return hipErrorInvalidValue;
         grid = dim3((unsigned)(((a.S + a.bundle - 1) / a.bundle) * a.C));
         block = dim3(64 * a.bundle);
         switch (a.L) {

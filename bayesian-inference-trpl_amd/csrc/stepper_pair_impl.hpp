@@ -136,7 +136,8 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
     double Nk[NR], Pk[NR], Ek[NR], hE[4][NR];
 #pragma unroll
     for (int j = 0; j < NR; j++) {                  // pvSimPCR.py:356-362
-        const double dn = a.dN[(int64_t)c * L + NR * ln + j] * cc.dx3;
+        // (a resume takes its state from the checkpoint; dN is not read -- it may be NULL there)
+        const double dn = (SNAP && a.resN != nullptr) ? 0.0 : a.dN[(int64_t)c * L + NR * ln + j] * cc.dx3;
         Nk[j] = N0 + dn;
         Pk[j] = P0 + dn;
         Ek[j] = 0.0;
@@ -155,6 +156,21 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
     bool deadA = false, deadB = !validB;            // dead: flagged non-converged (or the odd tail's duplicate)
     int64_t itotA = 0, itotB = 0;
     SnapSink snap(a, cc);
+    // park this lane's system at equilibrium (finite, converges trivially): a flagged system for the rest of the run
+    auto park = [&](bool mine, double (&cE_)[NR]) {
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            if (mine) {
+                Nk[j] = N0; Pk[j] = P0; Ek[j] = 0.0; cE_[j] = 0.0;
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    hE[m][j] = 0.0;
+                    hist[m * HSLOT + (0 * NR + j) * 64 + lane] = N0;
+                    hist[m * HSLOT + (1 * NR + j) * 64 + lane] = P0;
+                }
+            }
+        }
+    };
 
     int64_t t_begin = 0;
     if constexpr (SNAP) {
@@ -172,6 +188,16 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
                     hist[slot + (0 * NR + j) * 64 + lane] = a.resN[(r5 + 3 - m) * L + i];
                     hist[slot + (1 * NR + j) * 64 + lane] = a.resP[(r5 + 3 - m) * L + i];
                 }
+            }
+            // a system that was flagged before the checkpoint (its newest level carries the status word, see
+            // nan_status): it keeps that status, takes no step and is parked like a system flagged in this run
+            statusA = status_of_checkpoint(a.resN[(sinkA.orow * 5 + 4) * L], a.t0);
+            statusB = validB ? status_of_checkpoint(a.resN[(sinkB.orow * 5 + 4) * L], a.t0) : 0;
+            deadA = statusA != 0;
+            deadB = deadB || statusB != 0;
+            if (statusA || statusB) {
+                double scratch[NR];
+                park(hi ? statusB != 0 : statusA != 0, scratch);
             }
         }
     }
@@ -273,19 +299,7 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
         if (!deadB) { itotB += itB; if (itB >= MAX) { statusB = 1 + (int)t; killB = true; } }
         if (killA || killB) {
             // park the flagged system at equilibrium (finite, converges trivially) for the rest of the run
-            const bool mine = hi ? killB : killA;
-#pragma unroll
-            for (int j = 0; j < NR; j++) {
-                if (mine) {
-                    Nk[j] = N0; Pk[j] = P0; Ek[j] = 0.0; cE[j] = 0.0;
-#pragma unroll
-                    for (int m = 0; m < 4; m++) {
-                        hE[m][j] = 0.0;
-                        hist[m * HSLOT + (0 * NR + j) * 64 + lane] = N0;
-                        hist[m * HSLOT + (1 * NR + j) * 64 + lane] = P0;
-                    }
-                }
-            }
+            park(hi ? killB : killA, cE);
             deadA = deadA || killA;
             deadB = deadB || killB;
         }

@@ -160,7 +160,8 @@ int launch(const trpl::StepArgs &a_in, uint32_t flags, hipStream_t st, int64_t s
         return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_BUNDLE goes with TRPL_FLAG_STRICT or the plain fp64 one-system stepper only");
     if (a.bundle > 1 && !(flags & TRPL_FLAG_STRICT) && a.L > 128)
         return api_fail(TRPL_ERR_UNSUPPORTED, "TRPL_FLAG_BUNDLE without TRPL_FLAG_STRICT is built for L <= 128 (got %d)", a.L);
-    if (a.bundle > trpl::kMaxBundle) return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_BUNDLE(%d): at most %d systems per bundle", a.bundle, trpl::kMaxBundle);
+    if (a.bundle > trpl::bundle_cap(a.L))
+        return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_BUNDLE(%d): at most %d systems per bundle at L = %d", a.bundle, trpl::bundle_cap(a.L), a.L);
     if (flags & TRPL_FLAG_FP32) {
         if (flags & (TRPL_FLAG_STRICT | TRPL_FLAG_MIXED)) return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_FP32 excludes TRPL_FLAG_STRICT and TRPL_FLAG_MIXED");
         if (a.L < 128) return api_fail(TRPL_ERR_UNSUPPORTED, "the fp32 stepper is built for L >= 128 (got %d)", a.L);
@@ -177,13 +178,7 @@ int launch(const trpl::StepArgs &a_in, uint32_t flags, hipStream_t st, int64_t s
         return TRPL_OK;
     }
     if (pick_pair_kernel(a.S * a.C, a.L, steps, flags)) {
-#ifdef TRPL_WITH_QUAD
-        // EXPERIMENT (`make QUAD=1` + TRPL_QUAD=1): four systems per wave instead of two, for same-box A/B
-        static const bool quad = getenv("TRPL_QUAD") && atoi(getenv("TRPL_QUAD"));
-        hipError_t ep = (quad && a.n_snap == 0 && !a.resN) ? trpl::launch_stepper_quad(a, st) : trpl::launch_stepper_pair(a, st);
-#else
         hipError_t ep = trpl::launch_stepper_pair(a, st);
-#endif
         if (ep != hipSuccess) return api_fail(TRPL_ERR_HIP, "pair stepper launch: %s", hipGetErrorString(ep));
         return TRPL_OK;
     }
@@ -238,7 +233,7 @@ static int solve_pl_dev_impl(const double *matpar, int64_t S, double length_nm, 
     if (S > 0x7fffffffLL) return api_fail(TRPL_ERR_ARG, "S too large for one launch");
     trpl::StepArgs a;
     memset(&a, 0, sizeof a);
-    a.X = matpar; a.xld = 12; a.dN = dN ? dN : matpar /* never used on a resume: the state comes from res* */;
+    a.X = matpar; a.xld = 12; a.dN = dN;      // NULL on a resume: the kernels take the state from res* and never read it
     a.pl = plI; a.pl_bytes = pl_elem_bytes; a.pl_ld = pl_ld;
     a.status = status; a.iters_total = iters_total;
     a.S = S; a.C = 1; a.L = L; a.T = T; a.plT = plT; a.MAX = max_iter; a.flags = flags;
@@ -514,7 +509,7 @@ static int loglik_dev_impl(const double *X, int64_t S, int32_t C, const double *
                            int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN,
                            const double *obs, const int32_t *obs_hi, const double *obs_dx, const double *obs_h,
                            int64_t obs_ld, const int64_t *n_obs, double *P, double *sse, int32_t *status,
-                           int64_t *iters_total, uint32_t flags, void *stream)
+                           int64_t *iters_total, int32_t *floor_col, uint32_t flags, void *stream)
 {
     if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
     if (S < 0) return api_fail(TRPL_ERR_ARG, "S must be >= 0");
@@ -529,7 +524,7 @@ static int loglik_dev_impl(const double *X, int64_t S, int32_t C, const double *
     memset(&a, 0, sizeof a);
     a.X = X; a.xld = 13; a.dN = dN; a.obs = obs; a.obs_hi = obs_hi; a.obs_dx = obs_dx; a.obs_h = obs_h;
     a.obs_ld = obs_ld; a.sse = sse;
-    a.status = status; a.iters_total = iters_total;
+    a.status = status; a.iters_total = iters_total; a.floor_col = floor_col;
     a.S = S; a.C = C; a.L = L; a.T = T; a.plT = plT; a.MAX = max_iter; a.flags = flags;
     a.TOL = pow(10.0, -(double)tol_exp);
     const int64_t ncol = T / plT + 1;
@@ -550,28 +545,28 @@ static int loglik_dev_impl(const double *X, int64_t S, int32_t C, const double *
 int trpl_loglik_dev(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns, int32_t L,
                     int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN,
                     const double *obs, int64_t obs_ld, const int64_t *n_obs, double *P, double *sse,
-                    int32_t *status, int64_t *iters_total, uint32_t flags, void *stream)
+                    int32_t *status, int64_t *iters_total, int32_t *floor_col, uint32_t flags, void *stream)
 {
     return loglik_dev_impl(X, S, C, lengths_nm, time_ns, L, T, plT, tol_exp, max_iter, dN, obs, nullptr, nullptr,
-                           nullptr, obs_ld, n_obs, P, sse, status, iters_total, flags, stream);
+                           nullptr, obs_ld, n_obs, P, sse, status, iters_total, floor_col, flags, stream);
 }
 
 int trpl_loglik_obs_dev(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns, int32_t L,
                         int64_t T, int32_t tol_exp, int32_t max_iter, const double *dN, const double *obs,
                         const int32_t *obs_hi, const double *obs_dx, const double *obs_h, int64_t obs_ld,
                         const int64_t *n_obs, double *P, double *sse, int32_t *status, int64_t *iters_total,
-                        uint32_t flags, void *stream)
+                        int32_t *floor_col, uint32_t flags, void *stream)
 {
     if (!obs_hi || !obs_dx || !obs_h) return api_fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h must not be NULL");
     return loglik_dev_impl(X, S, C, lengths_nm, time_ns, L, T, 1, tol_exp, max_iter, dN, obs, obs_hi, obs_dx, obs_h,
-                           obs_ld, n_obs, P, sse, status, iters_total, flags, stream);
+                           obs_ld, n_obs, P, sse, status, iters_total, floor_col, flags, stream);
 }
 
 static int loglik_host_impl(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns, int32_t L,
                             int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN,
                             const double *obs, const int32_t *obs_hi, const double *obs_dx, const double *obs_h,
                             int64_t obs_ld, const int64_t *n_obs, double *P, double *sse, int32_t *status,
-                            int64_t *iters_total, uint32_t flags, int32_t device, double *seconds)
+                            int64_t *iters_total, int32_t *floor_col, uint32_t flags, int32_t device, double *seconds)
 {
     if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
     if (S < 0) return api_fail(TRPL_ERR_ARG, "S must be >= 0");
@@ -587,7 +582,7 @@ static int loglik_host_impl(const double *X, int64_t S, int32_t C, const double 
     if (interp) {                                    // the brackets are host data here: validate them
         if (int rc = check_brackets(obs_hi, obs_dx, obs_h, C, obs_ld, n_obs, T)) return rc;
     }
-    DevBuf dX, ddN, dobs, dhi, ddx, dh, dP, dsse, dst, dit;
+    DevBuf dX, ddN, dobs, dhi, ddx, dh, dP, dsse, dst, dit, dfl;
     const size_t nsys = (size_t)S * C, nobs = (size_t)C * obs_ld;
     HIP_TRY(dX.alloc((size_t)S * 13 * 8, cs.st));
     HIP_TRY(ddN.alloc((size_t)C * L * 8, cs.st));
@@ -596,6 +591,7 @@ static int loglik_host_impl(const double *X, int64_t S, int32_t C, const double 
     HIP_TRY(dsse.alloc(nsys * 8, cs.st));
     HIP_TRY(dst.alloc(nsys * 4, cs.st));
     HIP_TRY(dit.alloc(nsys * 8, cs.st));
+    if (floor_col) HIP_TRY(dfl.alloc(nsys * 4, cs.st));
     HIP_TRY(hipMemcpyAsync(dX.p, X, (size_t)S * 13 * 8, hipMemcpyHostToDevice, cs.st));
     HIP_TRY(hipMemcpyAsync(ddN.p, dN, (size_t)C * L * 8, hipMemcpyHostToDevice, cs.st));
     HIP_TRY(hipMemcpyAsync(dobs.p, obs, nobs * 8, hipMemcpyHostToDevice, cs.st));
@@ -610,8 +606,8 @@ static int loglik_host_impl(const double *X, int64_t S, int32_t C, const double 
     if (int rc = loglik_dev_impl(dX.as<double>(), S, C, lengths_nm, time_ns, L, T, plT, tol_exp, max_iter,
                                  ddN.as<double>(), dobs.as<double>(), interp ? dhi.as<int32_t>() : nullptr,
                                  interp ? ddx.as<double>() : nullptr, interp ? dh.as<double>() : nullptr, obs_ld, n_obs,
-                                 dP.as<double>(), dsse.as<double>(), dst.as<int32_t>(), dit.as<int64_t>(), flags,
-                                 cs.st))
+                                 dP.as<double>(), dsse.as<double>(), dst.as<int32_t>(), dit.as<int64_t>(),
+                                 dfl.as<int32_t>(), flags, cs.st))
         return rc;
     HIP_TRY(hipStreamSynchronize(cs.st));
     if (seconds) *seconds = now_s() - t0;
@@ -619,6 +615,7 @@ static int loglik_host_impl(const double *X, int64_t S, int32_t C, const double 
     if (sse) HIP_TRY(hipMemcpyAsync(sse, dsse.p, nsys * 8, hipMemcpyDeviceToHost, cs.st));
     if (status) HIP_TRY(hipMemcpyAsync(status, dst.p, nsys * 4, hipMemcpyDeviceToHost, cs.st));
     if (iters_total) HIP_TRY(hipMemcpyAsync(iters_total, dit.p, nsys * 8, hipMemcpyDeviceToHost, cs.st));
+    if (floor_col) HIP_TRY(hipMemcpyAsync(floor_col, dfl.p, nsys * 4, hipMemcpyDeviceToHost, cs.st));
     HIP_TRY(hipStreamSynchronize(cs.st));        // the copies back have landed (and their errors surface here)
     return TRPL_OK;
 }
@@ -626,21 +623,21 @@ static int loglik_host_impl(const double *X, int64_t S, int32_t C, const double 
 int trpl_loglik(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns, int32_t L,
                 int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN, const double *obs,
                 int64_t obs_ld, const int64_t *n_obs, double *P, double *sse, int32_t *status,
-                int64_t *iters_total, uint32_t flags, int32_t device, double *seconds)
+                int64_t *iters_total, int32_t *floor_col, uint32_t flags, int32_t device, double *seconds)
 {
     return loglik_host_impl(X, S, C, lengths_nm, time_ns, L, T, plT, tol_exp, max_iter, dN, obs, nullptr, nullptr,
-                            nullptr, obs_ld, n_obs, P, sse, status, iters_total, flags, device, seconds);
+                            nullptr, obs_ld, n_obs, P, sse, status, iters_total, floor_col, flags, device, seconds);
 }
 
 int trpl_loglik_obs(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns, int32_t L,
                     int64_t T, int32_t tol_exp, int32_t max_iter, const double *dN, const double *obs,
                     const int32_t *obs_hi, const double *obs_dx, const double *obs_h, int64_t obs_ld,
                     const int64_t *n_obs, double *P, double *sse, int32_t *status, int64_t *iters_total,
-                    uint32_t flags, int32_t device, double *seconds)
+                    int32_t *floor_col, uint32_t flags, int32_t device, double *seconds)
 {
     if (!obs_hi || !obs_dx || !obs_h) return api_fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h must not be NULL");
     return loglik_host_impl(X, S, C, lengths_nm, time_ns, L, T, 1, tol_exp, max_iter, dN, obs, obs_hi, obs_dx, obs_h,
-                            obs_ld, n_obs, P, sse, status, iters_total, flags, device, seconds);
+                            obs_ld, n_obs, P, sse, status, iters_total, floor_col, flags, device, seconds);
 }
 
 /* ------------------------------------------------------------------ posterior core ------ */

@@ -7,8 +7,12 @@ namespace trpl {
 
 constexpr int kMaxCurves = 16;
 constexpr int kMaxSnaps = 16;      // state snapshots per solve (trpl_solve_pl_snap)
-constexpr int kMaxBundle = 4;      // systems sharing one convergence test (TRPL_FLAG_BUNDLE), one wavefront each in one workgroup
-                                   // (the reference's 48 KB of shared memory hold 3 systems at L = 128, pvSimPCR.py:113-125)
+// Systems sharing one convergence test (TRPL_FLAG_BUNDLE): one wavefront each in ONE workgroup, so at most 16 (1024
+// threads).  The reference takes what its 48 KB of shared memory hold at 14 L-vectors per system (pvSimPCR.py:113-125):
+// 3 at L = 128, 6 at L = 64, 13 at L = 32.  Grids of up to 64 nodes keep a lane's whole state in a few registers and
+// run the full 16; from L = 128 on the register budget of a wavefront (and, FAST, its 9.7 KB history ring) allows 4.
+constexpr int kMaxBundle = 16;
+__host__ __device__ constexpr int bundle_cap(int L) { return L <= 64 ? 16 : 4; }
 
 // Per-curve constants, computed on the host exactly as pvSim does (pvSimPCR.py:314-331,
 // :393) so that the in-kernel products X[s][i] * scales[i] round like numpy's.
@@ -32,6 +36,7 @@ struct StepArgs {
     double *sse;            // [C][S] out (likelihood mode) or nullptr
     int32_t *status;        // [C][S] out or nullptr
     int64_t *iters_total;   // [C][S] out or nullptr
+    int32_t *floor_col;     // [C][S] out or nullptr: first compared PL column below 1e-12 of the system's first column, or -1
     // state snapshots (solve mode only; pvSimPCR.py:283-288, Legacy/pvSim.py:121-126,:169-171): the state
     // at time step snap_t[i] goes to slot snap_slot[i] of snapN/snapP [C*S][snap_ld][L], snapE [..][L+1]
     double *snapN, *snapP, *snapE;
@@ -52,7 +57,7 @@ struct StepArgs {
     int32_t MAX;
     int32_t pl_bytes;       // 4 or 8
     uint32_t flags;         // TRPL_FLAG_*
-    int32_t bundle;         // STRICT: the reference's max_sims_per_block, 1 .. kMaxBundle (1: every system converges alone)
+    int32_t bundle;         // the reference's max_sims_per_block, 1 .. bundle_cap(L) (1: every system converges alone)
     int32_t n_snap;         // number of (step, slot) pairs below, steps strictly ascending
     int32_t snap_ld;        // slots per system in the snapshot arrays
     int32_t snap_t[kMaxSnaps];
@@ -67,7 +72,6 @@ hipError_t launch_stepper_f32(const StepArgs &a, hipStream_t stream);   // stepp
 hipError_t launch_stepper_mixed(const StepArgs &a, hipStream_t stream);  // stepper_mixed.hip, L >= 128
 // stepper_pair.hip: FAST, L = 128, two systems per wavefront
 hipError_t launch_stepper_pair(const StepArgs &a, hipStream_t stream);
-hipError_t launch_stepper_quad(const StepArgs &a, hipStream_t stream);   // stepper_quad.hip, L = 128, four systems per wave
 
 // likelihood.hip
 hipError_t launch_log10_clamp(void *x, int elem_bytes, int64_t rows, int64_t cols, int64_t ld, double mn,

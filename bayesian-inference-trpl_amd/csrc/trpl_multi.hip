@@ -22,13 +22,14 @@ namespace {
 int shard_loglik(const double *X, int64_t n, int32_t C, const double *lengths_nm, double time_ns, int32_t L, int64_t T,
                  int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN, const double *obs,
                  const int32_t *obs_hi, const double *obs_dx, const double *obs_h, int64_t obs_ld, const int64_t *n_obs,
-                 double *P, double *sse, int32_t *status, int64_t *iters_total, uint32_t flags, hipStream_t st)
+                 double *P, double *sse, int32_t *status, int64_t *iters_total, int32_t *floor_col, uint32_t flags,
+                 hipStream_t st)
 {
     if (obs_hi)
         return trpl_loglik_obs_dev(X, n, C, lengths_nm, time_ns, L, T, tol_exp, max_iter, dN, obs, obs_hi, obs_dx, obs_h,
-                                   obs_ld, n_obs, P, sse, status, iters_total, flags, st);
+                                   obs_ld, n_obs, P, sse, status, iters_total, floor_col, flags, st);
     return trpl_loglik_dev(X, n, C, lengths_nm, time_ns, L, T, plT, tol_exp, max_iter, dN, obs, obs_ld, n_obs, P, sse,
-                           status, iters_total, flags, st);
+                           status, iters_total, floor_col, flags, st);
 }
 
 }  // namespace
@@ -58,11 +59,11 @@ struct Shard {                       // one device's share of the samples; relea
     int dev = 0;
     int64_t lo = 0, hi = 0;
     hipStream_t st = nullptr;
-    DevBuf X, dN, obs, ohi, odx, oh, P, sse, status, iters;
+    DevBuf X, dN, obs, ohi, odx, oh, P, sse, status, iters, floorc;
     ~Shard()
     {
         (void)hipSetDevice(dev);
-        for (DevBuf *b : {&X, &dN, &obs, &ohi, &odx, &oh, &P, &sse, &status, &iters}) b->release();   // stream-ordered frees
+        for (DevBuf *b : {&X, &dN, &obs, &ohi, &odx, &oh, &P, &sse, &status, &iters, &floorc}) b->release();   // stream-ordered frees
         if (st) {
             (void)hipStreamSynchronize(st);
             (void)hipStreamDestroy(st);
@@ -78,7 +79,7 @@ int trpl_loglik_multi(const double *X, int64_t S, int32_t C, const double *lengt
                       int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter, const double *dN, const double *obs,
                       const int32_t *obs_hi, const double *obs_dx, const double *obs_h, int64_t obs_ld,
                       const int64_t *n_obs, double *P, double *sse, int32_t *status, int64_t *iters_total,
-                      uint32_t flags, const int32_t *devices, int32_t n_devices, double *seconds)
+                      int32_t *floor_col, uint32_t flags, const int32_t *devices, int32_t n_devices, double *seconds)
 {
     if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
     if (S < 0) return api_fail(TRPL_ERR_ARG, "S must be >= 0");
@@ -132,6 +133,7 @@ int trpl_loglik_multi(const double *X, int64_t S, int32_t C, const double *lengt
             HIP_TRY(q.X.alloc((size_t)n * 13 * 8, q.st)); HIP_TRY(q.dN.alloc((size_t)C * L * 8, q.st)); HIP_TRY(q.obs.alloc(nobs * 8, q.st));
             HIP_TRY(q.P.alloc((size_t)n * 8, q.st)); HIP_TRY(q.sse.alloc(nsys * 8, q.st)); HIP_TRY(q.status.alloc(nsys * 4, q.st));
             HIP_TRY(q.iters.alloc(nsys * 8, q.st));
+            if (floor_col) HIP_TRY(q.floorc.alloc(nsys * 4, q.st));
             HIP_TRY(hipMemcpyAsync(q.X.p, X + q.lo * 13, (size_t)n * 13 * 8, hipMemcpyHostToDevice, q.st));
             HIP_TRY(hipMemcpyAsync(q.dN.p, dN, (size_t)C * L * 8, hipMemcpyHostToDevice, q.st));
             HIP_TRY(hipMemcpyAsync(q.obs.p, obs, nobs * 8, hipMemcpyHostToDevice, q.st));
@@ -146,7 +148,7 @@ int trpl_loglik_multi(const double *X, int64_t S, int32_t C, const double *lengt
                                 q.obs.as<double>(), interp ? q.ohi.as<int32_t>() : nullptr,
                                 interp ? q.odx.as<double>() : nullptr, interp ? q.oh.as<double>() : nullptr, obs_ld,
                                 n_obs, q.P.as<double>(), q.sse.as<double>(), q.status.as<int32_t>(),
-                                q.iters.as<int64_t>(), flags, q.st);
+                                q.iters.as<int64_t>(), q.floorc.as<int32_t>(), flags, q.st);
         }();
     }
     // only now the copies back: a device-to-host copy into pageable memory blocks the calling thread until
@@ -168,6 +170,9 @@ int trpl_loglik_multi(const double *X, int64_t S, int32_t C, const double *lengt
                                          hipMemcpyDeviceToHost, q.st));
             if (iters_total)
                 HIP_TRY(hipMemcpy2DAsync(iters_total + q.lo, (size_t)S * 8, q.iters.p, (size_t)n * 8, (size_t)n * 8, C,
+                                         hipMemcpyDeviceToHost, q.st));
+            if (floor_col)
+                HIP_TRY(hipMemcpy2DAsync(floor_col + q.lo, (size_t)S * 4, q.floorc.p, (size_t)n * 4, (size_t)n * 4, C,
                                          hipMemcpyDeviceToHost, q.st));
             return TRPL_OK;
         }();
@@ -257,6 +262,7 @@ struct trpl_multi {
     int n = 0;
     std::vector<int> dev;
     std::vector<hipStream_t> st;
+    std::vector<hipEvent_t> ev_in, ev_out; // ordering against the caller's streams (trpl_multi_wait_stream / _release_stream)
     std::vector<ncclComm_t> comm;
     std::vector<double *> send, recv;      // per device: padded shard [widest], gathered [n * widest]
     int64_t cap = 0;                       // `widest` the scratch buffers were sized for
@@ -292,20 +298,27 @@ int trpl_multi_create(const int32_t *devices, int32_t n_devices, trpl_multi_t **
     if (!api->dl) { delete h; return api_fail(TRPL_ERR_UNSUPPORTED, "RCCL could not be loaded: %s", api->why); }
     int prev = 0;
     (void)hipGetDevice(&prev);
+    h->ev_in.assign(n_devices, nullptr); h->ev_out.assign(n_devices, nullptr);
     h->st.assign(n_devices, nullptr); h->send.assign(n_devices, nullptr); h->recv.assign(n_devices, nullptr);
     h->comm.assign(n_devices, nullptr);
     int rc = [&]() -> int {
         for (int r = 0; r < n_devices; r++) {
             HIP_TRY(hipSetDevice(h->dev[r]));
             HIP_TRY(hipStreamCreateWithFlags(&h->st[r], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&h->ev_in[r], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&h->ev_out[r], hipEventDisableTiming));
         }
         RCCL_TRY(api->CommInitAll(h->comm.data(), n_devices, h->dev.data()));
         return TRPL_OK;
     }();
     (void)hipSetDevice(prev);
     if (rc != TRPL_OK) {
-        for (int r = 0; r < n_devices; r++)
-            if (h->st[r]) { (void)hipSetDevice(h->dev[r]); (void)hipStreamDestroy(h->st[r]); }
+        for (int r = 0; r < n_devices; r++) {
+            (void)hipSetDevice(h->dev[r]);
+            if (h->st[r]) (void)hipStreamDestroy(h->st[r]);
+            if (h->ev_in[r]) (void)hipEventDestroy(h->ev_in[r]);
+            if (h->ev_out[r]) (void)hipEventDestroy(h->ev_out[r]);
+        }
         (void)hipSetDevice(prev);
         delete h;
         return rc;
@@ -343,18 +356,48 @@ int trpl_multi_destroy(trpl_multi_t *h)
         if (h->send[r]) (void)hipFree(h->send[r]);
         if (h->recv[r]) (void)hipFree(h->recv[r]);
         if (h->st[r]) (void)hipStreamDestroy(h->st[r]);
+        if (h->ev_in[r]) (void)hipEventDestroy(h->ev_in[r]);
+        if (h->ev_out[r]) (void)hipEventDestroy(h->ev_out[r]);
     }
     (void)hipSetDevice(prev);
     delete h;
     return TRPL_OK;
 }
 
+// The handle works on its own non-blocking streams, which nothing orders against the streams the caller filled X /
+// obs / dN on or reads P_full from.  These two calls add that order without a host wait:
+//   wait_stream:    everything the handle enqueues on rank r from now on runs after what `stream` holds now
+//   release_stream: everything `stream` is given from now on runs after what the handle has enqueued on rank r
+static int multi_order(trpl_multi_t *h, int32_t rank, void *stream, bool handle_waits)
+{
+    if (!h) return api_fail(TRPL_ERR_ARG, "handle must not be NULL");
+    if (rank < 0 || rank >= h->n) return api_fail(TRPL_ERR_ARG, "rank %d out of range (%d devices)", rank, h->n);
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    int rc = [&]() -> int {
+        HIP_TRY(hipSetDevice(h->dev[rank]));
+        hipStream_t user = (hipStream_t)stream;
+        if (handle_waits) {
+            HIP_TRY(hipEventRecord(h->ev_in[rank], user));
+            HIP_TRY(hipStreamWaitEvent(h->st[rank], h->ev_in[rank], 0));
+        } else {
+            HIP_TRY(hipEventRecord(h->ev_out[rank], h->st[rank]));
+            HIP_TRY(hipStreamWaitEvent(user, h->ev_out[rank], 0));
+        }
+        return TRPL_OK;
+    }();
+    (void)hipSetDevice(prev);
+    return rc;
+}
+int trpl_multi_wait_stream(trpl_multi_t *h, int32_t rank, void *stream) { return multi_order(h, rank, stream, true); }
+int trpl_multi_release_stream(trpl_multi_t *h, int32_t rank, void *stream) { return multi_order(h, rank, stream, false); }
+
 int trpl_loglik_multi_dev(trpl_multi_t *h, const double *const *X, int64_t S, int32_t C, const double *lengths_nm,
                           double time_ns, int32_t L, int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter,
                           const double *const *dN, const double *const *obs, const int32_t *const *obs_hi,
                           const double *const *obs_dx, const double *const *obs_h, int64_t obs_ld, const int64_t *n_obs,
                           double *const *P_full, double *const *sse, int32_t *const *status, int64_t *const *iters_total,
-                          uint32_t flags)
+                          int32_t *const *floor_col, uint32_t flags)
 {
     if (!h) return api_fail(TRPL_ERR_ARG, "handle must not be NULL");
     if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
@@ -407,7 +450,8 @@ int trpl_loglik_multi_dev(trpl_multi_t *h, const double *const *X, int64_t S, in
             if (int e = shard_loglik(X[r], nr, C, lengths_nm, time_ns, L, T, plT, tol_exp, max_iter, dN[r], obs[r],
                                      interp ? obs_hi[r] : nullptr, interp ? obs_dx[r] : nullptr,
                                      interp ? obs_h[r] : nullptr, obs_ld, n_obs, h->send[r], sse_r,
-                                     status ? status[r] : nullptr, iters_total ? iters_total[r] : nullptr, flags, h->st[r]))
+                                     status ? status[r] : nullptr, iters_total ? iters_total[r] : nullptr,
+                                     floor_col ? floor_col[r] : nullptr, flags, h->st[r]))
                 return e;
         }
         // ONE collective: all-gather of `widest` fp64 per rank (RCCL over xGMI), straight into P_full when the

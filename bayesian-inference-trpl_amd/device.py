@@ -19,10 +19,11 @@ def _chk(t, dtype, name):
 
 
 def loglik_device(X, init_params, lengths, Time, L, T, obs, n_obs, P, sse, status=None, iters_total=None,
-                  tol=7, MAX=10000, plT=1, flags=0):
+                  tol=7, MAX=10000, plT=1, flags=0, floor_col=None):
     """trpl_loglik_dev on the current device and stream.  X (S,13) f64, init_params (C,L) f64,
     obs (C,obs_ld) f64, P (S,) f64 accumulated in place, sse (C,S) f64 out, optional status
-    (C,S) int32 and iters_total (C,S) int64.  lengths / n_obs are host sequences."""
+    (C,S) int32, iters_total (C,S) int64 and floor_col (C,S) int32 (first compared PL column below the
+    cancellation floor, -1 if none: include/trpl.h).  lengths / n_obs are host sequences."""
     import torch
     S, Cn = X.shape[0], init_params.shape[0]
     if X.shape[1] != 13 or init_params.shape[1] != L or obs.shape[0] != Cn or tuple(sse.shape) != (Cn, S) \
@@ -35,11 +36,12 @@ def loglik_device(X, init_params, lengths, Time, L, T, obs, n_obs, P, sse, statu
         int(MAX), _chk(init_params, torch.float64, "init_params"), _chk(obs, torch.float64, "obs"),
         obs.shape[1], _abi.ptr(n_obs), _chk(P, torch.float64, "P"), _chk(sse, torch.float64, "sse"),
         None if status is None else _chk(status, torch.int32, "status"),
-        None if iters_total is None else _chk(iters_total, torch.int64, "iters_total"), int(flags), _stream()))
+        None if iters_total is None else _chk(iters_total, torch.int64, "iters_total"),
+        None if floor_col is None else _chk(floor_col, torch.int32, "floor_col"), int(flags), _stream()))
 
 
 def loglik_obs_device(X, init_params, lengths, Time, L, T, obs, obs_hi, obs_dx, obs_h, n_obs, P, sse, status=None,
-                      iters_total=None, tol=7, MAX=10000, flags=0):
+                      iters_total=None, tol=7, MAX=10000, flags=0, floor_col=None):
     """trpl_loglik_obs_dev: observation times off the simulation grid.  obs / obs_dx / obs_h (C,obs_ld)
     f64 and obs_hi (C,obs_ld) int32 are the bracketing arrays of driver.bracket_times, on the device."""
     import torch
@@ -55,7 +57,8 @@ def loglik_obs_device(X, init_params, lengths, Time, L, T, obs, obs_hi, obs_dx, 
         _chk(obs_hi, torch.int32, "obs_hi"), _chk(obs_dx, torch.float64, "obs_dx"), _chk(obs_h, torch.float64, "obs_h"),
         obs.shape[1], _abi.ptr(n_obs), _chk(P, torch.float64, "P"), _chk(sse, torch.float64, "sse"),
         None if status is None else _chk(status, torch.int32, "status"),
-        None if iters_total is None else _chk(iters_total, torch.int64, "iters_total"), int(flags), _stream()))
+        None if iters_total is None else _chk(iters_total, torch.int64, "iters_total"),
+        None if floor_col is None else _chk(floor_col, torch.int32, "floor_col"), int(flags), _stream()))
 
 
 def solve_pl_device(matPar, Length, Time, L, T, dN, plI, status=None, iters_total=None, tol=7, MAX=10000, plT=1,
@@ -277,11 +280,16 @@ class MultiDevice:
         return tab
 
     def loglik(self, X, init_params, lengths, Time, L, T, obs, n_obs, P_full, sse=None, status=None, iters_total=None,
-               obs_hi=None, obs_dx=None, obs_h=None, tol=7, MAX=10000, plT=1, flags=0):
+               obs_hi=None, obs_dx=None, obs_h=None, tol=7, MAX=10000, plT=1, flags=0, floor_col=None, order=True):
         """Enqueue the sharded fused likelihood + the all-gather; returns at once (synchronize() waits).
         X: list of per-device shards (n_r, 13); init_params / obs (/ obs_hi, obs_dx, obs_h): lists of per-device
-        replicas; P_full: list of per-device (S,) f64 outputs; sse / status / iters_total: optional lists of
-        per-device (C, n_r) outputs.  S is taken from P_full."""
+        replicas; P_full: list of per-device (S,) f64 outputs; sse / status / iters_total / floor_col: optional
+        lists of per-device (C, n_r) outputs.  S is taken from P_full.
+        The handle works on its own streams.  With order=True (default) they are ordered on the device against
+        torch's current stream of every device, both ways (trpl_multi_wait_stream before, trpl_multi_release_stream
+        after): inputs just produced on the torch stream are complete when the solve reads them, and work given to
+        the torch stream afterwards sees the gathered P_full -- no host wait.  order=False leaves both to the
+        caller (synchronize())."""
         import torch
         S = int(P_full[0].shape[0])
         Cn = int(init_params[0].shape[0])
@@ -294,8 +302,13 @@ class MultiDevice:
                                   ("iters_total", iters_total, torch.int64)):
                 if lst is not None and tuple(lst[r].shape) != (Cn, hi - lo):
                     raise ValueError("%s[%d] must be (C, %d)" % (name, r, hi - lo))
+            if floor_col is not None and tuple(floor_col[r].shape) != (Cn, hi - lo):
+                raise ValueError("floor_col[%d] must be (C, %d)" % (r, hi - lo))
         lengths = np.ascontiguousarray(np.broadcast_to(np.asarray(lengths, dtype=np.float64), (Cn,)))
         n_obs = np.ascontiguousarray(np.broadcast_to(np.asarray(n_obs, dtype=np.int64), (Cn,)))
+        streams = [torch.cuda.current_stream(torch.device("cuda", d)).cuda_stream for d in self.devices] if order else []
+        for r, s in enumerate(streams):
+            _abi.check(_abi.lib().trpl_multi_wait_stream(self._h, r, s))
         _abi.check(_abi.lib().trpl_loglik_multi_dev(
             self._h, self._table(X, torch.float64, "X"), S, Cn, _abi.ptr(lengths), float(Time), int(L), int(T), int(plT),
             int(tol), int(MAX), self._table(init_params, torch.float64, "init_params"),
@@ -303,4 +316,7 @@ class MultiDevice:
             self._table(obs_dx, torch.float64, "obs_dx", True), self._table(obs_h, torch.float64, "obs_h", True),
             int(obs[0].shape[1]), _abi.ptr(n_obs), self._table(P_full, torch.float64, "P_full"),
             self._table(sse, torch.float64, "sse", True), self._table(status, torch.int32, "status", True),
-            self._table(iters_total, torch.int64, "iters_total", True), int(flags)))
+            self._table(iters_total, torch.int64, "iters_total", True),
+            self._table(floor_col, torch.int32, "floor_col", True), int(flags)))
+        for r, s in enumerate(streams):
+            _abi.check(_abi.lib().trpl_multi_release_stream(self._h, r, s))

@@ -124,9 +124,10 @@ def loglik(X, init_params, lengths, Time, L, T, obs, tol=7, MAX=10000, plT=1, P=
     sse = np.zeros((Cn, S))
     status = np.zeros((Cn, S), dtype=np.int32)
     iters = np.zeros((Cn, S), dtype=np.int64)
+    floor_col = np.full((Cn, S), -1, dtype=np.int32)
     flags = (_abi.FLAG_STRICT if strict else 0) | (_abi.FLAG_PL_F32 if pl_f32 else 0) \
         | (_abi.FLAG_NORMALIZE if normalize else 0) | (_abi.FLAG_FP32 if fp32 else 0) | _abi.kernel_flag(kernel) \
-        | (_abi.FLAG_MIXED if mixed else 0) | _abi.flag_bundle(bundle)
+        | (_abi.FLAG_MIXED if mixed else 0) | _abi.flag_bundle(bundle, L)
     sec = _abi.C.c_double(0.0)
     lib = _abi.lib()
     if devices is not None:
@@ -140,29 +141,31 @@ def loglik(X, init_params, lengths, Time, L, T, obs, tol=7, MAX=10000, plT=1, P=
                                    int(tol), int(MAX), _abi.ptr(ini), _abi.ptr(obs_mat),
                                    _abi.ptr(hi_mat) if off else None, _abi.ptr(dx_mat) if off else None,
                                    _abi.ptr(h_mat) if off else None, obs_ld, _abi.ptr(n_obs), _abi.ptr(P),
-                                   _abi.ptr(sse), _abi.ptr(status), _abi.ptr(iters), flags,
+                                   _abi.ptr(sse), _abi.ptr(status), _abi.ptr(iters), _abi.ptr(floor_col), flags,
                                    None if dev is None else _abi.ptr(dev), 0 if dev is None else len(dev),
                                    _abi.C.byref(sec))
     elif times is None:
         rc = lib.trpl_loglik(_abi.ptr(X), S, Cn, _abi.ptr(lengths), float(Time), int(L), int(T), int(plT), int(tol),
                              int(MAX), _abi.ptr(ini), _abi.ptr(obs_mat), obs_ld, _abi.ptr(n_obs), _abi.ptr(P),
-                             _abi.ptr(sse), _abi.ptr(status), _abi.ptr(iters), flags, int(device), _abi.C.byref(sec))
+                             _abi.ptr(sse), _abi.ptr(status), _abi.ptr(iters), _abi.ptr(floor_col), flags, int(device),
+                             _abi.C.byref(sec))
     else:
         rc = lib.trpl_loglik_obs(_abi.ptr(X), S, Cn, _abi.ptr(lengths), float(Time), int(L), int(T), int(tol), int(MAX),
                                  _abi.ptr(ini), _abi.ptr(obs_mat), _abi.ptr(hi_mat), _abi.ptr(dx_mat), _abi.ptr(h_mat),
                                  obs_ld, _abi.ptr(n_obs), _abi.ptr(P), _abi.ptr(sse), _abi.ptr(status),
-                                 _abi.ptr(iters), flags, int(device), _abi.C.byref(sec))
+                                 _abi.ptr(iters), _abi.ptr(floor_col), flags, int(device), _abi.C.byref(sec))
     _abi.check(rc)
     if info is not None:
-        info.update(sse=sse, status=status, iters_total=iters, seconds=sec.value)
+        info.update(sse=sse, status=status, iters_total=iters, floor_col=floor_col, seconds=sec.value)
     return P
 
 
 def _bundle_of(gpu_info, L):
-    """gpu_info['max_sims_per_block'] (bayeslib.py:93) as a TRPL_FLAG_BUNDLE size: 2 .. 4 at L <= 128 are honoured by the
-    default arithmetic, anything else means every sample on its own (model.pvSim applies the same rule)."""
+    """gpu_info['max_sims_per_block'] (bayeslib.py:93) as a TRPL_FLAG_BUNDLE size: 2 .. 4 at L = 128 and 2 .. 16 on
+    grids of up to 64 nodes are honoured by the default arithmetic, anything else means every sample on its own
+    (model.pvSim applies the same rule)."""
     m = int(gpu_info.get("max_sims_per_block", 1))
-    return m if (1 <= m <= _abi.MAX_BUNDLE and int(L) <= 128 and gpu_info.get("devices") is None) else 1
+    return m if (1 <= m <= _abi.bundle_cap(L) and int(L) <= 128 and gpu_info.get("devices") is None) else 1
 
 
 def _simulate_resident(e_data, P, X, num_curves, thicknesses, sim_params, init_params, normalize, pl_dtype, group,
@@ -209,7 +212,7 @@ def _simulate_resident(e_data, P, X, num_curves, thicknesses, sim_params, init_p
                 t0 = time.perf_counter()
                 tdev.solve_pl_device(mat_d, thicknesses[c], Time, L, T, ini_d[c].contiguous(), pl_d, status=st_d,
                                      tol=sim_params[6], MAX=sim_params[7], plT=sim_params[4],
-                                     flags=_abi.flag_bundle(bundle))
+                                     flags=_abi.flag_bundle(bundle, L))
                 torch.cuda.synchronize(dev)
                 t1 = time.perf_counter()
                 for e, per_curve in enumerate(staged):                        # :171

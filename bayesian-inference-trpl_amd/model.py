@@ -53,7 +53,7 @@ def solve_pl(matPar, Length, Time, L, T, dN, plT=1, tol=7, MAX=10000, out=None, 
     iters = np.zeros(S, dtype=np.int64)
     sec = _abi.C.c_double(0.0)
     flags = (_abi.FLAG_STRICT if strict else 0) | (_abi.FLAG_FP32 if fp32 else 0) | _abi.kernel_flag(kernel) \
-        | (_abi.FLAG_MIXED if mixed else 0) | (_abi.FLAG_SNAP_RAW if snap_raw else 0) | _abi.flag_bundle(bundle)
+        | (_abi.FLAG_MIXED if mixed else 0) | (_abi.FLAG_SNAP_RAW if snap_raw else 0) | _abi.flag_bundle(bundle, L)
     steps = None
     n_snap = 0
     if snap_steps is not None and len(snap_steps):
@@ -99,8 +99,8 @@ def _snapshot_target(arr, S, n, width):
 def pvSim(plI_main, plN_main, plP_main, plE_main, matPar, simPar, iniPar, TPB=None, BPG=None,
           max_sims_per_block=1, init_mode="exp", strict=False, device=0, info=None):
     """pvSimPCR.pvSim (pvSimPCR.py:309).  TPB and BPG (CUDA launch shape) are accepted and ignored: one wavefront owns
-    one system (or two).  max_sims_per_block = 2 .. 4 -- neighbouring samples sharing one convergence test -- is
-    honoured (bit for bit with strict=True).  init_mode "continue" (a stub in the reference,
+    one system (or two).  max_sims_per_block = 2 .. 4 (2 .. 16 on grids of up to 64 nodes) -- neighbouring samples
+    sharing one convergence test -- is honoured (bit for bit with strict=True).  init_mode "continue" (a stub in the reference,
     pvSimPCR.py:357-358) works here: iniPar = (t0, N5, P5, E5), see solve_pl(resume=...).  plN_main / plP_main / plE_main, the reference's
     debug outputs (recording hook pvSimPCR.py:283-288, disabled there; working form Legacy/pvSim.py:121-126,
     :169-171), are FILLED when they are float64 arrays of shape (S, len(pT), L) / (S, len(pT), L+1): the
@@ -109,10 +109,11 @@ def pvSim(plI_main, plN_main, plP_main, plE_main, matPar, simPar, iniPar, TPB=No
     'iters_total'."""
     Length, Time, L, T, plT, pT, tol, MAX = simPar
     # max_sims_per_block > 1 couples the convergence of neighbouring samples in the reference (pvSimPCR.py:213-216):
-    # honoured up to 4 per bundle (strict: any L, bit for bit; otherwise L <= 128, to rounding); beyond that -- which the
-    # reference's shared memory cannot hold either -- every sample converges on its own
+    # honoured up to 4 per bundle from L = 128 on and 16 up to L = 64 (strict: any L, bit for bit; otherwise L <= 128, to
+    # rounding) -- the reference's 48 KB of shared memory hold 3 / 6 / 13 at L = 128 / 64 / 32; beyond that every sample
+    # converges on its own
     bundle = int(max_sims_per_block)
-    if not (1 <= bundle <= _abi.MAX_BUNDLE and (strict or int(L) <= 128)):
+    if not (1 <= bundle <= _abi.bundle_cap(L) and (strict or int(L) <= 128)):
         bundle = 1
     dx = Length / L
     if init_mode == "exp":                                   # pvSimPCR.py:347-353

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TRPL_ABI_VERSION 2
+#define TRPL_ABI_VERSION 3
 
 /* status codes */
 #define TRPL_OK 0
@@ -71,9 +71,12 @@ extern "C" {
 #define TRPL_FLAG_SNAP_RAW 0x80   /* trpl_solve_pl_snap / _resume: snapshots in SOLVER units (no division by dx^3 / dx), the
                                      form trpl_solve_pl_resume reads back bit for bit */
 #define TRPL_FLAG_BUNDLE(m) ((uint32_t)(((m) - 1) & 0xF) << 8)
-                                  /* the reference's max_sims_per_block = m in [1, 4] (pvSimPCR.py:211-216,:258-266;
-                                     bayes_validate.connect_to_gpu defaults to 3, the most its shared memory holds at
-                                     L = 128): the samples p .. p+m-1 (p a multiple of m, counted inside the call's batch)
+                                  /* the reference's max_sims_per_block = m (pvSimPCR.py:211-216,:258-266;
+                                     bayes_validate.connect_to_gpu defaults to 3).  The reference takes what its 48 KB of
+                                     shared memory hold (pvSimPCR.py:113-125: 3 systems at L = 128, 6 at L = 64, 13 at
+                                     L = 32); here m <= 16 for L <= 64 and m <= 4 from L = 128 on (one wavefront per system,
+                                     one workgroup per bundle; a larger m is TRPL_ERR_ARG).
+                                     The samples p .. p+m-1 (p a multiple of m, counted inside the call's batch)
                                      iterate in lockstep until the LARGEST residual of the bundle is below tolerance;
                                      iteration counts and status are the bundle's.  With TRPL_FLAG_STRICT bit-identical to
                                      the reference run that way (tests/golden/pvsim_bundle.npz), any L; without it the
@@ -159,12 +162,15 @@ int trpl_solve_pl_snap_dev(const double *matpar, int64_t S, double length_nm, do
  * trpl_solve_pl_resume -- pvSim's init_mode = "continue" (pvSimPCR.py:357-358), which is only a stub in the
  * reference (`pass`: dN is undefined and the call raises; the commented block :294-306 shows the intent: keep the
  * last time levels in plN / plP / plE and start the next call from them).  Here: the time loop starts at step
- * t0 >= 4 from the five newest BDF levels U^{t0-4} .. U^{t0} of every system,
+ * t0 >= 4 (dN is not an argument: the state comes from the checkpoint) from the five newest BDF levels U^{t0-4} .. U^{t0} of every system,
  *   resN, resP [S][5][L], resE [S][5][L+1] fp64 in SOLVER units, level m <-> step t0 - 4 + m,
  * exactly what trpl_solve_pl_snap[_dev] stores for snap_steps = {t0-4, .., t0} under TRPL_FLAG_SNAP_RAW.
  * A run of T steps and a run to t0 followed by a resume to T give the same PL columns, snapshots and status
  * BIT FOR BIT, in every arithmetic mode (tested): a long window can be cut into segments, checkpointed and
- * continued.  Iteration totals add up once the step at t0 is counted once: the time loop runs t = 0 .. T
+ * continued.  That includes a system that was flagged BEFORE t0: the snapshot slots of a flagged system hold a
+ * quiet NaN whose low 31 payload bits are its status word (1 + failing step), the resume finds it in the newest
+ * level, reports that status, takes no step (iters_total 0 for this call) and fills PL columns >= the failing
+ * step and later snapshots with NaN, as the uninterrupted run does.  Iteration totals add up once the step at t0 is counted once: the time loop runs t = 0 .. T
  * inclusive (pvSimPCR.py:237, the step taken at t = T is computed and dropped), so the run to t0 has taken the
  * step that the resume takes again (a resume with T = t0 counts exactly that step).  PL columns before t0 / plT are not written (the caller's buffer keeps
  * them); snapshot steps before t0 are ignored; iters_total counts the steps taken by this call.
@@ -235,19 +241,35 @@ int trpl_loglik_from_pl_dev(const void *plI, int32_t elem_bytes, int64_t rows, i
  *   lengths [C] host doubles (per-curve thickness, bayeslib.py:109-119)
  *   dN      [C][L], obs [C][obs_ld] log10 observations, n_obs [C] host int64 (<= T/plT + 1)
  *   sse     [C][S] out;  status [C][S] out (nullable);  iters_total [C][S] out (nullable)
+ *   floor_col [C][S] out (nullable): the CANCELLATION FLOOR indicator.  PL = B (sum_i N_i P_i - L n0 p0) is a
+ *           difference of two nearly equal numbers once the excess carriers have decayed: below
+ *           TRPL_PL_FLOOR_REL = 1e-12 of the curve's first compared value what any fp64 evaluation returns is set
+ *           by the rounding of the 128-term sum, not by the physics -- the reference's own value there is the sign
+ *           and size of its last rounding error (pvSimPCR.py:276-281), often negative, i.e. clamped to DBL_MIN by
+ *           fastlog (bayeslib.py:157).  floor_col[c][s] is the first compared PL column (observation index; the
+ *           grid step with off-grid observations) whose value is below that floor, or -1 if none is.
+ *           CONTRACT: systems with floor_col = -1 agree with the reference evaluation (TRPL_FLAG_STRICT, which
+ *           reproduces it bit for bit) to <= 1e-9 in every compared PL value and <= 1e-8 in sse; for the others the
+ *           columns from floor_col on are arbitrary in BOTH (the default arithmetic forms the per-node excess
+ *           fma(N_i, P_i, -n0p0) before summing and typically lands on the DBL_MIN clamp; the reference order
+ *           returns rounding noise of either sign), their sse is dominated by those columns (>= 1e5 per clamped
+ *           point), and a caller who wants to compare such samples across implementations should drop them or
+ *           truncate the window at floor_col.  Measured on the reference's prior box over its full 2 us window:
+ *           3.8 % of the samples (all with tau_n <= 10 ns); none over the first 200 ns.
  * C <= 16 per call.
  * ------------------------------------------------------------------------------------- */
+#define TRPL_PL_FLOOR_REL 1e-12
 int trpl_loglik(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns,
                 int32_t L, int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter,
                 const double *dN, const double *obs, int64_t obs_ld, const int64_t *n_obs,
-                double *P, double *sse, int32_t *status, int64_t *iters_total, uint32_t flags,
-                int32_t device, double *seconds);
+                double *P, double *sse, int32_t *status, int64_t *iters_total, int32_t *floor_col,
+                uint32_t flags, int32_t device, double *seconds);
 
 int trpl_loglik_dev(const double *X, int64_t S, int32_t C, const double *lengths_nm /*host*/,
                     double time_ns, int32_t L, int64_t T, int32_t plT, int32_t tol_exp,
                     int32_t max_iter, const double *dN, const double *obs, int64_t obs_ld,
                     const int64_t *n_obs /*host*/, double *P, double *sse, int32_t *status,
-                    int64_t *iters_total, uint32_t flags, void *stream);
+                    int64_t *iters_total, int32_t *floor_col, uint32_t flags, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * trpl_loglik_obs -- trpl_loglik for observation times that do NOT lie on the simulation grid:
@@ -263,13 +285,14 @@ int trpl_loglik_obs(const double *X, int64_t S, int32_t C, const double *lengths
                     int32_t L, int64_t T, int32_t tol_exp, int32_t max_iter, const double *dN,
                     const double *obs, const int32_t *obs_hi, const double *obs_dx, const double *obs_h,
                     int64_t obs_ld, const int64_t *n_obs, double *P, double *sse, int32_t *status,
-                    int64_t *iters_total, uint32_t flags, int32_t device, double *seconds);
+                    int64_t *iters_total, int32_t *floor_col, uint32_t flags, int32_t device, double *seconds);
 
 int trpl_loglik_obs_dev(const double *X, int64_t S, int32_t C, const double *lengths_nm /*host*/,
                         double time_ns, int32_t L, int64_t T, int32_t tol_exp, int32_t max_iter,
                         const double *dN, const double *obs, const int32_t *obs_hi, const double *obs_dx,
                         const double *obs_h, int64_t obs_ld, const int64_t *n_obs /*host*/, double *P,
-                        double *sse, int32_t *status, int64_t *iters_total, uint32_t flags, void *stream);
+                        double *sse, int32_t *status, int64_t *iters_total, int32_t *floor_col, uint32_t flags,
+                        void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * trpl_loglik_multi -- trpl_loglik / trpl_loglik_obs over several devices from ONE host thread:
@@ -291,8 +314,8 @@ int trpl_loglik_multi(const double *X, int64_t S, int32_t C, const double *lengt
                       int32_t L, int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter,
                       const double *dN, const double *obs, const int32_t *obs_hi, const double *obs_dx,
                       const double *obs_h, int64_t obs_ld, const int64_t *n_obs, double *P, double *sse,
-                      int32_t *status, int64_t *iters_total, uint32_t flags, const int32_t *devices,
-                      int32_t n_devices, double *seconds);
+                      int32_t *status, int64_t *iters_total, int32_t *floor_col /*[C][S], nullable*/,
+                      uint32_t flags, const int32_t *devices, int32_t n_devices, double *seconds);
 
 /* ---------------------------------------------------------------------------------------
  * trpl_multi_* / trpl_loglik_multi_dev -- the device-resident multi-GPU form: ONE process drives
@@ -311,7 +334,7 @@ int trpl_loglik_multi(const double *X, int64_t S, int32_t C, const double *lengt
  *     dN[r]     [C][L]      replicated;  obs[r] [C][obs_ld] replicated (obs_hi / obs_dx / obs_h: tables of
  *               replicated bracket arrays, or all three NULL for on-grid observations)
  *     P_full[r] [S]         OUT on every device: P[s] = - sum_c sse[c][s], the all-gathered likelihoods
- *     sse[r], status[r], iters_total[r]  [C][n_r] per-shard outputs (tables nullable, as are entries)
+ *     sse[r], status[r], iters_total[r], floor_col[r]  [C][n_r] per-shard outputs (tables nullable, as are entries)
  *   Everything is enqueued on the handle's streams (solve, all-gather, unpadding) and the call returns
  *   without waiting; trpl_multi_synchronize waits for all devices.  The kernel variant is pinned from the
  *   whole batch, as in trpl_loglik_multi.
@@ -327,7 +350,18 @@ int trpl_loglik_multi_dev(trpl_multi_t *handle, const double *const *X, int64_t 
                           const int32_t *const *obs_hi, const double *const *obs_dx, const double *const *obs_h,
                           int64_t obs_ld, const int64_t *n_obs /*host*/, double *const *P_full,
                           double *const *sse, int32_t *const *status, int64_t *const *iters_total,
-                          uint32_t flags);
+                          int32_t *const *floor_col, uint32_t flags);
+/* The handle's streams are its own (non-blocking): nothing orders them against the streams on which the caller
+ * produced X / dN / obs or will consume P_full.  Either wait on the host (trpl_multi_synchronize on both sides), or
+ * add the order on the device:
+ *   trpl_multi_wait_stream(h, r, s):    what the handle enqueues on rank r from now on runs after what stream s (a
+ *                                       hipStream_t of devices[r]; NULL = its default stream) holds now -- call it for
+ *                                       every rank BEFORE trpl_loglik_multi_dev when the inputs were just written on s;
+ *   trpl_multi_release_stream(h, r, s): what s is given from now on runs after what the handle has enqueued on rank r
+ *                                       -- call it AFTER trpl_loglik_multi_dev before reading P_full[r] on s.
+ * (trpl_amd.device.MultiDevice.loglik does both with torch's current stream of each device.) */
+int trpl_multi_wait_stream(trpl_multi_t *handle, int32_t rank, void *stream);
+int trpl_multi_release_stream(trpl_multi_t *handle, int32_t rank, void *stream);
 
 /* [lo, hi) of shard `shard` of S samples cut into n_shards contiguous ranges; the first S % n_shards
  * shards hold one more.  The same rule shards the samples over ranks in the one-process-per-GPU

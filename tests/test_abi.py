@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(trpl):
     for n in names:
         assert hasattr(dll, n), n
     assert set(trpl._abi.SIGNATURES) == set(names)       # the binding covers the whole header
-    assert dll.trpl_abi_version() == 2
+    assert dll.trpl_abi_version() == 3
 
 
 def test_cites_reference_interfaces():
@@ -139,7 +139,9 @@ def test_round2_entry_points_validate_without_a_device(trpl):
     assert lib.trpl_multi_device_count(None) == 0 and lib.trpl_multi_destroy(None) == A.OK
     assert lib.trpl_multi_synchronize(None) == A.ERR_ARG
     assert lib.trpl_loglik_multi_dev(None, None, 0, 1, None, 1.0, 128, 10, 1, 7, 10, None, None, None, None, None, 1,
-                                     None, None, None, None, None, 0) == A.ERR_ARG
+                                     None, None, None, None, None, None, 0) == A.ERR_ARG
+    assert lib.trpl_multi_wait_stream(None, 0, None) == A.ERR_ARG
+    assert lib.trpl_multi_release_stream(None, 0, None) == A.ERR_ARG
 
 
 def test_library_has_no_link_dependency_on_rccl():
@@ -150,35 +152,71 @@ def test_library_has_no_link_dependency_on_rccl():
     assert "NEEDED" in out and "rccl" not in out.lower()
 
 
-def test_concurrent_first_imports_build_the_library_once(tmp_path):
-    """Three processes that find no shared object at the same time (the ranks of torch.distributed.run on a
-    fresh checkout): the build is serialised by a lock file and re-checked under it -- one build runs, every
-    process loads a complete library.  The package tree is copied and its Makefile replaced by a stand-in that
-    logs each invocation and installs the real library the way the real Makefile does (temporary name + rename)."""
+def _copy_package_with_stand_in_makefile(tmp_path):
+    """The package tree (python + csrc + include/trpl.h) copied under tmp_path with a Makefile that logs each link and
+    installs the REAL library the way the real Makefile does (temporary name + rename, then the source-hash stamp)."""
     import shutil
-    import subprocess
-    import sys
     pkg = os.path.join(ROOT, "bayesian-inference-trpl_amd")
     dst = tmp_path / "pkg"
     dst.mkdir()
     for f in os.listdir(pkg):
         if f.endswith(".py"):
             shutil.copy(os.path.join(pkg, f), dst / f)
+    shutil.copytree(os.path.join(pkg, "csrc"), dst / "csrc", ignore=shutil.ignore_patterns("build"))
+    (tmp_path / "include").mkdir()
+    shutil.copy(os.path.join(ROOT, "include", "trpl.h"), tmp_path / "include" / "trpl.h")
     real = os.path.join(pkg, "libtrpl_hip.so")
     (dst / "Makefile").write_text(
-        "libtrpl_hip.so:\n\techo build >> builds.log; sleep 1; cp %s $@.tmp.$$$$ && mv -f $@.tmp.$$$$ $@\n" % real)
+        "SRCFILES := $(sort $(wildcard csrc/*.hip csrc/*.hpp)) ../include/trpl.h Makefile\n"
+        "all: libtrpl_hip.so libtrpl_hip.so.srchash\n"
+        "libtrpl_hip.so: $(SRCFILES)\n\techo build >> builds.log; sleep 1; cp %s $@.tmp.$$$$ && mv -f $@.tmp.$$$$ $@\n"
+        "libtrpl_hip.so.srchash: libtrpl_hip.so $(SRCFILES)\n\tcat $(SRCFILES) | sha256sum | cut -d' ' -f1 > $@\n" % real)
     code = ("import importlib.util, sys\n"
             "spec = importlib.util.spec_from_file_location('trpl_tmp', %r, submodule_search_locations=[%r])\n"
             "m = importlib.util.module_from_spec(spec); sys.modules['trpl_tmp'] = m; spec.loader.exec_module(m)\n"
             "assert m._abi.lib().trpl_abi_version() == m._abi.ABI_VERSION\n"
+            "assert m._abi.library_is_current()\n"
             "print('loaded', m._abi.LIB_PATH)\n") % (str(dst / "__init__.py"), str(dst))
     env = {k: v for k, v in os.environ.items() if k not in ("TRPL_LIBRARY", "TRPL_AUTOBUILD")}
+    return dst, code, env
+
+
+def test_concurrent_first_imports_build_the_library_once(tmp_path):
+    """Three processes that find no shared object at the same time (the ranks of torch.distributed.run on a
+    fresh checkout): the build is serialised by a lock file and re-checked under it -- one build runs, every
+    process loads a complete library."""
+    import subprocess
+    import sys
+    dst, code, env = _copy_package_with_stand_in_makefile(tmp_path)
     procs = [subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                               text=True) for _ in range(3)]
     outs = [p.communicate(timeout=300) for p in procs]
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0 and str(dst) in o, e[-1500:]
     assert (dst / "builds.log").read_text().count("build") == 1
+
+
+def test_a_library_older_than_its_sources_is_rebuilt_not_used(tmp_path):
+    """ensure_built() compares the hash of csrc/ + include/trpl.h + Makefile with the one recorded at the last link
+    (libtrpl_hip.so.srchash): an import after an edit rebuilds, a second import does not, and a stamp that disagrees
+    although `make` sees nothing to do (file times lost in a copy) forces a full rebuild."""
+    import subprocess
+    import sys
+    dst, code, env = _copy_package_with_stand_in_makefile(tmp_path)
+    run = lambda: subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    builds = lambda: (dst / "builds.log").read_text().count("build")
+    r = run(); assert r.returncode == 0, r.stderr[-1500:]
+    assert builds() == 1
+    r = run(); assert r.returncode == 0 and builds() == 1               # current: nothing is built
+    with open(dst / "csrc" / "trpl_common.hpp", "a") as fh:              # an edit of a kernel header
+        fh.write("// edited\n")
+    r = run(); assert r.returncode == 0, r.stderr[-1500:]
+    assert builds() == 2
+    (dst / "libtrpl_hip.so.srchash").write_text("0" * 64 + "\n")        # stamp disagrees, every file time is in order
+    later = os.path.getmtime(dst / "libtrpl_hip.so") + 5
+    os.utime(dst / "libtrpl_hip.so", (later, later)); os.utime(dst / "libtrpl_hip.so.srchash", (later + 1, later + 1))
+    r = run(); assert r.returncode == 0, r.stderr[-1500:]
+    assert builds() == 3
 
 
 def test_bundle_flag_encoding_matches_the_header():
@@ -188,10 +226,15 @@ def test_bundle_flag_encoding_matches_the_header():
     A = trpl_amd._abi
     hdr = open(os.path.join(ROOT, "include", "trpl.h")).read()
     assert re.search(r"#define TRPL_FLAG_BUNDLE\(m\) \(\(uint32_t\)\(\(\(m\) - 1\) & 0xF\) << 8\)", hdr)
-    assert [A.flag_bundle(m) for m in (1, 2, 3, 4)] == [0, 0x100, 0x200, 0x300]
-    for bad in (0, 5, 17):
+    assert [A.flag_bundle(m) for m in (1, 2, 3, 4, 16)] == [0, 0x100, 0x200, 0x300, 0xF00]
+    for bad in (0, 17):
         with pytest.raises(ValueError):
             A.flag_bundle(bad)
+    # the library takes 16 systems per bundle up to L = 64 and 4 from L = 128 on (csrc/trpl_common.hpp: bundle_cap)
+    assert [A.bundle_cap(L) for L in (8, 32, 64, 128, 512)] == [16, 16, 16, 4, 4]
+    assert A.flag_bundle(13, 32) == 0xC00 and A.flag_bundle(4, 128) == 0x300
+    with pytest.raises(ValueError):
+        A.flag_bundle(5, 128)
     # no other flag uses bits 8-11
     others = [A.FLAG_STRICT, A.FLAG_PL_F32, A.FLAG_NORMALIZE, A.FLAG_FP32, A.FLAG_KERNEL_PAIR, A.FLAG_KERNEL_SINGLE,
               A.FLAG_MIXED, A.FLAG_SNAP_RAW]

@@ -34,11 +34,11 @@ def test_bundled_strict_is_the_reference_bit_for_bit(gpu, golden):
         assert 1e-12 < d < 1e-5
 
 
-@pytest.mark.parametrize("m,L", [(2, 128), (3, 128), (4, 128), (3, 32), (2, 256)])
+@pytest.mark.parametrize("m,L", [(2, 128), (3, 128), (4, 128), (3, 32), (2, 256), (6, 64), (13, 32), (16, 64), (16, 8)])
 def test_bundled_strict_vs_oracle_with_short_last_bundle_and_snapshots(gpu, oracle, m, L):
     w = gpu.workloads
     ini, lens = w.twothick(L)
-    S = 4 * m + 1                                            # a last bundle of one system
+    S = (4 if m <= 4 else 2) * m + 1                         # a last bundle of one system
     X = w.samples(S, seed=100 + m)[:, :12]
     T, Time = 48, 1.2
     want = oracle.pvsim(X, lens[0], Time, L, T, ini[0], mspb=m, nthreads=4)
@@ -54,11 +54,11 @@ def test_bundled_strict_vs_oracle_with_short_last_bundle_and_snapshots(gpu, orac
     assert (alone <= it).all() and (alone < it).any()
 
 
-@pytest.mark.parametrize("m,L", [(2, 128), (3, 128), (4, 128), (3, 32), (4, 64)])
+@pytest.mark.parametrize("m,L", [(2, 128), (3, 128), (4, 128), (3, 32), (4, 64), (6, 64), (13, 32), (16, 16)])
 def test_bundled_fast_kernel_vs_oracle(gpu, oracle, m, L):
     w = gpu.workloads
     ini, lens = w.twothick(L)
-    S = 5 * m + 2
+    S = (5 if m <= 4 else 2) * m + 2
     X = w.samples(S, seed=200 + m)[:, :12]
     T, Time = 64, 1.6
     want = oracle.pvsim(X, lens[0], Time, L, T, ini[0], mspb=m, nthreads=4)
@@ -101,6 +101,16 @@ def test_bundle_flag_is_validated(gpu):
         gpu.solve_pl(X, lens256[0], 0.5, 256, 20, ini256[0], bundle=2)
     with pytest.raises(ValueError):
         gpu.solve_pl(X, lens[0], 0.5, 128, 20, ini[0], strict=True, bundle=5)
+    # the C ABI itself refuses what the binding refuses: 5 systems per bundle at L = 128, 16 are fine at L = 64
+    lib, A = gpu._abi.lib(), gpu._abi
+    pl, st = np.zeros((4, 21)), np.zeros(4, np.int32)
+    rc = lib.trpl_solve_pl(X.ctypes.data, 4, float(lens[0]), 0.5, 128, 20, 1, 7, 100, ini[0].ctypes.data, pl.ctypes.data, 8, 21,
+                           st.ctypes.data, None, A.FLAG_STRICT | (4 << 8), 0, None)
+    assert rc == A.ERR_ARG and b"at most 4" in lib.trpl_last_error()
+    ini64, lens64 = w.twothick(64)
+    rc = lib.trpl_solve_pl(X.ctypes.data, 4, float(lens64[0]), 0.5, 64, 20, 1, 7, 100, ini64[0].ctypes.data, pl.ctypes.data, 8, 21,
+                           st.ctypes.data, None, A.FLAG_STRICT | (15 << 8), 0, None)
+    assert rc == A.OK and not st.any() and np.isfinite(pl).all()
     # bundle = 1 is the plain call
     a = gpu.solve_pl(X, lens[0], 0.5, 128, 20, ini[0], strict=True, bundle=1)[0]
     assert np.array_equal(a, gpu.solve_pl(X, lens[0], 0.5, 128, 20, ini[0], strict=True)[0])
@@ -129,3 +139,29 @@ def test_simulate_passes_max_sims_per_block_through_all_three_routes(gpu, oracle
             gpu.simulate(gpu.pvSim, e_data[:n_exp], P, X, [None], [None], 3, sim_params, g["ini"], flags, info, 0,
                          z.copy(), z.copy(), z.copy())
             assert np.max(np.abs(P - want[:n_exp]) / np.abs(want[:n_exp])) < 1e-8, (extra, n_exp)
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_bundles_whose_steps_take_one_iteration_hand_the_verdict_buffer_over_cleanly(gpu, oracle, strict):
+    """The verdicts of a bundle are double-buffered in LDS by the parity of a counter that runs across time steps.
+    Systems that START AT EQUILIBRIUM (no excitation) converge in the first inner iteration of every step, so every
+    step ends on the same parity it began with -- the hand-over a per-step parity got wrong (a fast wavefront could
+    overwrite the verdict a slow one was still reading; round-2 review).  Mixed with excited systems in the same
+    launch so that bundles of both kinds alternate.  Iteration totals equal the oracle's, STRICT PL bit for bit."""
+    w = gpu.workloads
+    L, m = 128, 4
+    ini, lens = w.twothick(L)
+    S = 8 * m + 3
+    X = w.samples(S, seed=77)[:, :12]
+    T, Time = 400, 10.0
+    for dN in (np.zeros(L), ini[0]):
+        want = oracle.pvsim(X, lens[0], Time, L, T, dN, mspb=m, nthreads=8)
+        pl, st, it, _ = gpu.solve_pl(X, lens[0], Time, L, T, dN, strict=strict, bundle=m)
+        assert not st.any() and np.array_equal(it, want["iters_total"])
+        if not dN.any():
+            assert (it == T + 1).all()                       # one iteration per step, t = 0 .. T
+            continue                                         # PL of an equilibrium state is pure cancellation
+        if strict:
+            assert np.array_equal(pl, want["plI"])
+        else:
+            assert np.max(np.abs(pl / want["plI"] - 1)) < 1e-9

@@ -267,3 +267,74 @@ def test_repeated_launches_give_the_same_bits(gpu, kernel):
     for a, b in zip(runs[0], runs[1]):
         assert np.array_equal(a, b)
     assert np.isfinite(runs[0][0]).all()
+
+
+@pytest.mark.parametrize("flag", ["pair", "single", "strict", "mixed"])
+def test_device_resident_continue_of_a_single_system(gpu, flag):
+    """trpl_solve_pl_resume_dev takes no excitation (the state comes from the checkpoint) and must not read one: with
+    S = 1 the only other array of the call, matpar, holds 12 doubles -- a kernel that still loaded L excitation values
+    through an alias of it read ~1 KB past the caller's tensor (round-2 advisor finding)."""
+    import torch
+    dv = gpu.device
+    X, length, ini = _case(gpu, 1, seed=31)
+    L, T, Time, t0 = 128, 64, 64 * DT, 20
+    dev = torch.device("cuda:0")
+    fl = {"pair": gpu.FLAG_KERNEL_PAIR, "single": gpu.FLAG_KERNEL_SINGLE, "strict": gpu.FLAG_STRICT, "mixed": gpu.FLAG_MIXED}[flag]
+    # the parameters sit at the very end of their own allocation
+    tX = torch.from_numpy(X).to(dev).clone()
+    tini = torch.from_numpy(np.ascontiguousarray(ini)).to(dev)
+    full = torch.empty((1, T + 1), dtype=torch.float64, device=dev)
+    dv.solve_pl_snap_device(tX, length, Time, L, T, tini, full, [], flags=fl)
+    cN = torch.zeros((1, 5, L), dtype=torch.float64, device=dev); cP = torch.zeros_like(cN)
+    cE = torch.zeros((1, 5, L + 1), dtype=torch.float64, device=dev)
+    first = torch.empty((1, t0 + 1), dtype=torch.float64, device=dev)
+    dv.solve_pl_snap_device(tX, length, Time * t0 / T, L, t0, tini, first, gpu.checkpoint_steps(t0), cN, cP, cE,
+                            flags=fl | gpu.FLAG_SNAP_RAW)
+    out = torch.full((1, T + 1), float("nan"), dtype=torch.float64, device=dev)
+    out[:, :t0 + 1] = first
+    st = torch.full((1,), -1, dtype=torch.int32, device=dev)
+    dv.solve_pl_resume_device(tX, length, Time, L, T, t0, cN, cP, cE, out, status=st, flags=fl)
+    torch.cuda.synchronize()
+    assert torch.equal(out, full) and int(st[0]) == 0
+
+
+@pytest.mark.parametrize("mode", MODES + [dict(strict=True, bundle=3), dict(bundle=2)],
+                         ids=lambda m: "-".join("%s=%s" % kv for kv in m.items()))
+def test_a_system_flagged_before_the_checkpoint_keeps_its_status_through_the_resume(gpu, oracle, mode):
+    """A small iteration cap flags some systems in the first steps.  The checkpoint of a flagged system carries its
+    status word (NaN payload); the continuation reports THAT status (not 1 + t0), takes no step for it (0 iterations
+    instead of max_iter on NaNs at every step) and its PL / later snapshots are NaN exactly where the uninterrupted
+    run's are -- status, PL and snapshots of every system bit for bit, iteration totals once the step at t0 is
+    counted once."""
+    X, length, ini = _case(gpu, 12, seed=5)
+    L, T, t0 = 128, 96, 40
+    Time = T * DT
+    # a cap between the systems' (bundles') largest per-step iteration counts: about half of them are flagged
+    per_step = oracle.pvsim(X, length, Time, L, T, ini, mspb=mode.get("bundle", 1), want_step_iters=True, nthreads=4)["step_iters"]
+    worst = np.unique(per_step.max(axis=1))
+    assert len(worst) >= 2 and per_step.argmax(axis=1).max() <= t0
+    cap = int(worst[len(worst) // 2])          # a step that needs >= cap iterations is flagged (pvSimPCR.py:269)
+    kw = dict(MAX=cap, **mode)
+    late = (t0 + 3, T)
+    full_snaps = {}
+    pl, st, it, _ = gpu.solve_pl(X, length, Time, L, T, ini, snap_steps=list(late), snapshots=full_snaps, **kw)
+    assert (st > 0).any() and (st == 0).any() and (st[st > 0] <= t0).all()
+    ck = {}
+    pl_a, st_a, it_a, _ = gpu.solve_pl(X, length, Time * t0 / T, L, t0, ini, snap_steps=gpu.checkpoint_steps(t0),
+                                       snapshots=ck, snap_raw=True, **kw)
+    assert np.array_equal(st_a, st)
+    out = np.full((len(X), T + 1), np.nan)
+    out[:, :t0 + 1] = pl_a
+    got = {}
+    pl_b, st_b, it_b, _ = gpu.solve_pl(X, length, Time, L, T, None, out=out, resume=(t0, ck["plN"], ck["plP"], ck["plE"]),
+                                       snap_steps=list(late), snapshots=got, **kw)
+    assert np.array_equal(st_b, st)                            # the ORIGINAL failing step, through the checkpoint
+    assert (it_b[st > 0] == 0).all() and (it_b[st == 0] > 0).all()
+    assert np.array_equal(np.isnan(pl_b), np.isnan(pl)) and np.array_equal(pl_b[~np.isnan(pl)], pl[~np.isnan(pl)])
+    for k in ("plN", "plP", "plE"):
+        assert np.array_equal(np.isnan(got[k]), np.isnan(full_snaps[k])), k
+        ok = ~np.isnan(got[k])
+        assert np.array_equal(got[k][ok], full_snaps[k][ok]), k
+    tail = np.full((len(X), t0 + 1), np.nan)
+    it_c = gpu.solve_pl(X, length, Time * t0 / T, L, t0, None, out=tail, resume=(t0, ck["plN"], ck["plP"], ck["plE"]), **kw)[2]
+    assert np.array_equal(it_a + it_b - it_c, it)

@@ -209,7 +209,7 @@ def test_multi_validates_observation_brackets_like_the_single_device_call(gpu):
     def call(hi_, dx_, h_):
         return lib.trpl_loglik_multi(X.ctypes.data, 6, 3, lens.ctypes.data, Time, 128, T, 1, 7, 1000, ini.ctypes.data,
                                      obs.ctypes.data, hi_.ctypes.data, dx_.ctypes.data, h_.ctypes.data, n,
-                                     n_obs.ctypes.data, P.ctypes.data, None, None, None, 0, dev.ctypes.data, 2, None)
+                                     n_obs.ctypes.data, P.ctypes.data, None, None, None, None, 0, dev.ctypes.data, 2, None)
     assert call(hi, dx, h) == A.ERR_ARG and b"sorted" in lib.trpl_last_error()
     good = np.tile(np.array([2, 3, 5, 7, 9], dtype=np.int32), (3, 1))
     bad_hi = good.copy(); bad_hi[1, 4] = T + 1
