@@ -17,7 +17,7 @@ OK, ERR_ARG, ERR_HIP, ERR_NODEVICE, ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 FLAG_STRICT, FLAG_PL_F32, FLAG_NORMALIZE, FLAG_FP32 = 0x1, 0x2, 0x4, 0x8
 FLAG_KERNEL_PAIR, FLAG_KERNEL_SINGLE, FLAG_MIXED, FLAG_SNAP_RAW = 0x10, 0x20, 0x40, 0x80
 MAX_BUNDLE = 16                 # the flag's range; the library accepts bundle_cap(L) of it
-PL_FLOOR_REL = 1e-12            # TRPL_PL_FLOOR_REL
+PL_FLOOR_EXCESS = 1e-4          # TRPL_PL_FLOOR_EXCESS
 
 
 def bundle_cap(L):

@@ -214,6 +214,7 @@ __global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
     }
 
     PlSink sink(a, cc, c, s, mag);
+    sink.set_floor(rated, n0p0d, L);
     int status = 0;
     int64_t itot = 0;
 

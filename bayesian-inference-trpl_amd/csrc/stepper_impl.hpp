@@ -27,7 +27,7 @@ namespace trpl {
 constexpr uint32_t kFlagPlF32 = 0x2;       // TRPL_FLAG_PL_F32
 constexpr uint32_t kFlagNormalize = 0x4;   // TRPL_FLAG_NORMALIZE
 constexpr uint32_t kFlagSnapRaw = 0x80;    // TRPL_FLAG_SNAP_RAW
-constexpr double kPlFloorRel = 1e-12;      // TRPL_PL_FLOOR_REL
+constexpr double kPlFloorExcess = 1e-4;    // TRPL_PL_FLOOR_EXCESS
 
 // A flagged system's snapshot / checkpoint slots hold a quiet NaN whose payload is its status word (1 + failing step):
 // a resume that finds it in the newest level knows the system was flagged, and when, without iterating on NaNs.
@@ -193,11 +193,12 @@ struct PlSink {
     // batched emission (FAST): lane k parks column base+k; a batch of up to 64 columns is processed at once
     double pend = 0.0;
     int64_t base = 0;
-    // the cancellation floor (include/trpl.h, floor_col): first compared column whose PL is below kPlFloorRel of the
-    // system's first emitted column -- from there on sum N P - L n0p0 is dominated by rounding in ANY arithmetic
-    double pl_floor = 0.0;
+    // the cancellation floor (include/trpl.h, floor_col): first compared column whose PL = B (sum N P - L n0p0) is
+    // below kPlFloorExcess of B L n0p0, i.e. whose mean excess product is a 1e-4 of the equilibrium product: the
+    // ~1e-12 by which two correct fp64 evaluations of the state differ is then amplified to >= 1e-8 of PL
+    double pl_floor = 0.0;                   // set_floor(); 0: only a non-positive PL counts
     int32_t first_floor = -1;
-    bool floor_armed = false;
+    __device__ __forceinline__ void set_floor(double rate, double n0p0, int L) { pl_floor = kPlFloorExcess * (rate * ((double)L * n0p0)); }
 
     int lane_;               // lane within the wavefront (== threadIdx.x except in the multi-wave bundled kernel)
 
@@ -224,10 +225,7 @@ struct PlSink {
     // PL columns instead of dividing t by plT every step (a 64-bit scalar division is ~130 instructions).
     __device__ __forceinline__ void emit(int64_t col, double plv)
     {
-        if (a.floor_col && (interp || col < ncol_ll)) {
-            if (!floor_armed) { pl_floor = kPlFloorRel * plv; floor_armed = true; }
-            if (first_floor < 0 && plv < pl_floor) first_floor = (int32_t)col;
-        }
+        if (a.floor_col && (interp || col < ncol_ll) && first_floor < 0 && !(plv >= pl_floor)) first_floor = (int32_t)col;
         if (want_pl && lane_ == 0) {                                                   // :281,:393
             if (a.pl_bytes == 4) ((float *)a.pl)[orow * a.pl_ld + col] = (float)plv / (float)cc.plnorm;
             else                 ((double *)a.pl)[orow * a.pl_ld + col] = plv / cc.plnorm;
@@ -293,12 +291,9 @@ struct PlSink {
                 if (a.pl_bytes == 4) ((float *)a.pl)[orow * a.pl_ld + col] = (float)pend / (float)cc.plnorm;
                 else                 ((double *)a.pl)[orow * a.pl_ld + col] = pend / cc.plnorm;
             }
-            if (a.floor_col && base < ncol_ll) {
-                if (!floor_armed) { pl_floor = kPlFloorRel * uniform_d(pend); floor_armed = true; }   // lane 0 holds column `base`
-                if (first_floor < 0) {
-                    const uint64_t below = __builtin_amdgcn_ballot_w64(live && col < ncol_ll && pend < pl_floor);
-                    if (below) first_floor = (int32_t)(base + __builtin_ctzll(below));
-                }
+            if (a.floor_col && base < ncol_ll && first_floor < 0) {
+                const uint64_t below = __builtin_amdgcn_ballot_w64(live && col < ncol_ll && !(pend >= pl_floor));
+                if (below) first_floor = (int32_t)(base + __builtin_ctzll(below));
             }
             if (base < ncol_ll) {                           // bayeslib.py:150-157, probs.py:29-44
                 if (a.flags & kFlagNormalize) {
@@ -627,7 +622,10 @@ stepper_kernel(const StepArgs a)
 #pragma unroll
     for (int j = 0; j < NR; j++) {                 // pvSimPCR.py:356-362
         // (a resume takes its state from the checkpoint; dN is not read -- it may be NULL there)
-        const double dn = (SNAP && a.resN != nullptr) ? 0.0 : a.dN[(int64_t)c * L + node_of<LAY, NR, W>(ln, j)] * cc.dx3;
+        // (the select sits on the loaded value, so that product and sum are the same expression -- and the same
+        // contraction -- in the SNAP and the plain instantiation: their results must agree bit for bit)
+        const double raw = (SNAP && a.resN != nullptr) ? 0.0 : a.dN[(int64_t)c * L + node_of<LAY, NR, W>(ln, j)];
+        const double dn = raw * cc.dx3;
         Nk[j] = N0 + dn;
         Pk[j] = P0 + dn;
         Ek[j] = 0.0;
@@ -640,6 +638,7 @@ stepper_kernel(const StepArgs a)
     }
 
     PlSink sink(a, cc, c, s, mag, lane64);
+    sink.set_floor(rate, n0p0, L);
     if constexpr (BUNDLE) { if (!valid) sink.mute(); }
     SnapSink snap(a, cc);
     int status = 0;

@@ -137,7 +137,8 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
 #pragma unroll
     for (int j = 0; j < NR; j++) {                  // pvSimPCR.py:356-362
         // (a resume takes its state from the checkpoint; dN is not read -- it may be NULL there)
-        const double dn = (SNAP && a.resN != nullptr) ? 0.0 : a.dN[(int64_t)c * L + NR * ln + j] * cc.dx3;
+        const double raw = (SNAP && a.resN != nullptr) ? 0.0 : a.dN[(int64_t)c * L + NR * ln + j];
+        const double dn = raw * cc.dx3;
         Nk[j] = N0 + dn;
         Pk[j] = P0 + dn;
         Ek[j] = 0.0;
@@ -152,6 +153,8 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
     PlSink sinkA(a, cc, c, sA, lane_value(mag, 0));
     PlSink sinkB(a, cc, c, sB, lane_value(mag, WS));
     const double rateA = lane_value(rate, 0), rateB = lane_value(rate, WS);
+    sinkA.set_floor(rateA, lane_value(n0p0, 0), L);
+    sinkB.set_floor(rateB, lane_value(n0p0, WS), L);
     int statusA = 0, statusB = 0;
     bool deadA = false, deadB = !validB;            // dead: flagged non-converged (or the odd tail's duplicate)
     int64_t itotA = 0, itotB = 0;

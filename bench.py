@@ -19,7 +19,13 @@ steps after the excitation need many more inner iterations than the rest, so sho
 under-state the full-length rate (3.2 iterations per step at T = 1000, 2.2 at 8000, 2.0 at 80 000):
 `--T 80000` runs the full length, `--T 1000` the transient-dominated case of the earlier profiles.
 
-At N = 1 the line also carries `host_api_block` -- the reference's own call sequence (pvSim -> fastlog -> prob per
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself: N fresh child
+processes under `python -m torch.distributed.run` (127.0.0.1 rendezvous, a free port), BEFORE this process has
+imported torch or touched the GPU; rank 0's JSON line is relayed and the exit status is the children's.  The N > 1
+line carries `rccl`: the world RCCL saw, every rank's device, the bytes and the time of the one all-gather.
+
+At N = 1 the line also carries `other_configs` -- ONE event-timed pass each of BASELINE configs[2] (Twothick x 65 536
+samples x 6 curves) and of one GPU's share of configs[4] (L = 512 x 32 768 samples, fp64 at tol 1e-6) -- `host_api_block` -- the reference's own call sequence (pvSim -> fastlog -> prob per
 curve, host buffers) on one reference-shaped 1024-sample block, PCIe included -- and `full_length`: ONE extra pass at the production length T = 80 000 over the
 same resident batch (event-timed, ~26 s), so that the full-length rate is measured by every driver run.
 
@@ -54,6 +60,22 @@ HBM_PEAK_GBS = 8000.0               # HBM3E spec (MI355X_MICROARCH.md); ~6300 ac
 FLOP_PER_ITER_PER_NODE = 268
 
 
+def self_launch(argv, n):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start the N ranks as fresh child processes under
+    torch.distributed.run and relay what they print.  Called before this process imports torch / trpl_amd or touches
+    the GPU; never an exec (a process that has initialised the GPU must not be replaced), never under a profiler."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,10 +108,14 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (one GPU per rank); gloo = rehearsal of the N>1 control flow "
                          "with host-staged collectives (ranks may share a GPU)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the one pass each of configs[2] (Twothick) and configs[4]'s share (L = 512) (N = 1 only, ~15 s)")
     args = ap.parse_args()
 
     if args.single_process:
         return main_single_process(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -155,7 +181,7 @@ def main():
     iters = torch.empty((C, S), dtype=torch.int64, device=dev)
     n_obs = [T + 1] * C
 
-    ev = []
+    ev, ev_ag = [], []
 
     def step(record):
         P.zero_()
@@ -167,7 +193,12 @@ def main():
             e1.record()
             ev.append((e0, e1))
         if world > 1:
-            return trpl_amd.dist.gather_likelihoods(P[None, :].to(cdev), S_total)
+            full_ = trpl_amd.dist.gather_likelihoods(P[None, :].to(cdev), S_total)
+            if record and args.backend == "nccl":       # solve end -> gathered vector usable: the all-gather + the wait
+                e2 = torch.cuda.Event(enable_timing=True)     # for the slowest rank's solve
+                e2.record()
+                ev_ag.append((e1, e2))
+            return full_
         return P[None, :]
 
     def fence():
@@ -245,8 +276,11 @@ def main():
                                % (args.workload, args.samples_per_gpu, S_total, C, L, T, tol,
                                   "fp32 state" if args.fp32 else ("fp64 state + fp32 solves" if args.mixed else "fp64"),
                                   "strict" if args.strict else "fast"),
+                   "arithmetic": "strict" if args.strict else "fast", "precision": "fp32 state" if args.fp32 else
+                   ("fp64 state + fp32 solves" if args.mixed else "fp64"), "tol_exp": tol,
                    "samples_total": S_total, "curves": C, "L": L, "T": T, "parallelism": "sample-shard x%d" % world,
                    "collective": "none" if world == 1 else ("RCCL all_gather" if args.backend == "nccl" else "gloo all_gather (rehearsal)")},
+        "value_n1_equiv": value / world,              # per-GPU rate: what this job's N = 1 line reports as `value`
         "likelihoods_per_s_at_T": S_total * args.steps / elapsed,
         "likelihoods_per_s_at_T80000_equiv": value / (C * 80001),
         "inner_iterations_per_s": it_all * args.steps / elapsed,
@@ -263,6 +297,11 @@ def main():
                              "kernel is ~0.1 KB per system by construction (see profiles/)"},
     }
 
+    if world > 1:
+        out["rccl"] = rccl_record(torch, dist, trpl_amd, args, rank, world, local_rank, dev, cdev, S_total, ev_ag)
+    if rank == 0 and world == 1 and not args.no_other_configs and args.workload == "power_scan" and L == 128 \
+            and not (args.fp32 or args.mixed or args.strict):
+        out["other_configs"] = other_configs(torch, tdev, trpl_amd, wl, dev, args.samples_per_gpu, T, dt_ns)
     if rank == 0 and not args.no_pcr:
         out["roofline_hbm_pcr"] = bench_pcr(torch, tdev, dev, flags & trpl_amd.FLAG_STRICT, L=L,
                                             dtype=torch.float32 if args.fp32 else torch.float64)
@@ -361,6 +400,96 @@ def main_single_process(args):
                         "note": "wall-clock over the whole step (solve + all-gather + unpadding) on all devices"}}
     md.close()
     print(json.dumps(out), flush=True)
+
+
+def rccl_record(torch, dist, trpl_amd, args, rank, world, local_rank, dev, cdev, S_total, ev_ag):
+    """What proves the ranks: the world size the process group reports, every rank's device (ordinal, name, PCI bus id
+    where the runtime exposes it), the payload of the one collective of a step, its time inside the timed loop (from
+    the end of this rank's solve to the gathered vector: includes waiting for the slowest rank) and isolated (20
+    back-to-back all-gathers of the same payload after a barrier).  Collective on every rank; rank 0 keeps the dict."""
+    props = torch.cuda.get_device_properties(dev)
+    mine = {"rank": rank, "local_rank": local_rank, "device": int(dev.index), "name": props.name,
+            "pci_bus_id": getattr(props, "pci_bus_id", None), "pid": os.getpid()}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    widest = -(-S_total // world)
+    payload = torch.zeros((1, widest), dtype=torch.float64, device=cdev)
+    for _ in range(3):
+        trpl_amd.dist.gather_likelihoods(payload, S_total)
+    iso_us = None
+    dist.barrier()
+    if args.backend == "nccl":
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            trpl_amd.dist.gather_likelihoods(payload, S_total)
+        e1.record()
+        torch.cuda.synchronize()
+        iso_us = e0.elapsed_time(e1) * 1e3 / 20
+    else:
+        t0 = time.perf_counter()
+        for _ in range(20):
+            trpl_amd.dist.gather_likelihoods(payload, S_total)
+        iso_us = (time.perf_counter() - t0) * 1e6 / 20
+    in_loop = float(np.mean([a.elapsed_time(b) for a, b in ev_ag])) * 1e3 if ev_ag else None
+    return {"world": dist.get_world_size(), "backend": dist.get_backend(), "devices": everyone,
+            "distinct_devices": len({(d["device"], d["pci_bus_id"]) for d in everyone}),
+            "allgather_bytes": widest * 8 * world, "allgather_bytes_per_rank": widest * 8,
+            "allgather_us": in_loop if in_loop is not None else iso_us,
+            "allgather_us_in_loop_incl_rank_skew": in_loop, "allgather_us_isolated": iso_us,
+            "note": "one all_gather_into_tensor of ceil(S/N) fp64 per rank per step + the unpadding copies"}
+
+
+def one_pass(torch, tdev, trpl_amd, wl, dev, workload, S, L, T, dt_ns, tol, flags=0):
+    """ONE event-timed fused pass of another configuration (inputs resident, one short untimed launch first)."""
+    Time = T * dt_ns
+    ini, lens = wl.power_scan(L) if workload == "power_scan" else wl.twothick(L)
+    C = len(lens)
+    X = torch.from_numpy(np.ascontiguousarray(wl.samples(S))).to(dev)
+    ini_d = torch.from_numpy(ini).to(dev)
+    mark = torch.from_numpy((wl.MARKED_POINT * trpl_amd.UNIT_CONVERSIONS)[None, :-1].copy()).to(dev)
+    obs = torch.empty((C, T + 1), dtype=torch.float64, device=dev)
+    for c in range(C):
+        pl = torch.empty((1, T + 1), dtype=torch.float64, device=dev)
+        tdev.solve_pl_device(mark, lens[c], Time, L, T, ini_d[c].contiguous(), pl, flags=trpl_amd.FLAG_STRICT, tol=7)
+        obs[c] = torch.log10(pl[0])
+    P = torch.zeros(S, dtype=torch.float64, device=dev)
+    sse = torch.empty((C, S), dtype=torch.float64, device=dev)
+    status = torch.empty((C, S), dtype=torch.int32, device=dev)
+    iters = torch.empty((C, S), dtype=torch.int64, device=dev)
+    flags = trpl_amd._abi.pin_variant(flags, S * C, L, T)
+    tdev.loglik_device(X, ini_d, lens, 50 * dt_ns, L, 50, obs[:, :51].contiguous(), [51] * C, P, sse, status, iters, flags=flags, tol=tol)
+    P.zero_()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    tdev.loglik_device(X, ini_d, lens, Time, L, T, obs, [T + 1] * C, P, sse, status, iters, flags=flags, tol=tol)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    it = int(iters.sum().item())
+    tf = it * FLOP_PER_ITER_PER_NODE * L / (ms * 1e-3) / 1e12
+    variant = trpl_amd._abi.lib().trpl_kernel_variant(S * C, L, T, flags)
+    return {"workload": "%s x %d samples, %d curves, L=%d nodes, T=%d steps of dt=0.025 ns, tol=1e-%d, fp64, arithmetic=fast"
+                        % (workload, S, C, L, T, tol),
+            "samples": S, "curves": C, "L": L, "T": T, "tol_exp": tol, "passes": 1, "ms": ms,
+            "system_timesteps_per_s": S * C * (T + 1) / (ms * 1e-3), "likelihoods_per_s_at_T": S / (ms * 1e-3),
+            "inner_iterations": it, "mean_inner_iterations_per_step": it / (S * C * (T + 1)),
+            "roofline_achieved_tflops": tf, "roofline_frac": tf / FP64_VECTOR_PEAK_TFLOPS,
+            "kernel": "pair::stepper_pair_kernel" if variant == trpl_amd._abi.KERNEL_FAST_PAIR else "stepper_kernel<%d>" % L,
+            "nonconverged": int((status != 0).sum().item()), "finite_likelihoods": int(torch.isfinite(P).sum().item())}
+
+
+def other_configs(torch, tdev, trpl_amd, wl, dev, S, T, dt_ns):
+    """The other single-GPU configurations BASELINE.json names, one event-timed pass each at the headline's window:
+    configs[2] Twothick (311 / 2000 nm films x 3 powers = 6 curves) x S samples, and ONE GPU's share of configs[4]
+    (L = 512 x 262 144 samples over 8 GPUs = 32 768 per GPU) in fp64 at tol 1e-6 -- the setting DESIGN.md section 7
+    recommends for that grid (an fp32 STATE, as the config is worded, loses the decay over thousands of steps)."""
+    out = [dict(config="configs[2]", **one_pass(torch, tdev, trpl_amd, wl, dev, "twothick", S, 128, T, dt_ns, 7))]
+    torch.cuda.empty_cache()
+    out.append(dict(config="configs[4], one GPU's share of 8", **one_pass(torch, tdev, trpl_amd, wl, dev, "power_scan", 32768, 512, T, dt_ns, 6)))
+    return out
 
 
 def full_length_pass(torch, tdev, trpl_amd, dev, X, ini_d, mark, lens, L, T, dt_ns, flags, tol, C, fp32):
@@ -526,6 +655,19 @@ def bench_pcr(torch, tdev, dev, flags, S=65536, L=128, reps=48, dtype=None, nset
             "max_abs_residual": res}
 
 
+def cpu_model():
+    """The host CPU's model string (SURVEY 8d asks for it beside the core count)."""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(wl, trpl_amd, ini, lens, Time, L, T, budget_s):
     """The CPU oracle (kind "port": the reference's algorithm restated in C, pinned bit-exact to
     it) on this host's cores, on a bounded sample of the SAME workload (same box, seed, curves,
@@ -550,7 +692,7 @@ def cpu_baseline(wl, trpl_amd, ini, lens, Time, L, T, budget_s):
     n2 = int(min(max(n1, n1 * budget_s / max(t1, 1e-3)), 64 * n1))
     t2 = run(n2)
     rate = n2 * len(lens) * (T + 1) / t2
-    return {"value": rate, "unit": "system-timesteps/s", "cores": cores, "kind": "port",
+    return {"value": rate, "unit": "system-timesteps/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
             "sample": "%d seeded samples of the same box x %d curves x T=%d steps (%.1f s on %d OpenMP threads)"
                       % (n2, len(lens), T, t2, cores),
             "likelihoods_per_s_at_T": n2 / t2}
@@ -566,7 +708,7 @@ def cpu_baseline_scipy(wl, ini, lens, Time, L, T):
     n = max(1, (2 * cores) // len(lens))
     X = wl.samples(n)
     sec, nsys = scipy_mol.timed_batch(X, ini, lens, Time, L, T, cores)
-    return {"value": nsys * (T + 1) / sec, "unit": "system-timesteps/s", "cores": cores, "kind": "port",
+    return {"value": nsys * (T + 1) / sec, "unit": "system-timesteps/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
             "sample": "%d seeded samples x %d curves, scipy solve_ivp(BDF, rtol 1e-5) sampled on T=%d output steps "
                       "(%.1f s on %d processes)" % (n, len(lens), T, sec, cores),
             "likelihoods_per_s_at_T": n / sec}

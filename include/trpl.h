@@ -242,23 +242,30 @@ int trpl_loglik_from_pl_dev(const void *plI, int32_t elem_bytes, int64_t rows, i
  *   dN      [C][L], obs [C][obs_ld] log10 observations, n_obs [C] host int64 (<= T/plT + 1)
  *   sse     [C][S] out;  status [C][S] out (nullable);  iters_total [C][S] out (nullable)
  *   floor_col [C][S] out (nullable): the CANCELLATION FLOOR indicator.  PL = B (sum_i N_i P_i - L n0 p0) is a
- *           difference of two nearly equal numbers once the excess carriers have decayed: below
- *           TRPL_PL_FLOOR_REL = 1e-12 of the curve's first compared value what any fp64 evaluation returns is set
- *           by the rounding of the 128-term sum, not by the physics -- the reference's own value there is the sign
- *           and size of its last rounding error (pvSimPCR.py:276-281), often negative, i.e. clamped to DBL_MIN by
- *           fastlog (bayeslib.py:157).  floor_col[c][s] is the first compared PL column (observation index; the
- *           grid step with off-grid observations) whose value is below that floor, or -1 if none is.
- *           CONTRACT: systems with floor_col = -1 agree with the reference evaluation (TRPL_FLAG_STRICT, which
- *           reproduces it bit for bit) to <= 1e-9 in every compared PL value and <= 1e-8 in sse; for the others the
- *           columns from floor_col on are arbitrary in BOTH (the default arithmetic forms the per-node excess
- *           fma(N_i, P_i, -n0p0) before summing and typically lands on the DBL_MIN clamp; the reference order
- *           returns rounding noise of either sign), their sse is dominated by those columns (>= 1e5 per clamped
- *           point), and a caller who wants to compare such samples across implementations should drop them or
- *           truncate the window at floor_col.  Measured on the reference's prior box over its full 2 us window:
- *           3.8 % of the samples (all with tau_n <= 10 ns); none over the first 200 ns.
+ *           difference of two nearly equal numbers once the excess carriers have decayed.  With
+ *               r(t) = PL(t) / (B L n0 p0)        (mean excess product per node over the equilibrium product)
+ *           two correct fp64 evaluations of the same scheme -- this library's default arithmetic and the reference's
+ *           order of operations (TRPL_FLAG_STRICT, which reproduces the sequentially executed reference bit for
+ *           bit), or the reference with and without FMA contraction -- hold states that differ by ~1e-12 relative
+ *           (the solver tolerance is 1e-7), and the subtraction amplifies that to
+ *               |dPL / PL|  <~  1e-9 + 1e-12 / r(t)
+ *           (measured, profiles/r3_floor_study.json: 1e-9 at r = 1e-3, 1e-8 at 1e-4, 1e-6 at 1e-6, O(1) at 1e-12;
+ *           below r ~ 1e-13 the reference's own value is the sign and size of the last rounding of its 128-term
+ *           sum, pvSimPCR.py:276-281 -- negative about half the time, i.e. clamped to DBL_MIN by fastlog,
+ *           bayeslib.py:157 -- while the default arithmetic, which forms the per-node excess fma(N_i, P_i, -n0p0)
+ *           before summing, keeps following the state and lands on the clamp when that turns non-positive).
+ *           floor_col[c][s] is the first compared PL column (observation index; the grid step with off-grid
+ *           observations) with r < TRPL_PL_FLOOR_EXCESS = 1e-4 (or a non-positive / NaN PL), or -1 if there is none.
+ *           CONTRACT: a system with floor_col = -1 agrees with the reference evaluation to <= 2e-8 in every compared
+ *           PL value and to <= 1e-8 (relative) in sse; for the others that holds for the columns before floor_col,
+ *           and from there on PL -- hence sse -- depends on the evaluation order at the level given above: compare
+ *           such samples across implementations on the window before floor_col, or not at all (once PL is on the
+ *           clamp their sse grows by ~1e5 per point in one evaluation and by (log10 of rounding noise)^2 in another;
+ *           either way their posterior weight is 0).  On the reference's prior box and full 2 us window the samples
+ *           that get there all have tau_n <= 10 ns; none does within the first 200 ns.
  * C <= 16 per call.
  * ------------------------------------------------------------------------------------- */
-#define TRPL_PL_FLOOR_REL 1e-12
+#define TRPL_PL_FLOOR_EXCESS 1e-4
 int trpl_loglik(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns,
                 int32_t L, int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter,
                 const double *dN, const double *obs, int64_t obs_ld, const int64_t *n_obs,

@@ -468,20 +468,37 @@ def test_bench_two_rank_rehearsal_gathers_the_single_rank_likelihoods(gpu, tmp_p
     """bench.py --gpus 2 --backend gloo as fresh child processes sharing this box's GPU (the N > 1 path:
     sample shards, pinned kernel variant, all-gather, max-over-ranks timing) must print one contract line
     and gather exactly the likelihood vector a single rank computes for the same 4 096 samples."""
-    common = ["--steps", "1", "--warmup", "0", "--T", "200", "--no-cpu-baseline", "--no-pcr", "--no-full-length", "--no-host-api"]
+    common = ["--steps", "1", "--warmup", "0", "--T", "200", "--no-cpu-baseline", "--no-pcr", "--no-full-length", "--no-host-api",
+              "--no-other-configs"]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", TRPL_AUTOBUILD="0")
     p1, p2 = str(tmp_path / "p1.npy"), str(tmp_path / "p2.npy")
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--samples-per-gpu", "4096",
                          "--dump-p", p1] + common, env=env, capture_output=True, text=True, timeout=900)
     assert r1.returncode == 0, r1.stderr[-2000:]
-    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                         "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"),
-                         "--gpus", "2", "--backend", "gloo", "--samples-per-gpu", "2048", "--dump-p", p2] + common,
-                        env=env, capture_output=True, text=True, timeout=900)
+    # the plain form the driver uses for N = 1, with N = 2: bench.py starts its two ranks itself (fresh children under
+    # torch.distributed.run, before the parent has imported torch or touched the GPU) and relays rank 0's line
+    env2 = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                         "--samples-per-gpu", "2048", "--dump-p", p2] + common,
+                        env=env2, capture_output=True, text=True, timeout=900)
     assert r2.returncode == 0, r2.stderr[-2000:]
     line1 = json.loads(r1.stdout.strip().splitlines()[-1])
-    line2 = json.loads(r2.stdout.strip().splitlines()[-1])
+    lines2 = [ln for ln in r2.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines2) == 1                                              # ONE contract line, rank 0's
+    line2 = json.loads(lines2[0])
     assert line2["n_gpus"] == 2 and line2["scaling"] == "weak" and line2["config"]["samples_total"] == 4096
+    rc = line2["rccl"]                                                   # the ranks are proven, not assumed
+    assert rc["world"] == 2 and [d["rank"] for d in rc["devices"]] == [0, 1] and rc["backend"] == "gloo"
+    assert len({d["pid"] for d in rc["devices"]}) == 2 and rc["allgather_bytes"] == 4096 * 8 and rc["allgather_us"] > 0
+    assert abs(line2["value_n1_equiv"] * 2 - line2["value"]) < 1e-6 * line2["value"] and "cpu_baseline" not in line2
+    assert line1["config"]["arithmetic"] == "fast" and line1["config"]["precision"] == "fp64" and "rccl" not in line1
+    # a launcher that has already set WORLD_SIZE is honoured as before (the driver's N > 1 form)
+    r2b = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--backend", "gloo", "--samples-per-gpu", "2048"] + common,
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert r2b.returncode == 0, r2b.stderr[-2000:]
+    assert json.loads(r2b.stdout.strip().splitlines()[-1])["rccl"]["world"] == 2
     assert line1["config"]["samples_total"] == 4096
     assert line2["nonconverged_systems"] == line1["nonconverged_systems"] == 0
     a, b = np.load(p1), np.load(p2)

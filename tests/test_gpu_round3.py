@@ -1,0 +1,201 @@
+"""Round 3: the regime the benchmark times, against the ORACLE inside the GPU suite, and the cancellation floor as a
+tested contract (round-2 review, "What's weak" 1).
+
+  * Power_scan x 64 samples (BASELINE configs[0]) over the bench's window, T = 8000 steps of 0.025 ns: STRICT is the
+    oracle bit for bit (PL as bit patterns, iteration totals); both FAST kernels hold the oracle's iteration totals,
+    its PL to the stated bound and its likelihood to 1e-8 on every sample that stays above the floor;
+  * short-lifetime samples that DO reach the floor: floor_col is the same in every arithmetic and equals the column
+    the oracle's own PL gives; before it PL and the squared-error sum follow the oracle, and a window truncated there
+    is floor-free;
+  * floor_col through the multi-device and off-grid entry points.
+
+The floor (include/trpl.h): r(t) = PL(t) / (B L n0p0) < TRPL_PL_FLOOR_EXCESS = 1e-4; the measured bound on the
+deviation between two correct fp64 evaluations is 1e-9 + 1e-12 / r (profiles/r3_floor_study.json)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+DT = 0.025
+KERNELS = [dict(strict=True), dict(kernel="single"), dict(kernel="pair")]
+IDS = ["strict", "single", "pair"]
+
+
+def excess_scale(X, length, L=128):
+    """B L n0p0 in the units of PL (nm^-2 ns^-1): the non-dimensional rate * L * N0 * P0 of pvSimPCR.py:327-331 divided
+    by dx^2 dt (:393) -- the time step cancels."""
+    dx = length / L
+    return X[:, 4] * L * X[:, 0] * X[:, 1] * dx
+
+
+def deviation_bound(pl_ref, scale):
+    """1e-9 + 2e-12 / r per point (twice the measured envelope); inf where the reference PL is not positive."""
+    r = pl_ref / scale[:, None]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        b = 1e-9 + 2e-12 / r
+    b[~(pl_ref > 0)] = np.inf
+    return b
+
+
+def first_below(pl, thr):
+    """first column with pl < thr (or non-positive / NaN), -1 if none"""
+    bad = ~(pl >= thr[:, None])
+    return np.where(bad.any(axis=1), bad.argmax(axis=1), -1).astype(np.int32)
+
+
+@pytest.fixture(scope="module")
+def long_window(gpu, oracle):
+    """configs[0] at the bench's window, solved once by the oracle (16 threads: seconds)."""
+    w = gpu.workloads
+    T, L, S = 8000, 128, 64
+    Time = T * DT
+    ini, lens = w.power_scan(L)
+    X = w.samples(S)
+    mark = (w.MARKED_POINT * gpu.UNIT_CONVERSIONS)[None, :-1]
+    ref = [oracle.pvsim(X[:, :12], lens[c], Time, L, T, ini[c], nthreads=16) for c in range(3)]
+    obs = [np.log10(oracle.pvsim(mark, lens[c], Time, L, T, ini[c])["plI"][0]) for c in range(3)]
+    P = np.zeros(S)
+    sse = np.zeros((3, S))
+    for c in range(3):
+        lg = ref[c]["plI"].copy()
+        oracle.fastlog(lg)                                   # probs.fastlog
+        Pc = np.zeros(S)
+        oracle.prob(Pc, lg, obs[c], np.ascontiguousarray(X[:, -1]))      # probs.prob: P -= sum (lg + mag - obs)^2
+        sse[c] = -Pc
+        P += Pc
+    return dict(T=T, L=L, S=S, Time=Time, ini=ini, lens=lens, X=X, ref=ref, obs=obs, P=P, sse=sse)
+
+
+@pytest.mark.parametrize("mode", KERNELS, ids=IDS)
+def test_bench_window_pl_and_iteration_totals_against_the_oracle(gpu, long_window, mode):
+    g = long_window
+    for c in range(3):
+        want = g["ref"][c]
+        assert not want["status"].any()
+        pl, st, it, _ = gpu.solve_pl(g["X"][:, :12], g["lens"][c], g["Time"], g["L"], g["T"], g["ini"][c], **mode)
+        assert not st.any()
+        assert np.array_equal(it, want["iters_total"]), (c, int((it != want["iters_total"]).sum()))
+        if mode.get("strict"):
+            assert np.array_equal(pl.view(np.int64), want["plI"].view(np.int64))       # bit patterns
+            continue
+        dev = np.abs(pl / want["plI"] - 1)
+        bound = deviation_bound(want["plI"], excess_scale(g["X"], g["lens"][c]))
+        assert (dev <= bound).all(), (c, float(np.nanmax(dev / bound)))
+        # the review's wording: every point >= 1e-12 of the curve's start that is also above the floor, to 2e-8
+        above = (want["plI"] >= 1e-12 * want["plI"][:, :1]) & (want["plI"] >= 1e-4 * excess_scale(g["X"], g["lens"][c])[:, None])
+        assert dev[above].max() < 2e-8 and above.mean() > 0.9
+
+
+@pytest.mark.parametrize("mode", KERNELS, ids=IDS)
+def test_bench_window_fused_likelihood_and_floor_indicator_against_the_oracle(gpu, long_window, mode):
+    g = long_window
+    info = {}
+    P = gpu.loglik(g["X"], g["ini"], g["lens"], g["Time"], g["L"], g["T"], g["obs"], info=info, **mode)
+    assert not info["status"].any()
+    for c in range(3):
+        assert np.array_equal(info["iters_total"][c], g["ref"][c]["iters_total"])
+        # the indicator is what the oracle's own PL says
+        want_col = first_below(g["ref"][c]["plI"], 1e-4 * excess_scale(g["X"], g["lens"][c]))
+        assert np.array_equal(info["floor_col"][c], want_col), c
+    clear = (info["floor_col"] < 0).all(axis=0)              # samples that never reach the floor, on any curve
+    assert clear.sum() >= 0.8 * g["S"]
+    rel = np.abs(P - g["P"]) / np.abs(g["P"])
+    assert rel[clear].max() < 1e-8, float(rel[clear].max())
+    rel_sse = np.abs(info["sse"] - g["sse"]) / g["sse"]
+    assert rel_sse[info["floor_col"] < 0].max() < 1e-8
+    if mode.get("strict"):                                   # the reference evaluation: every sample, floor or not
+        assert rel.max() < 1e-12
+
+
+@pytest.fixture(scope="module")
+def decayed(gpu, oracle):
+    """Samples with tau_n, tau_p of 0.3 .. 3 ns: gone by e^-17 .. e^-170 inside a 50 ns window."""
+    w = gpu.workloads
+    T, L, S = 2000, 128, 48
+    Time = T * DT
+    ini, lens = w.power_scan(L)
+    X = w.samples(S, seed=7)
+    rng = np.random.default_rng(3)
+    X[:, 9] = 10 ** rng.uniform(np.log10(0.3), np.log10(3.0), S)
+    X[:, 10] = X[:, 9] * 10 ** rng.uniform(-0.3, 0.3, S)
+    ref = [oracle.pvsim(X[:, :12], lens[c], Time, L, T, ini[c], nthreads=16) for c in range(3)]
+    return dict(T=T, L=L, S=S, Time=Time, ini=ini, lens=lens, X=X, ref=ref)
+
+
+def test_floor_indicator_and_contract_on_samples_that_reach_the_floor(gpu, oracle, decayed):
+    g = decayed
+    T, S = g["T"], g["S"]
+    obs = [np.linspace(18.0, 2.0, T + 1)] * 3                # any observation set: the contract is about PL and sse
+    cols, sses, pls = {}, {}, {}
+    for name, mode in zip(IDS, KERNELS):
+        info = {}
+        gpu.loglik(g["X"], g["ini"], g["lens"], g["Time"], g["L"], T, obs, info=info, **mode)
+        assert not info["status"].any()
+        cols[name], sses[name] = info["floor_col"], info["sse"]
+        pls[name] = [gpu.solve_pl(g["X"][:, :12], g["lens"][c], g["Time"], g["L"], T, g["ini"][c], **mode)[0] for c in range(3)]
+    # the same column in every arithmetic, and the one the oracle's PL gives
+    want = np.stack([first_below(g["ref"][c]["plI"], 1e-4 * excess_scale(g["X"], g["lens"][c])) for c in range(3)])
+    assert (want >= 0).mean() > 0.9 and (want[want >= 0] > 50).all()
+    for name in IDS:
+        assert np.array_equal(cols[name], want), name
+    mag = np.ascontiguousarray(g["X"][:, -1])
+    for c in range(3):
+        ref = g["ref"][c]["plI"]
+        assert np.array_equal(pls["strict"][c].view(np.int64), ref.view(np.int64))
+        before = np.arange(T + 1)[None, :] < np.where(want[c] >= 0, want[c], T + 1)[:, None]
+        for name in ("single", "pair"):
+            dev = np.abs(pls[name][c] / ref - 1)
+            assert dev[before].max() < 2e-8, (name, c, float(dev[before].max()))       # the contract, columns before floor_col
+            assert (dev <= deviation_bound(ref, excess_scale(g["X"], g["lens"][c])))[ref > 0].all()
+            # squared-error sum over the window before floor_col: the oracle's, to 1e-8
+            def sse_before(pl):
+                lg = np.log10(np.maximum(pl, np.finfo(float).tiny))
+                e = np.where(before, lg + mag[:, None] - obs[c][None, :], 0.0)
+                return (e * e).sum(axis=1)
+            a, b = sse_before(pls[name][c]), sse_before(ref)
+            assert np.max(np.abs(a - b) / b) < 1e-8
+    # ... and past it the values are arbitrary, as documented: the reference order returns rounding noise of either
+    # sign (some of it clamped), the default arithmetic follows the state onto the clamp -- their sse differ by far
+    # more than any tolerance on at least some of these systems, which is why the indicator exists
+    on_floor = want >= 0
+    gap = np.abs(sses["pair"] - sses["strict"]) / sses["strict"]
+    assert gap[on_floor].max() > 1e-3
+    # a window that ends before the earliest floor column is floor-free, and there the fused likelihood is the oracle's
+    n = int(want[want >= 0].min())
+    info = {}
+    P = gpu.loglik(g["X"], g["ini"], g["lens"], g["Time"], g["L"], T, [o[:n] for o in obs], info=info, kernel="pair")
+    assert (info["floor_col"] == -1).all()
+    Pw = np.zeros(S)
+    for c in range(3):
+        lg = g["ref"][c]["plI"][:, :n].copy()
+        oracle.fastlog(lg)
+        oracle.prob(Pw, lg, obs[c][:n], mag)
+    assert np.max(np.abs(P - Pw) / np.abs(Pw)) < 1e-8
+
+
+def test_floor_indicator_through_the_sharded_and_off_grid_entry_points(gpu, decayed):
+    g = decayed
+    T, S = 600, 21
+    Time = T * DT
+    X = g["X"][:S]
+    obs = [np.linspace(18.0, 12.0, T + 1)] * 3
+    one, multi, off = {}, {}, {}
+    gpu.loglik(X, g["ini"], g["lens"], Time, g["L"], T, obs, info=one, kernel="single")
+    gpu.loglik(X, g["ini"], g["lens"], Time, g["L"], T, obs, info=multi, kernel="single", devices=[0, 0, 0])
+    assert np.array_equal(one["floor_col"], multi["floor_col"]) and (one["floor_col"] >= 0).any()
+    # observation times off the grid: the indicator counts grid steps
+    times = [np.linspace(0.0, Time, 301)[1:-1] + 0.003] * 3
+    gpu.loglik(X, g["ini"], g["lens"], Time, g["L"], T, [np.full(299, 15.0)] * 3, info=off, times=times, kernel="single")
+    reached = one["floor_col"] >= 0
+    assert np.array_equal(off["floor_col"][reached & (one["floor_col"] < T - 2)], one["floor_col"][reached & (one["floor_col"] < T - 2)])
+    # the device-resident call, with and without the output
+    import torch
+    dev = torch.device("cuda:0")
+    tX = torch.from_numpy(X).to(dev); tini = torch.from_numpy(g["ini"]).to(dev)
+    tobs = torch.from_numpy(np.stack(obs)).to(dev)
+    P = torch.zeros(S, dtype=torch.float64, device=dev); sse = torch.empty((3, S), dtype=torch.float64, device=dev)
+    fc = torch.full((3, S), -7, dtype=torch.int32, device=dev)
+    gpu.device.loglik_device(tX, tini, g["lens"], Time, g["L"], T, tobs, [T + 1] * 3, P, sse, floor_col=fc,
+                             flags=gpu.FLAG_KERNEL_SINGLE)
+    torch.cuda.synchronize()
+    assert np.array_equal(fc.cpu().numpy(), one["floor_col"]) and np.array_equal(sse.cpu().numpy(), one["sse"])
