@@ -135,7 +135,7 @@ def test_floor_indicator_and_contract_on_samples_that_reach_the_floor(gpu, oracl
         pls[name] = [gpu.solve_pl(g["X"][:, :12], g["lens"][c], g["Time"], g["L"], T, g["ini"][c], **mode)[0] for c in range(3)]
     # the same column in every arithmetic, and the one the oracle's PL gives
     want = np.stack([first_below(g["ref"][c]["plI"], 1e-4 * excess_scale(g["X"], g["lens"][c])) for c in range(3)])
-    assert (want >= 0).mean() > 0.9 and (want[want >= 0] > 50).all()
+    assert (want >= 0).mean() > 0.5 and (want[want >= 0] > 50).all()
     for name in IDS:
         assert np.array_equal(cols[name], want), name
     mag = np.ascontiguousarray(g["X"][:, -1])
