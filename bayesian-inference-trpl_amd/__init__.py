@@ -7,7 +7,7 @@ The directory name carries hyphens, so import it through the repo-root alias `tr
 """
 from . import _abi  # noqa: F401
 _abi.ensure_built()            # a fresh checkout builds here, before this process can have touched the GPU
-from ._abi import (FLAG_FP32, FLAG_KERNEL_PAIR, FLAG_KERNEL_SINGLE, FLAG_MIXED, FLAG_NORMALIZE, FLAG_PL_F32, FLAG_SNAP_RAW,  # noqa: F401
+from ._abi import (FLAG_FP32, FLAG_FP32_LONG, FLAG_KERNEL_PAIR, FLAG_KERNEL_SINGLE, FLAG_MIXED, FLAG_NORMALIZE, FLAG_PL_F32, FLAG_SNAP_RAW,  # noqa: F401
                    FLAG_STRICT, TrplError)
 from . import dataio, device, dist, posterior, workloads  # noqa: F401
 from .dataio import export, get_data, get_initpoints  # noqa: F401

@@ -16,6 +16,15 @@ LIB_PATH = os.environ.get("TRPL_LIBRARY", os.path.join(_HERE, "libtrpl_hip.so"))
 OK, ERR_ARG, ERR_HIP, ERR_NODEVICE, ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 FLAG_STRICT, FLAG_PL_F32, FLAG_NORMALIZE, FLAG_FP32 = 0x1, 0x2, 0x4, 0x8
 FLAG_KERNEL_PAIR, FLAG_KERNEL_SINGLE, FLAG_MIXED, FLAG_SNAP_RAW = 0x10, 0x20, 0x40, 0x80
+FLAG_FP32_LONG, FP32_MAX_STEPS = 0x1000, 256
+
+
+def fp32_flags(fp32):
+    """fp32 = False | True (TRPL_FLAG_FP32: windows of up to FP32_MAX_STEPS steps) | "long" (+ TRPL_FLAG_FP32_LONG: any
+    window, as a screening pass -- an fp32 state loses the decay over thousands of steps)."""
+    if not fp32:
+        return 0
+    return FLAG_FP32 | (FLAG_FP32_LONG if fp32 == "long" else 0)
 MAX_BUNDLE = 16                 # the flag's range; the library accepts bundle_cap(L) of it
 PL_FLOOR_EXCESS = 1e-4          # TRPL_PL_FLOOR_EXCESS
 

@@ -13,12 +13,23 @@
 // first, so not even a NaN/Inf of one system can reach the other.  Each system is computed by the
 // same instruction sequence whichever half it sits in: results do not depend on the pairing.
 //
+// WHICH two systems share a wavefront does not change their bits (tested), only how many iterations the wave runs:
+// each time step costs max(itA, itB).  Default pairing: the two curves of ONE sample that the host table names
+// (StepArgs::pair_*: curves of equal thickness and observation count, neighbouring excitation powers) -- same material
+// parameters, similar stiffness: 2.1 % of the wave-iterations lost to the partner at T = 8000 against 4.2 % for adjacent
+// samples of one curve (oracle traces, 1024 samples x 3 curves).  Without a table (one curve,
+// off-grid observations): adjacent samples of one curve.
+//
 // Convergence is per system (pvSimPCR.py:213-216): a system that has converged in this time step is
 // frozen (its lanes keep their state) while its partner iterates on; a system that hits MAX is
 // flagged (:269) and parked in its equilibrium state for the rest of the run.
 // Reference for the arithmetic: see stepper_impl.hpp (assemble / PlSink are shared with it).
 #pragma once
 #include "stepper_impl.hpp"
+
+#ifndef TRPL_E_RING
+#define TRPL_E_RING 0      // 1: field history as a register ring without the per-step shift -- measured, spills
+#endif
 
 namespace trpl {
 namespace pair {
@@ -103,12 +114,20 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
     const int ln = lane & (WS - 1);                 // lane within the system
     const bool hi = lane >= WS;
     const int64_t blk = blockIdx.x;
-    const int c = (int)(blk % a.C);
-    const int64_t sA = 2 * (blk / a.C);
-    const bool validB = sA + 1 < a.S;
-    const int64_t sB = validB ? sA + 1 : sA;        // an odd tail is computed twice and stored once
+    int cA = (int)(blk % a.C), cB = cA;
+    int64_t sA = 2 * (blk / a.C), sB = sA + 1;
+    if (a.pair_n > 0) {                             // the host's table: block k of the period that covers samples 2p, 2p + 1
+        const int k = cA;
+        cA = a.pair_cA[k]; cB = a.pair_cB[k];
+        sB = sA + a.pair_oB[k];
+        sA = sA + a.pair_oA[k];
+        if (sA >= a.S) return;                      // an odd batch: the second sample of the last period does not exist
+    }
+    const bool validB = sB < a.S;
+    if (!validB) { sB = sA; cB = cA; }              // an odd tail is computed twice and stored once
     const int64_t s = hi ? sB : sA;
-    const CurveConst &cc = a.curve[c];
+    const int c = hi ? cB : cA;
+    const CurveConst &cc = a.curve[cA];             // paired curves share thickness, grid and window: one set of scales
 
     // ---- non-dimensional material parameters (pvSimPCR.py:327-331), per lane: two samples per wave ----
     const double *xs = a.X + s * a.xld;
@@ -128,12 +147,14 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
     const int MAX = a.MAX;
 
     // ---- state U^t in registers; U^{t-1..t-4} of N and P in a 4-slot LDS ring (slot = t mod 4), E's in registers ----
+    // ring layout [slot][row][lane]{N, P}: a lane's N and P of one row and level are one ds_read_b128 / ds_write_b128
+    // (20 DS instructions per time step instead of 40); the field history is a REGISTER ring, slot (t' mod 4) too
     constexpr int HSLOT = 2 * NR * 64;
     constexpr int XCH = (XM & 1) ? 0 : 3 * 64;      // PCR exchange buffer, only for the LDS-staged levels
     __shared__ __attribute__((aligned(16))) double lds[4 * HSLOT + XCH];
-    double *hist = lds;
+    double2 *hist2 = reinterpret_cast<double2 *>(lds);            // hist2[(slot * NR + row) * 64 + lane] = {N, P}
     double *xch = lds + 4 * HSLOT;                  // never dereferenced when XCH == 0
-    double Nk[NR], Pk[NR], Ek[NR], hE[4][NR];
+    double Nk[NR], Pk[NR], Ek[NR], hE[4][NR];       // hE[q]: the field at the newest time t' <= t-1 with t' mod 4 == q
 #pragma unroll
     for (int j = 0; j < NR; j++) {                  // pvSimPCR.py:356-362
         // (a resume takes its state from the checkpoint; dN is not read -- it may be NULL there)
@@ -145,13 +166,12 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
 #pragma unroll
         for (int m = 0; m < 4; m++) {
             hE[m][j] = 0.0;
-            hist[m * HSLOT + (0 * NR + j) * 64 + lane] = 0.0;
-            hist[m * HSLOT + (1 * NR + j) * 64 + lane] = 0.0;
+            hist2[(m * NR + j) * 64 + lane] = make_double2(0.0, 0.0);
         }
     }
 
-    PlSink sinkA(a, cc, c, sA, lane_value(mag, 0));
-    PlSink sinkB(a, cc, c, sB, lane_value(mag, WS));
+    PlSink sinkA(a, cc, cA, sA, lane_value(mag, 0));
+    PlSink sinkB(a, cc, cB, sB, lane_value(mag, WS));      // same n_obs and plnorm as cA's by construction of the table
     const double rateA = lane_value(rate, 0), rateB = lane_value(rate, WS);
     sinkA.set_floor(rateA, lane_value(n0p0, 0), L);
     sinkB.set_floor(rateB, lane_value(n0p0, WS), L);
@@ -160,16 +180,15 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
     int64_t itotA = 0, itotB = 0;
     SnapSink snap(a, cc);
     // park this lane's system at equilibrium (finite, converges trivially): a flagged system for the rest of the run
-    auto park = [&](bool mine, double (&cE_)[NR]) {
+    auto park = [&](bool mine) {
 #pragma unroll
         for (int j = 0; j < NR; j++) {
             if (mine) {
-                Nk[j] = N0; Pk[j] = P0; Ek[j] = 0.0; cE_[j] = 0.0;
+                Nk[j] = N0; Pk[j] = P0; Ek[j] = 0.0;
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
                     hE[m][j] = 0.0;
-                    hist[m * HSLOT + (0 * NR + j) * 64 + lane] = N0;
-                    hist[m * HSLOT + (1 * NR + j) * 64 + lane] = P0;
+                    hist2[(m * NR + j) * 64 + lane] = make_double2(N0, P0);
                 }
             }
         }
@@ -185,11 +204,16 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
                 const int i = NR * ln + j;
                 Nk[j] = a.resN[(r5 + 4) * L + i]; Pk[j] = a.resP[(r5 + 4) * L + i]; Ek[j] = a.resE[(r5 + 4) * (L + 1) + i];
 #pragma unroll
-                for (int m = 0; m < 4; m++) {
-                    const int slot = (int)((a.t0 - 1 - m) & 3) * HSLOT;
-                    hE[m][j] = a.resE[(r5 + 3 - m) * (L + 1) + i];
-                    hist[slot + (0 * NR + j) * 64 + lane] = a.resN[(r5 + 3 - m) * L + i];
-                    hist[slot + (1 * NR + j) * 64 + lane] = a.resP[(r5 + 3 - m) * L + i];
+                for (int m = 0; m < 4; m++) {       // level t0-1-m lives in slot (t0-1-m) mod 4 of both rings
+                    const int slot = (int)((a.t0 - 1 - m) & 3);
+                    const double e_ = a.resE[(r5 + 3 - m) * (L + 1) + i];
+#if TRPL_E_RING
+#pragma unroll
+                    for (int q = 0; q < 4; q++) hE[q][j] = slot == q ? e_ : hE[q][j];
+#else
+                    hE[m][j] = e_;
+#endif
+                    hist2[(slot * NR + j) * 64 + lane] = make_double2(a.resN[(r5 + 3 - m) * L + i], a.resP[(r5 + 3 - m) * L + i]);
                 }
             }
             // a system that was flagged before the checkpoint (its newest level carries the status word, see
@@ -198,10 +222,7 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
             statusB = validB ? status_of_checkpoint(a.resN[(sinkB.orow * 5 + 4) * L], a.t0) : 0;
             deadA = statusA != 0;
             deadB = deadB || statusB != 0;
-            if (statusA || statusB) {
-                double scratch[NR];
-                park(hi ? statusB != 0 : statusA != 0, scratch);
-            }
+            if (statusA || statusB) park(hi ? statusB != 0 : statusA != 0);
         }
     }
     int64_t pl_next = 0, pl_col = 0;                // next step with t % plT == 0 and its PL column t / plT (:276)
@@ -236,20 +257,45 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
         }
 
         // BDF right-hand sides (:128-135); U^t replaces U^{t-4} in the ring
-        double bN[NR], bP[NR], bE[NR], cE[NR];
+        double bN[NR], bP[NR], bE[NR];
         {
-            const int s1 = (int)((t + 3) & 3) * HSLOT, s2 = (int)((t + 2) & 3) * HSLOT,
-                      s3 = (int)((t + 1) & 3) * HSLOT, s4 = (int)(t & 3) * HSLOT;
+            const int s1 = (int)((t + 3) & 3) * NR, s2 = (int)((t + 2) & 3) * NR,
+                      s3 = (int)((t + 1) & 3) * NR, s4 = (int)(t & 3) * NR;
 #pragma unroll
             for (int j = 0; j < NR; j++) {
-                const int oN = (0 * NR + j) * 64 + lane, oP = (1 * NR + j) * 64 + lane;
-                cE[j] = Ek[j];
-                bN[j] = a1 * Nk[j] + a2 * hist[s1 + oN] + a3 * hist[s2 + oN] + a4 * hist[s3 + oN] + a5 * hist[s4 + oN];
-                bP[j] = a1 * Pk[j] + a2 * hist[s1 + oP] + a3 * hist[s2 + oP] + a4 * hist[s3 + oP] + a5 * hist[s4 + oP];
-                bE[j] = a1 * Ek[j] + a2 * hE[0][j] + a3 * hE[1][j] + a4 * hE[2][j] + a5 * hE[3][j];
-                hist[s4 + oN] = Nk[j];
-                hist[s4 + oP] = Pk[j];
+                const double2 h1 = hist2[(s1 + j) * 64 + lane], h2 = hist2[(s2 + j) * 64 + lane],
+                              h3 = hist2[(s3 + j) * 64 + lane], h4 = hist2[(s4 + j) * 64 + lane];
+                bN[j] = a1 * Nk[j] + a2 * h1.x + a3 * h2.x + a4 * h3.x + a5 * h4.x;
+                bP[j] = a1 * Pk[j] + a2 * h1.y + a3 * h2.y + a4 * h3.y + a5 * h4.y;
+                hist2[(s4 + j) * 64 + lane] = make_double2(Nk[j], Pk[j]);
             }
+            // the field's register ring: slot (t mod 4) holds E^{t-4} and takes E^t; the four phases are four copies of
+            // this short block with the slots as compile-time indices -- nothing is ever moved (the shifted history
+            // cost 32 register moves per time step)
+#if TRPL_E_RING
+            auto rhsE = [&](auto ph) {
+                constexpr int p = decltype(ph)::value;
+#pragma unroll
+                for (int j = 0; j < NR; j++) {
+                    bE[j] = a1 * Ek[j] + a2 * hE[(p + 3) & 3][j] + a3 * hE[(p + 2) & 3][j] + a4 * hE[(p + 1) & 3][j] + a5 * hE[p][j];
+                    hE[p][j] = Ek[j];
+                }
+            };
+            switch ((int)(t & 3)) {
+            case 0: rhsE(std::integral_constant<int, 0>{}); break;
+            case 1: rhsE(std::integral_constant<int, 1>{}); break;
+            case 2: rhsE(std::integral_constant<int, 2>{}); break;
+            default: rhsE(std::integral_constant<int, 3>{}); break;
+            }
+#else
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                bE[j] = a1 * Ek[j] + a2 * hE[0][j] + a3 * hE[1][j] + a4 * hE[2][j] + a5 * hE[3][j];
+#pragma unroll
+                for (int m = 3; m >= 1; m--) hE[m][j] = hE[m - 1][j];
+                hE[0][j] = Ek[j];
+            }
+#endif
         }
 
         // ---------------- iterate, pvSimPCR.py:93-225, both systems ----------------
@@ -302,7 +348,7 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
         if (!deadB) { itotB += itB; if (itB >= MAX) { statusB = 1 + (int)t; killB = true; } }
         if (killA || killB) {
             // park the flagged system at equilibrium (finite, converges trivially) for the rest of the run
-            park(hi ? killB : killA, cE);
+            park(hi ? killB : killA);
             deadA = deadA || killA;
             deadB = deadB || killB;
         }
@@ -314,12 +360,6 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
             pl_col++;
         }
 
-#pragma unroll
-        for (int j = 0; j < NR; j++) {              // shift the field history by one level
-#pragma unroll
-            for (int m = 3; m >= 1; m--) hE[m][j] = hE[m - 1][j];
-            hE[0][j] = cE[j];
-        }
     }
 
     if (!sinkA.interp) {                            // columns parked since the last full batch
@@ -342,7 +382,7 @@ template <bool ISO, int XM>
 hipError_t launch_stepper_pair_t(const StepArgs &a, hipStream_t stream)
 {
     if (a.L != pair::L) return hipErrorInvalidValue;
-    const int64_t nblk = ((a.S + 1) / 2) * a.C;
+    const int64_t nblk = ((a.S + 1) / 2) * a.C;      // with and without a pairing table
     if (nblk <= 0) return hipSuccess;
     if (a.n_snap > 0 || a.resN != nullptr) hipLaunchKernelGGL((pair::stepper_pair_kernel<ISO, XM, true>), dim3((unsigned)nblk), dim3(64), 0, stream, a);
     else              hipLaunchKernelGGL((pair::stepper_pair_kernel<ISO, XM, false>), dim3((unsigned)nblk), dim3(64), 0, stream, a);

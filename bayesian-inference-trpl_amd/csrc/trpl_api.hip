@@ -109,6 +109,43 @@ bool use_pair_kernel(int64_t nsys, int64_t steps)
 
 constexpr uint32_t kVariantBits = TRPL_FLAG_KERNEL_PAIR | TRPL_FLAG_KERNEL_SINGLE;
 
+// Who shares a wavefront in the paired kernel.  Two curves of ONE sample have the same material parameters and need
+// similar iteration counts step by step, which is what a pair pays for (max of the two per time step); adjacent
+// samples of one curve do not.  Curves are grouped by identical grid (thickness) and observation count; inside a
+// group consecutive curves -- neighbouring excitation powers in the reference's files -- are paired for each of the
+// two samples of a period; the first curve of a group of odd size pairs with itself across the two samples.  Every
+// (curve, sample) of the period appears exactly once.  A system's bits do not depend on its partner (tested), so the
+// table is purely a scheduling matter; TRPL_PAIR_CURVES=0 switches it off for A/B measurements.
+void build_pair_table(trpl::StepArgs &a)
+{
+    a.pair_n = 0;
+    static const bool enabled = !(getenv("TRPL_PAIR_CURVES") && atoi(getenv("TRPL_PAIR_CURVES")) == 0);
+    if (!enabled || a.C < 2 || a.obs_hi != nullptr || a.pl != nullptr) return;
+    bool used[trpl::kMaxCurves] = {};
+    int k = 0;
+    for (int c0 = 0; c0 < a.C; c0++) {
+        if (used[c0]) continue;
+        int group[trpl::kMaxCurves], n = 0;
+        for (int c = c0; c < a.C; c++)
+            if (!used[c] && memcmp(a.curve[c].scales, a.curve[c0].scales, sizeof a.curve[c].scales) == 0 &&
+                a.curve[c].plnorm == a.curve[c0].plnorm && a.curve[c].n_obs == a.curve[c0].n_obs) {
+                group[n++] = c;
+                used[c] = true;
+            }
+        for (int i = n & 1; i + 1 < n; i += 2)
+            for (int off = 0; off < 2; off++) {
+                a.pair_cA[k] = (uint8_t)group[i]; a.pair_oA[k] = (uint8_t)off;
+                a.pair_cB[k] = (uint8_t)group[i + 1]; a.pair_oB[k] = (uint8_t)off;
+                k++;
+            }
+        if (n & 1) {
+            a.pair_cA[k] = a.pair_cB[k] = (uint8_t)group[0]; a.pair_oA[k] = 0; a.pair_oB[k] = 1;
+            k++;
+        }
+    }
+    a.pair_n = k;                                   // == a.C
+}
+
 }  // namespace
 
 int check_variant_flags(uint32_t flags, int32_t L)
@@ -166,6 +203,10 @@ int launch(const trpl::StepArgs &a_in, uint32_t flags, hipStream_t st, int64_t s
         if (flags & (TRPL_FLAG_STRICT | TRPL_FLAG_MIXED)) return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_FP32 excludes TRPL_FLAG_STRICT and TRPL_FLAG_MIXED");
         if (a.L < 128) return api_fail(TRPL_ERR_UNSUPPORTED, "the fp32 stepper is built for L >= 128 (got %d)", a.L);
         if (a.n_snap > 0) return api_fail(TRPL_ERR_UNSUPPORTED, "state snapshots are not available with TRPL_FLAG_FP32");
+        if (steps > TRPL_FP32_MAX_STEPS && !(flags & TRPL_FLAG_FP32_LONG))
+            return api_fail(TRPL_ERR_UNSUPPORTED, "TRPL_FLAG_FP32 over %lld time steps: an fp32 state loses the decay beyond ~%d steps "
+                            "(PL errors of percents, then tens of percents: include/trpl.h); use the fp64 / TRPL_FLAG_MIXED "
+                            "path, or add TRPL_FLAG_FP32_LONG for a screening pass", (long long)steps, TRPL_FP32_MAX_STEPS);
         hipError_t e32 = trpl::launch_stepper_f32(a, st);
         if (e32 != hipSuccess) return api_fail(TRPL_ERR_HIP, "fp32 stepper launch: %s", hipGetErrorString(e32));
         return TRPL_OK;
@@ -178,6 +219,7 @@ int launch(const trpl::StepArgs &a_in, uint32_t flags, hipStream_t st, int64_t s
         return TRPL_OK;
     }
     if (pick_pair_kernel(a.S * a.C, a.L, steps, flags)) {
+        build_pair_table(a);
         hipError_t ep = trpl::launch_stepper_pair(a, st);
         if (ep != hipSuccess) return api_fail(TRPL_ERR_HIP, "pair stepper launch: %s", hipGetErrorString(ep));
         return TRPL_OK;

@@ -62,6 +62,11 @@ struct StepArgs {
     int32_t snap_ld;        // slots per system in the snapshot arrays
     int32_t snap_t[kMaxSnaps];
     int32_t snap_slot[kMaxSnaps];
+    // stepper_pair only: which two systems share a wavefront.  pair_n = 0: adjacent samples of one curve.  pair_n = C:
+    // the C blocks of the period that covers samples 2p, 2p + 1 run the systems (curve pair_cA[k], sample 2p + pair_oA[k])
+    // and (pair_cB[k], 2p + pair_oB[k]) -- every system of the period exactly once (build_pair_table, trpl_api.hip)
+    int32_t pair_n;
+    uint8_t pair_cA[kMaxCurves], pair_oA[kMaxCurves], pair_cB[kMaxCurves], pair_oB[kMaxCurves];
     CurveConst curve[kMaxCurves];
 };
 

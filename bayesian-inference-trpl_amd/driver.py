@@ -126,7 +126,7 @@ def loglik(X, init_params, lengths, Time, L, T, obs, tol=7, MAX=10000, plT=1, P=
     iters = np.zeros((Cn, S), dtype=np.int64)
     floor_col = np.full((Cn, S), -1, dtype=np.int32)
     flags = (_abi.FLAG_STRICT if strict else 0) | (_abi.FLAG_PL_F32 if pl_f32 else 0) \
-        | (_abi.FLAG_NORMALIZE if normalize else 0) | (_abi.FLAG_FP32 if fp32 else 0) | _abi.kernel_flag(kernel) \
+        | (_abi.FLAG_NORMALIZE if normalize else 0) | _abi.fp32_flags(fp32) | _abi.kernel_flag(kernel) \
         | (_abi.FLAG_MIXED if mixed else 0) | _abi.flag_bundle(bundle, L)
     sec = _abi.C.c_double(0.0)
     lib = _abi.lib()

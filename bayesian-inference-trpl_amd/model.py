@@ -52,7 +52,7 @@ def solve_pl(matPar, Length, Time, L, T, dN, plT=1, tol=7, MAX=10000, out=None, 
     status = np.zeros(S, dtype=np.int32)
     iters = np.zeros(S, dtype=np.int64)
     sec = _abi.C.c_double(0.0)
-    flags = (_abi.FLAG_STRICT if strict else 0) | (_abi.FLAG_FP32 if fp32 else 0) | _abi.kernel_flag(kernel) \
+    flags = (_abi.FLAG_STRICT if strict else 0) | _abi.fp32_flags(fp32) | _abi.kernel_flag(kernel) \
         | (_abi.FLAG_MIXED if mixed else 0) | (_abi.FLAG_SNAP_RAW if snap_raw else 0) | _abi.flag_bundle(bundle, L)
     steps = None
     n_snap = 0

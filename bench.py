@@ -160,8 +160,8 @@ def main():
     lo, hi = trpl_amd.dist.shard_bounds(S_total, world, rank)
     S = hi - lo
     X_host = wl.samples(S_total)[lo:hi]                      # same seeded draw on every rank, own shard
-    flags = (trpl_amd.FLAG_STRICT if args.strict else 0) | (trpl_amd.FLAG_FP32 if args.fp32 else 0) \
-        | (trpl_amd.FLAG_MIXED if args.mixed else 0)
+    flags = (trpl_amd.FLAG_STRICT if args.strict else 0) | (trpl_amd.FLAG_MIXED if args.mixed else 0) \
+        | ((trpl_amd.FLAG_FP32 | trpl_amd.FLAG_FP32_LONG) if args.fp32 else 0)     # a screening-mode number, flagged as such below
     # the stepper variant is a property of the LOGICAL batch (all ranks' samples), not of this rank's shard:
     # a sample's bits then do not depend on how many GPUs the batch is cut over (include/trpl.h)
     flags = trpl_amd._abi.pin_variant(flags, S_total * C, L, T)
@@ -269,7 +269,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32 state, f64 reductions" if args.fp32 else ("f64 state, f32 correction solves" if args.mixed else "f64"),
+        "dtype": "f32 state (SCREENING mode: PL errors of percents over this window), f64 reductions" if args.fp32 else ("f64 state, f32 correction solves" if args.mixed else "f64"),
         "data": "synthetic",
         "config": {"workload": "%s x %d samples/GPU (%d total), %d curves, L=%d nodes, T=%d steps of dt=0.025 ns, "
                                "tol=1e-%d, MAX=10000, %s, arithmetic=%s"

@@ -58,7 +58,13 @@ extern "C" {
                                      steps the PL error grows to percents and, on the decayed tail, tens of
                                      percent (measured at L = 512, T = 8000: DESIGN.md section 7); use the
                                      default fp64 path (or TRPL_FLAG_MIXED) at tol_exp 6 for results.  No
-                                     reference exists for this mode (the reference is fp64 only) */
+                                     reference exists for this mode (the reference is fp64 only).  A launch that
+                                     takes more than TRPL_FP32_MAX_STEPS time steps is refused (TRPL_ERR_UNSUPPORTED)
+                                     unless TRPL_FLAG_FP32_LONG is set too */
+#define TRPL_FP32_MAX_STEPS 256   /* measured at L = 512 (tests/test_gpu_round3.py): PL error
+                                     ~1e-3 after 60 steps, percents after 1000, 0.4 after 8000 */
+#define TRPL_FLAG_FP32_LONG 0x1000 /* with TRPL_FLAG_FP32: run a window longer than TRPL_FP32_MAX_STEPS anyway -- the
+                                     caller has read the paragraph above and wants the screening pass */
 
 #define TRPL_FLAG_MIXED 0x40      /* fp64 state, history, assembly, residuals, PL and likelihood; each inner iteration
                                      solves its tridiagonal CORRECTION equation A delta = b - A c in fp32 (L >= 128, not

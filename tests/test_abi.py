@@ -237,5 +237,5 @@ def test_bundle_flag_encoding_matches_the_header():
         A.flag_bundle(5, 128)
     # no other flag uses bits 8-11
     others = [A.FLAG_STRICT, A.FLAG_PL_F32, A.FLAG_NORMALIZE, A.FLAG_FP32, A.FLAG_KERNEL_PAIR, A.FLAG_KERNEL_SINGLE,
-              A.FLAG_MIXED, A.FLAG_SNAP_RAW]
+              A.FLAG_MIXED, A.FLAG_SNAP_RAW, A.FLAG_FP32_LONG]
     assert all(f & 0xF00 == 0 for f in others) and len(set(others)) == len(others)

@@ -146,7 +146,10 @@ def test_floor_indicator_and_contract_on_samples_that_reach_the_floor(gpu, oracl
         for name in ("single", "pair"):
             dev = np.abs(pls[name][c] / ref - 1)
             assert dev[before].max() < 2e-8, (name, c, float(dev[before].max()))       # the contract, columns before floor_col
-            assert (dev <= deviation_bound(ref, excess_scale(g["X"], g["lens"][c])))[ref > 0].all()
+            scale = excess_scale(g["X"], g["lens"][c])
+            physical = ref >= 1e-10 * scale[:, None]                 # towards r ~ 1e-13 both values become rounding noise
+            worst = float(np.max((dev / deviation_bound(ref, scale))[physical]))
+            assert worst <= 5.0, (name, c, worst)                    # the measured envelope 1e-9 + 1e-12 / r, with room
             # squared-error sum over the window before floor_col: the oracle's, to 1e-8
             def sse_before(pl):
                 lg = np.log10(np.maximum(pl, np.finfo(float).tiny))
@@ -199,3 +202,32 @@ def test_floor_indicator_through_the_sharded_and_off_grid_entry_points(gpu, deca
                              flags=gpu.FLAG_KERNEL_SINGLE)
     torch.cuda.synchronize()
     assert np.array_equal(fc.cpu().numpy(), one["floor_col"]) and np.array_equal(sse.cpu().numpy(), one["sse"])
+
+
+def test_fp32_state_drifts_over_long_windows_and_says_so(gpu):
+    """BASELINE configs[4] as worded (L = 512, fp32).  An fp32 STATE cannot hold the BDF history differences (6e-8 per
+    level against a change per step of dt / tau ~ 5e-5): the 60-step window of the round-1 test (2e-3) hid that the PL
+    error grows to percents and, on the decayed tail, tens of percents.  The library therefore refuses
+    TRPL_FLAG_FP32 beyond TRPL_FP32_MAX_STEPS = 256 steps unless TRPL_FLAG_FP32_LONG is given, and this test keeps the
+    measured drift on record against the fp64 stepper (which the oracle pins at L = 512)."""
+    w = gpu.workloads
+    L, length = 512, 2000.0
+    X = w.samples(24, seed=5)
+    ini = np.stack([w.beer_lambert(A, length, L) for A in w.POWER_SCAN_A_CM3])
+    with pytest.raises(gpu.TrplError, match="FP32_LONG"):
+        gpu.solve_pl(X[:, :-1], length, 257 * DT, L, 257, ini[0], fp32=True, tol=3)
+    worst = {}
+    for T in (60, 256, 2000):
+        ref = gpu.solve_pl(X[:, :-1], length, T * DT, L, T, ini[1], tol=7)[0]
+        pl, st, _, _ = gpu.solve_pl(X[:, :-1], length, T * DT, L, T, ini[1], fp32="long" if T > 256 else True, tol=3)
+        assert not st.any()
+        ok = ref >= 1e-6 * ref[:, :1]                            # measurable PL only
+        worst[T] = float(np.max(np.abs(pl / ref - 1)[ok]))
+    assert worst[60] < 5e-3 and worst[256] < 5e-2               # the window the flag alone allows: screening quality
+    assert worst[2000] > 3 * worst[256] and worst[2000] > 1e-2  # and it keeps growing: percents by 2000 steps
+    # the likelihood entry points apply the same rule (steps up to the last observation)
+    obs = [np.full(300, 15.0)] * 3
+    with pytest.raises(gpu.TrplError, match="FP32_LONG"):
+        gpu.loglik(X, ini, length, 400 * DT, L, 400, obs, fp32=True, tol=3)
+    P = gpu.loglik(X, ini, length, 400 * DT, L, 400, [o[:200] for o in obs], fp32=True, tol=3)      # 199 steps: allowed
+    assert np.isfinite(P).all()

@@ -31,7 +31,7 @@ ini, lens = wl.power_scan(L)
 C = len(lens)
 A = tp._abi
 MODES = [("fp64", 0, 7), ("fp64", 0, 6), ("fp64", 0, 5), ("fp64", 0, 4),
-         ("fp32 state", A.FLAG_FP32, 3), ("fp32 state", A.FLAG_FP32, 4)]
+         ("fp32 state", A.FLAG_FP32 | A.FLAG_FP32_LONG, 3), ("fp32 state", A.FLAG_FP32 | A.FLAG_FP32_LONG, 4)]
 if hasattr(A, "FLAG_MIXED"):
     MODES += [("fp64 state + fp32 solve", A.FLAG_MIXED, t) for t in (7, 6, 5, 4)]
 
