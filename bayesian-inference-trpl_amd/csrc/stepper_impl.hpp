@@ -614,6 +614,8 @@ stepper_kernel(const StepArgs a)
     constexpr int LDSW = HREG ? 2 : 4 * HSLOT + XCH;                // per wavefront
     __shared__ __attribute__((aligned(16))) double lds[LDSW * (BUNDLE ? bundle_cap(L) : 1)];
     double *hist = lds + (BUNDLE ? wv * LDSW : 0);
+    // ring layout [slot][row][lane]{N, P}: a lane's N and P of one row and level are ONE 16-byte LDS access
+    double2 *hist2 = reinterpret_cast<double2 *>(hist);
     double *xch = hist + (HREG ? 0 : 4 * HSLOT);    // PCR exchange buffer (LAY 2)
     const int hl = lane64;                          // this lane's column of the ring
     double Nk[NR], Pk[NR], Ek[NR];
@@ -633,7 +635,7 @@ stepper_kernel(const StepArgs a)
         for (int m = 0; m < 4; m++) {
             hE[m][j] = 0.0;
             if constexpr (HREG) { hN[m][j] = 0.0; hP[m][j] = 0.0; }
-            else { hist[m * HSLOT + (0 * NR + j) * 64 + hl] = 0.0; hist[m * HSLOT + (1 * NR + j) * 64 + hl] = 0.0; }
+            else hist2[(m * NR + j) * 64 + hl] = make_double2(0.0, 0.0);
         }
     }
 
@@ -665,8 +667,8 @@ stepper_kernel(const StepArgs a)
                     hE[m][j] = a.resE[(r5 + 3 - m) * (L + 1) + i];
                     if constexpr (HREG) { hN[m][j] = n_; hP[m][j] = p_; }
                     else {
-                        const int slot = (int)((a.t0 - 1 - m) & 3) * HSLOT;      // the ring: slot (t' mod 4) holds U^{t'}
-                        hist[slot + (0 * NR + j) * 64 + hl] = n_; hist[slot + (1 * NR + j) * 64 + hl] = p_;
+                        const int slot = (int)((a.t0 - 1 - m) & 3);      // the ring: slot (t' mod 4) holds U^{t'}
+                        hist2[(slot * NR + j) * 64 + hl] = make_double2(n_, p_);
                     }
                 }
             }
@@ -731,27 +733,32 @@ stepper_kernel(const StepArgs a)
 
         // ---------------- iterate, pvSimPCR.py:93-225 ----------------
         double bN[NR], bP[NR], bE[NR];
-        double cN[NR], cP[NR], cE[NR];             // cN, cP HREG only: U^t, to enter the history after the step
+        // BDF right-hand sides from U^t and the four older levels (:128-135); then U^t enters the history at once (no
+        // copy of it is carried through the iterations)
         if constexpr (HREG) {
 #pragma unroll
-            for (int j = 0; j < NR; j++) {         // :128-135
-                cN[j] = Nk[j]; cP[j] = Pk[j]; cE[j] = Ek[j];
+            for (int j = 0; j < NR; j++) {
                 bN[j] = a1 * Nk[j] + a2 * hN[0][j] + a3 * hN[1][j] + a4 * hN[2][j] + a5 * hN[3][j];
                 bP[j] = a1 * Pk[j] + a2 * hP[0][j] + a3 * hP[1][j] + a4 * hP[2][j] + a5 * hP[3][j];
                 bE[j] = a1 * Ek[j] + a2 * hE[0][j] + a3 * hE[1][j] + a4 * hE[2][j] + a5 * hE[3][j];
+#pragma unroll
+                for (int m = 3; m >= 1; m--) { hN[m][j] = hN[m - 1][j]; hP[m][j] = hP[m - 1][j]; hE[m][j] = hE[m - 1][j]; }
+                hN[0][j] = Nk[j]; hP[0][j] = Pk[j]; hE[0][j] = Ek[j];
             }
         } else {
-            const int s1 = (int)((t + 3) & 3) * HSLOT, s2 = (int)((t + 2) & 3) * HSLOT,
-                      s3 = (int)((t + 1) & 3) * HSLOT, s4 = (int)(t & 3) * HSLOT;   // slots of t-1 .. t-4
+            const int s1 = (int)((t + 3) & 3) * NR, s2 = (int)((t + 2) & 3) * NR,
+                      s3 = (int)((t + 1) & 3) * NR, s4 = (int)(t & 3) * NR;        // slots of t-1 .. t-4
 #pragma unroll
             for (int j = 0; j < NR; j++) {
-                const int oN = (0 * NR + j) * 64 + hl, oP = (1 * NR + j) * 64 + hl;
-                cE[j] = Ek[j];
-                bN[j] = a1 * Nk[j] + a2 * hist[s1 + oN] + a3 * hist[s2 + oN] + a4 * hist[s3 + oN] + a5 * hist[s4 + oN];
-                bP[j] = a1 * Pk[j] + a2 * hist[s1 + oP] + a3 * hist[s2 + oP] + a4 * hist[s3 + oP] + a5 * hist[s4 + oP];
+                const double2 h1 = hist2[(s1 + j) * 64 + hl], h2 = hist2[(s2 + j) * 64 + hl],
+                              h3 = hist2[(s3 + j) * 64 + hl], h4 = hist2[(s4 + j) * 64 + hl];
+                bN[j] = a1 * Nk[j] + a2 * h1.x + a3 * h2.x + a4 * h3.x + a5 * h4.x;
+                bP[j] = a1 * Pk[j] + a2 * h1.y + a3 * h2.y + a4 * h3.y + a5 * h4.y;
                 bE[j] = a1 * Ek[j] + a2 * hE[0][j] + a3 * hE[1][j] + a4 * hE[2][j] + a5 * hE[3][j];
-                hist[s4 + oN] = Nk[j];             // U^t replaces U^{t-4} (same slot, t mod 4)
-                hist[s4 + oP] = Pk[j];
+                hist2[(s4 + j) * 64 + hl] = make_double2(Nk[j], Pk[j]);            // U^t replaces U^{t-4} (same slot, t mod 4)
+#pragma unroll
+                for (int m = 3; m >= 1; m--) hE[m][j] = hE[m - 1][j];
+                hE[0][j] = Ek[j];
             }
         }
         int it = MAX;                              // value if the loop runs to exhaustion (:225)
@@ -812,16 +819,6 @@ stepper_kernel(const StepArgs a)
             pl_col++;
         }
 
-#pragma unroll
-        for (int j = 0; j < NR; j++) {             // shift the register histories by one level
-#pragma unroll
-            for (int m = 3; m >= 1; m--) {
-                hE[m][j] = hE[m - 1][j];
-                if constexpr (HREG) { hN[m][j] = hN[m - 1][j]; hP[m][j] = hP[m - 1][j]; }
-            }
-            hE[0][j] = cE[j];
-            if constexpr (HREG) { hN[0][j] = cN[j]; hP[0][j] = cP[j]; }
-        }
     }
 
     if (!(STRICT || sink.interp) && valid) {       // columns parked since the last full batch
