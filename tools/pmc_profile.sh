@@ -12,5 +12,5 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_IFETCH SQ_IFETCH_LEVEL SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_MISC SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_INST_LEVEL_LDS SQ_INSTS" \
            "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc_${TAG}_$i -- python3 $R/bench.py --steps 1 --warmup 0 --T 100 --no-cpu-baseline --no-pcr --no-full-length --no-host-api $BENCH_EXTRA > $R/gpurun_out/pmc_${TAG}_$i.log 2>&1 || echo "pmc set $i failed"
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc_${TAG}_$i -- python3 $R/bench.py --steps 1 --warmup 0 --T 100 --no-cpu-baseline --no-pcr --no-full-length --no-host-api --no-other-configs $BENCH_EXTRA > $R/gpurun_out/pmc_${TAG}_$i.log 2>&1 || echo "pmc set $i failed"
 done
