@@ -231,3 +231,43 @@ def test_fp32_state_drifts_over_long_windows_and_says_so(gpu):
         gpu.loglik(X, ini, length, 400 * DT, L, 400, obs, fp32=True, tol=3)
     P = gpu.loglik(X, ini, length, 400 * DT, L, 400, [o[:200] for o in obs], fp32=True, tol=3)      # 199 steps: allowed
     assert np.isfinite(P).all()
+
+
+def test_multi_device_call_is_ordered_against_the_callers_torch_stream(gpu):
+    """trpl_loglik_multi_dev works on the handle's own streams.  MultiDevice.loglik(order=True) makes them wait for what
+    the caller's torch stream holds (trpl_multi_wait_stream) and makes that stream wait for the result
+    (trpl_multi_release_stream), on the device: parameters written by a copy that is still QUEUED behind ~0.3 s of
+    other work when loglik() is called are the ones the solve reads, and a read of P_full queued right after the call
+    sees the gathered vector -- no host synchronisation anywhere in between (round-2 advisor finding)."""
+    import torch
+    w = gpu.workloads
+    dev = torch.device("cuda:0")
+    L, T, S = 128, 40, 1500
+    Time = T * DT
+    ini, lens = w.power_scan(L)
+    Xa, Xb = w.samples(S, seed=21), w.samples(S, seed=22)
+    ini_d = torch.from_numpy(ini).to(dev)
+    obs = torch.full((3, T + 1), 15.0, dtype=torch.float64, device=dev)
+    want = {}
+    for name, Xh in (("a", Xa), ("b", Xb)):
+        Xd = torch.from_numpy(Xh).to(dev)
+        P = torch.zeros(S, dtype=torch.float64, device=dev); sse = torch.empty((3, S), dtype=torch.float64, device=dev)
+        gpu.device.loglik_device(Xd, ini_d, lens, Time, L, T, obs, [T + 1] * 3, P, sse, flags=gpu.FLAG_KERNEL_SINGLE)
+        torch.cuda.synchronize()
+        want[name] = P.clone()
+    assert not torch.equal(want["a"], want["b"])
+    X = torch.from_numpy(Xa).to(dev)
+    Xb_pinned = torch.from_numpy(Xb).pin_memory()
+    Pf = torch.zeros(S, dtype=torch.float64, device=dev)
+    out = torch.empty(S, dtype=torch.float64, device=dev)
+    with gpu.device.MultiDevice([0]) as md:
+        md.loglik([X], [ini_d], lens, Time, L, T, [obs], [T + 1] * 3, [Pf], flags=gpu.FLAG_KERNEL_SINGLE)      # warm: RCCL channels up
+        md.synchronize()
+        torch.cuda.synchronize()
+        torch.cuda._sleep(int(6e8))                          # ~0.3 s of work ahead of the copy on the torch stream
+        X.copy_(Xb_pinned, non_blocking=True)                # still queued when loglik() is called
+        md.loglik([X], [ini_d], lens, Time, L, T, [obs], [T + 1] * 3, [Pf], flags=gpu.FLAG_KERNEL_SINGLE)
+        out.copy_(Pf)                                        # queued on the torch stream right behind the call
+        torch.cuda.synchronize()
+        md.synchronize()
+    assert torch.equal(out, want["b"])
