@@ -1,4 +1,4 @@
-// FAST time-stepper for L = 128 with TWO SYSTEMS PER WAVEFRONT (same curve, adjacent samples).
+// FAST time-stepper for L = 128 with TWO SYSTEMS PER WAVEFRONT (two curves of one sample, or adjacent samples of one curve).
 //
 // Why: the tridiagonal solve is the largest part of an inner iteration, and its in-lane
 // cyclic-reduction levels are work-efficient (O(rows)) while the cross-lane PCR levels are not
