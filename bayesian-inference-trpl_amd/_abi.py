@@ -61,6 +61,7 @@ SIGNATURES = {
     "trpl_abi_version": [],
     "trpl_last_error": [],
     "trpl_device_count": [],
+    "trpl_pair_table": [_vp, _vp, _i32, _i32, _i64, _f64, _vp, _vp, _vp, _vp],
     "trpl_solve_pl": [_vp, _i64, _f64, _f64, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _i64, _vp, _vp, _u32,
                       _i32, _pd],
     "trpl_solve_pl_dev": [_vp, _i64, _f64, _f64, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _i64, _vp, _vp,

@@ -244,6 +244,25 @@ int trpl_kernel_variant(int64_t nsys, int32_t L, int64_t steps, uint32_t flags)
     return pick_pair_kernel(nsys, L, steps, flags) ? TRPL_KERNEL_FAST_PAIR : TRPL_KERNEL_FAST;
 }
 
+int trpl_pair_table(const double *lengths_nm, const int64_t *n_obs, int32_t C, int32_t L, int64_t T, double time_ns,
+                    int32_t *cA, int32_t *oA, int32_t *cB, int32_t *oB)
+{
+    if (C < 1 || C > trpl::kMaxCurves) return -api_fail(TRPL_ERR_ARG, "C=%d must be in [1, %d]", C, trpl::kMaxCurves);
+    if (!lengths_nm || !n_obs || !cA || !oA || !cB || !oB) return -api_fail(TRPL_ERR_ARG, "NULL pointer argument");
+    if (int rc = check_grid(L, T, 1, 1, time_ns)) return -rc;
+    trpl::StepArgs a;
+    memset(&a, 0, sizeof a);
+    a.C = C; a.L = L; a.T = T;
+    for (int c = 0; c < C; c++) {
+        if (!(lengths_nm[c] > 0)) return -api_fail(TRPL_ERR_ARG, "lengths_nm[%d] must be > 0", c);
+        curve_const(lengths_nm[c], time_ns, L, T, a.curve[c]);
+        a.curve[c].n_obs = n_obs[c];
+    }
+    build_pair_table(a);
+    for (int k = 0; k < a.pair_n; k++) { cA[k] = a.pair_cA[k]; oA[k] = a.pair_oA[k]; cB[k] = a.pair_cB[k]; oB[k] = a.pair_oB[k]; }
+    return a.pair_n;
+}
+
 int trpl_device_count(void)
 {
     int n = 0;

@@ -108,6 +108,17 @@ extern "C" {
 #define TRPL_KERNEL_MIXED 4
 int trpl_kernel_variant(int64_t nsys, int32_t L, int64_t steps, uint32_t flags);
 
+/* Who shares a wavefront in the two-systems-per-wavefront stepper of a fused on-grid likelihood launch (a scheduling
+ * matter only: a system's bits do not depend on its partner).  Curves with the same thickness and observation count
+ * form a group; inside a group consecutive curves -- neighbouring excitation powers in the reference's files -- are
+ * paired for each of the two samples of a period (samples 2p, 2p + 1), and the first curve of a group of odd size pairs
+ * with itself across the two samples: two curves of ONE sample need similar iteration counts step by step, adjacent
+ * samples of one curve do not.  Fills cA/oA/cB/oB [C]: block k of a period runs the systems (curve
+ * cA[k], sample 2p + oA[k]) and (cB[k], 2p + oB[k]); returns the number of entries (C; 0 when the table is not used: one
+ * curve), or -TRPL_ERR_* on a bad argument.  Host only, no device needed. */
+int trpl_pair_table(const double *lengths_nm, const int64_t *n_obs, int32_t C, int32_t L, int64_t T, double time_ns,
+                    int32_t *cA, int32_t *oA, int32_t *cB, int32_t *oB);
+
 int trpl_abi_version(void);
 const char *trpl_last_error(void);
 /* number of visible HIP devices (0 with none); never fails */

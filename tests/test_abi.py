@@ -239,3 +239,39 @@ def test_bundle_flag_encoding_matches_the_header():
     others = [A.FLAG_STRICT, A.FLAG_PL_F32, A.FLAG_NORMALIZE, A.FLAG_FP32, A.FLAG_KERNEL_PAIR, A.FLAG_KERNEL_SINGLE,
               A.FLAG_MIXED, A.FLAG_SNAP_RAW, A.FLAG_FP32_LONG]
     assert all(f & 0xF00 == 0 for f in others) and len(set(others)) == len(others)
+
+
+def test_pair_table_covers_every_system_of_a_period_once(trpl):
+    """trpl_pair_table: the paired stepper's rule for who shares a wavefront (host logic, no device).  Every (curve, sample
+    offset) of a two-sample period appears exactly once; partners have the same thickness and observation count;
+    same-sample pairs are neighbouring curves of a group, a group of odd size pairs its first curve across the samples."""
+    lib = trpl._abi.lib()
+
+    def table(lengths, n_obs):
+        C = len(lengths)
+        ln = np.ascontiguousarray(lengths, dtype=np.float64)
+        no = np.ascontiguousarray(n_obs, dtype=np.int64)
+        out = [np.full(C, -1, dtype=np.int32) for _ in range(4)]
+        n = lib.trpl_pair_table(ln.ctypes.data, no.ctypes.data, C, 128, 8000, 200.0, *[o.ctypes.data for o in out])
+        return n, [tuple(int(o[k]) for o in out) for k in range(max(n, 0))]
+
+    n, t = table([2000.0] * 3, [8001] * 3)                       # Power_scan
+    assert n == 3 and t == [(1, 0, 2, 0), (1, 1, 2, 1), (0, 0, 0, 1)]
+    n, t = table([311.0, 2000.0] * 3, [8001] * 6)                # Twothick: two groups of three
+    assert n == 6 and t == [(2, 0, 4, 0), (2, 1, 4, 1), (0, 0, 0, 1), (3, 0, 5, 0), (3, 1, 5, 1), (1, 0, 1, 1)]
+    n, t = table([2000.0] * 4, [8001] * 4)                       # even group: only same-sample pairs
+    assert t == [(0, 0, 1, 0), (0, 1, 1, 1), (2, 0, 3, 0), (2, 1, 3, 1)]
+    n, t = table([2000.0] * 3, [8001, 8001, 500])                # a different observation count is a group of its own
+    assert t == [(0, 0, 1, 0), (0, 1, 1, 1), (2, 0, 2, 1)]
+    assert table([2000.0], [8001])[0] == 0                       # one curve: adjacent samples, no table
+    rng = np.random.default_rng(0)
+    for _ in range(50):                                          # any grouping: a partition of the period's 2 C systems
+        C = int(rng.integers(2, 17))
+        lengths = rng.choice([311.0, 1000.0, 2000.0], C)
+        n_obs = rng.choice([100, 8001], C)
+        n, t = table(lengths, n_obs)
+        seen = sorted([(a, oa) for a, oa, _, _ in t] + [(b, ob) for _, _, b, ob in t])
+        assert n == C and seen == sorted((c, o) for c in range(C) for o in (0, 1))
+        for a, oa, b, ob in t:
+            assert lengths[a] == lengths[b] and n_obs[a] == n_obs[b] and ((a != b and oa == ob) or (a == b and (oa, ob) == (0, 1)))
+    assert lib.trpl_pair_table(None, None, 3, 128, 8000, 200.0, None, None, None, None) == -trpl._abi.ERR_ARG

@@ -271,3 +271,33 @@ def test_multi_device_call_is_ordered_against_the_callers_torch_stream(gpu):
         torch.cuda.synchronize()
         md.synchronize()
     assert torch.equal(out, want["b"])
+
+
+def test_likelihoods_do_not_depend_on_the_pairing_rule(gpu, tmp_path):
+    """The paired stepper pairs two curves of one sample (trpl_pair_table) or, with TRPL_PAIR_CURVES=0, adjacent samples
+    of one curve.  Scheduling only: likelihoods, per-curve sums, iteration totals, status and floor columns are the
+    same bits -- Twothick (two groups of three curves: same-sample pairs and cross-sample leftovers), an odd batch (the
+    last period has one sample), two child processes because the switch is read once per process."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    code = ("import sys, numpy as np\\n"
+            "sys.path.insert(0, %r)\\n"
+            "import trpl_amd\\n"
+            "w = trpl_amd.workloads\\n"
+            "ini, lens = w.twothick(128)\\n"
+            "X = w.samples(4099, seed=17)\\n"
+            "T = 300\\n"
+            "obs = [np.linspace(17.0, 14.0, T + 1)] * 6\\n"
+            "info = {}\\n"
+            "P = trpl_amd.loglik(X, ini, lens, T * 0.025, 128, T, obs, info=info, kernel='pair')\\n"
+            "np.savez(sys.argv[1], P=P, sse=info['sse'], it=info['iters_total'], st=info['status'], fc=info['floor_col'])\\n") % ROOT
+    out = {}
+    for v in ("0", "1"):
+        path = str(tmp_path / ("pair%s.npz" % v))
+        env = dict(os.environ, TRPL_PAIR_CURVES=v, TRPL_AUTOBUILD="0")
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[v] = np.load(path)
+    for k in ("P", "sse", "it", "st", "fc"):
+        assert np.array_equal(out["0"][k], out["1"][k]), k
+    assert np.isfinite(out["1"]["P"]).all() and not out["1"]["st"].any()
