@@ -280,17 +280,17 @@ def test_likelihoods_do_not_depend_on_the_pairing_rule(gpu, tmp_path):
     last period has one sample), two child processes because the switch is read once per process."""
     import os, subprocess, sys
     from conftest import ROOT
-    code = ("import sys, numpy as np\\n"
-            "sys.path.insert(0, %r)\\n"
-            "import trpl_amd\\n"
-            "w = trpl_amd.workloads\\n"
-            "ini, lens = w.twothick(128)\\n"
-            "X = w.samples(4099, seed=17)\\n"
-            "T = 300\\n"
-            "obs = [np.linspace(17.0, 14.0, T + 1)] * 6\\n"
-            "info = {}\\n"
-            "P = trpl_amd.loglik(X, ini, lens, T * 0.025, 128, T, obs, info=info, kernel='pair')\\n"
-            "np.savez(sys.argv[1], P=P, sse=info['sse'], it=info['iters_total'], st=info['status'], fc=info['floor_col'])\\n") % ROOT
+    code = ("import sys, numpy as np\n"
+            "sys.path.insert(0, %r)\n"
+            "import trpl_amd\n"
+            "w = trpl_amd.workloads\n"
+            "ini, lens = w.twothick(128)\n"
+            "X = w.samples(4099, seed=17)\n"
+            "T = 300\n"
+            "obs = [np.linspace(17.0, 14.0, T + 1)] * 6\n"
+            "info = {}\n"
+            "P = trpl_amd.loglik(X, ini, lens, T * 0.025, 128, T, obs, info=info, kernel='pair')\n"
+            "np.savez(sys.argv[1], P=P, sse=info['sse'], it=info['iters_total'], st=info['status'], fc=info['floor_col'])\n") % ROOT
     out = {}
     for v in ("0", "1"):
         path = str(tmp_path / ("pair%s.npz" % v))
