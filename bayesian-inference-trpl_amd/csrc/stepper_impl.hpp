@@ -184,15 +184,17 @@ struct PlSink {
     const double *obs;
     const int32_t *obs_hi;   // off-grid observation times (trpl_loglik_obs) or nullptr
     const double *obs_dx, *obs_h;
-    int64_t ncol_ll;         // number of observations of this curve (0 outside likelihood mode)
-    int64_t t_last;          // last step that can influence an output
-    int64_t next_obs = 0;
+    // columns and steps are 32-bit (T < 2^31, checked at the ABI): the per-step bookkeeping is scalar code, and
+    // 64-bit scalar adds / compares are two instructions each; only addresses are formed in 64 bits
+    int32_t ncol_ll;         // number of observations of this curve (0 outside likelihood mode)
+    int32_t t_last;          // last step that can influence an output
+    int32_t next_obs = 0;
     double mag, lg_prev = 0.0, sse = 0.0, pl0_d = 1.0;
     float pl0_f = 1.0f;
     bool want_pl, want_ll, interp;
     // batched emission (FAST): lane k parks column base+k; a batch of up to 64 columns is processed at once
     double pend = 0.0;
-    int64_t base = 0;
+    int32_t base = 0;
     // the cancellation floor (include/trpl.h, floor_col): first compared column whose PL = B (sum N P - L n0p0) is
     // below kPlFloorExcess of B L n0p0, i.e. whose mean excess product is a 1e-4 of the equilibrium product: the
     // ~1e-12 by which two correct fp64 evaluations of the state differ is then amplified to >= 1e-8 of PL
@@ -207,7 +209,7 @@ struct PlSink {
     {
         want_pl = a.pl != nullptr;
         want_ll = a.sse != nullptr;
-        ncol_ll = want_ll ? cc.n_obs : 0;
+        ncol_ll = want_ll ? (int32_t)cc.n_obs : 0;
         obs = want_ll ? a.obs + (int64_t)c * a.obs_ld : nullptr;
         interp = want_ll && a.obs_hi != nullptr;
         obs_hi = interp ? a.obs_hi + (int64_t)c * a.obs_ld : nullptr;
@@ -215,7 +217,7 @@ struct PlSink {
         obs_h = interp ? a.obs_h + (int64_t)c * a.obs_ld : nullptr;
         // all T+1 steps when PL is stored (the reference runs them all), otherwise up to the last
         // observation
-        t_last = want_pl ? a.T : (interp ? (int64_t)obs_hi[ncol_ll - 1] : (ncol_ll - 1) * a.plT);
+        t_last = want_pl ? (int32_t)a.T : (interp ? obs_hi[ncol_ll - 1] : (ncol_ll - 1) * a.plT);
     }
 
     // a spare wavefront of a short bundle: computes, emits nothing (t_last stays the workgroup's)
@@ -223,7 +225,7 @@ struct PlSink {
 
     // plv = rate * (sum N P - L n0 p0) of the state at time t = col * plT, non-dimensional.  The steppers count
     // PL columns instead of dividing t by plT every step (a 64-bit scalar division is ~130 instructions).
-    __device__ __forceinline__ void emit(int64_t col, double plv)
+    __device__ __forceinline__ void emit(int32_t col, double plv)
     {
         if (a.floor_col && (interp || col < ncol_ll) && first_floor < 0 && !(plv >= pl_floor)) first_floor = (int32_t)col;
         if (want_pl && lane_ == 0) {                                                   // :281,:393
@@ -250,7 +252,7 @@ struct PlSink {
         } else {
             // every observation bracketed by grid points (col-1, col): scipy interp1d's
             // slope * (x - x_lo) + y_lo (bayeslib.py:189)
-            while (next_obs < ncol_ll && obs_hi[next_obs] == (int32_t)col) {
+            while (next_obs < ncol_ll && obs_hi[next_obs] == col) {
                 const double dy = (a.flags & kFlagPlF32) ? (double)((float)lg - (float)lg_prev) : lg - lg_prev;
                 const double y = (dy / obs_h[next_obs]) * obs_dx[next_obs] + lg_prev;
                 double err = y + mag;
@@ -270,9 +272,9 @@ struct PlSink {
     // batch are added by a wave reduction, so the likelihood sum is associated differently from the
     // reference's serial loop (~1e-16 relative; STRICT keeps emit()).  Not used for off-grid
     // observation times, which need consecutive values in order (emit()).
-    __device__ __forceinline__ void push(int64_t col, double plv)
+    __device__ __forceinline__ void push(int32_t col, double plv)
     {
-        if ((int64_t)lane_ == col - base) pend = plv;
+        if (lane_ == col - base) pend = plv;
         if (col - base == 63) flush_batch(64);
     }
 
@@ -280,7 +282,7 @@ struct PlSink {
     {
         if (n > 0) {
             const int lane = lane_;
-            const int64_t col = base + lane;
+            const int32_t col = base + lane;
             const bool live = lane < n;
             const bool f32 = (a.flags & kFlagPlF32) != 0;
             double v;                                       // re-dimensionalised PL (pvSimPCR.py:393)
@@ -652,10 +654,10 @@ stepper_kernel(const StepArgs a)
     __shared__ int agree[2][BUNDLE ? bundle_cap(L) : 1];
     unsigned phase = 0;
 
-    int64_t t_begin = 0;
+    int32_t t_begin = 0;
     if constexpr (SNAP) {
         if (a.resN != nullptr) {                   // resume at t0 >= 4 from the five levels U^{t0-4} .. U^{t0} (level m <-> t0-4+m)
-            t_begin = a.t0;
+            t_begin = (int32_t)a.t0;
             const int64_t r5 = sink.orow * 5;
 #pragma unroll
             for (int j = 0; j < NR; j++) {
@@ -674,7 +676,7 @@ stepper_kernel(const StepArgs a)
             }
         }
     }
-    int64_t pl_next = 0, pl_col = 0;               // next step with t % plT == 0 and its PL column t / plT (:276)
+    int32_t pl_next = 0, pl_col = 0;               // next step with t % plT == 0 and its PL column t / plT (:276)
     if constexpr (SNAP) {
         if (t_begin > 0) { pl_col = (t_begin + a.plT - 1) / a.plT; pl_next = pl_col * a.plT; sink.base = pl_col; }
         if (a.resN != nullptr) {
@@ -691,7 +693,7 @@ stepper_kernel(const StepArgs a)
             if (st0) { status = st0; t_begin = sink.t_last + 1; }
         }
     }
-    for (int64_t t = t_begin; t <= sink.t_last; t++) {   // tEvol, pvSimPCR.py:237
+    for (int32_t t = t_begin; t <= sink.t_last; t++) {   // tEvol, pvSimPCR.py:237
         if constexpr (SNAP) {                      // the state at time t, before it is stepped (:283-288)
             if (snap.due(t))
                 snap.template take<NR, L>(Nk, Pk, Ek, sink.orow, valid && lane64 < W,

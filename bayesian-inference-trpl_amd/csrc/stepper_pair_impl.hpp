@@ -194,10 +194,10 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
         }
     };
 
-    int64_t t_begin = 0;
+    int32_t t_begin = 0;
     if constexpr (SNAP) {
         if (a.resN != nullptr) {                    // resume at t0 >= 4 (see stepper_impl.hpp)
-            t_begin = a.t0;
+            t_begin = (int32_t)a.t0;
             const int64_t r5 = (hi ? sinkB.orow : sinkA.orow) * 5;
 #pragma unroll
             for (int j = 0; j < NR; j++) {
@@ -225,11 +225,11 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
             if (statusA || statusB) park(hi ? statusB != 0 : statusA != 0);
         }
     }
-    int64_t pl_next = 0, pl_col = 0;                // next step with t % plT == 0 and its PL column t / plT (:276)
+    int32_t pl_next = 0, pl_col = 0;                // next step with t % plT == 0 and its PL column t / plT (:276)
     if constexpr (SNAP) {
         if (t_begin > 0) { pl_col = (t_begin + a.plT - 1) / a.plT; pl_next = pl_col * a.plT; sinkA.base = sinkB.base = pl_col; }
     }
-    for (int64_t t = t_begin; t <= sinkA.t_last; t++) {   // tEvol, pvSimPCR.py:237
+    for (int32_t t = t_begin; t <= sinkA.t_last; t++) {   // tEvol, pvSimPCR.py:237
         if (deadA && deadB) break;
         if constexpr (SNAP) {                       // the state at time t, before it is stepped (:283-288)
             if (snap.due(t))
