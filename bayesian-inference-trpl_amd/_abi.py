@@ -215,6 +215,12 @@ def lib():
         if not os.path.isfile(LIB_PATH):
             raise ImportError("%s not found: build it with `make -C %s` (hipcc, gfx950); "
                               "there is no CPU fallback" % (LIB_PATH, _HERE))
+        if "TRPL_LIBRARY" not in os.environ and not library_is_current():
+            # no compiler here (or TRPL_AUTOBUILD=0): the binary could not be brought up to date -- say so, loudly
+            import warnings
+            warnings.warn("%s was built from other sources than the ones next to it (csrc/, include/trpl.h, Makefile) and "
+                          "could not be rebuilt here: results are those of the OLD kernels; run `make -C %s`"
+                          % (LIB_PATH, _HERE), RuntimeWarning, stacklevel=2)
         _share_torch_hip_runtime()
         dll = C.CDLL(LIB_PATH)
         dll.trpl_abi_version.restype = C.c_int

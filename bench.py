@@ -297,6 +297,14 @@ def main():
                              "kernel is ~0.1 KB per system by construction (see profiles/)"},
     }
 
+    if variant == trpl_amd._abi.KERNEL_FAST_PAIR:             # who shares a wavefront (scheduling only: bits do not depend on it)
+        tab = [np.full(C, -1, dtype=np.int32) for _ in range(4)]
+        ln_ = np.ascontiguousarray(lens, dtype=np.float64)
+        no_ = np.full(C, T + 1, dtype=np.int64)
+        n_tab = trpl_amd._abi.lib().trpl_pair_table(ln_.ctypes.data, no_.ctypes.data, C, L, T, Time, *[t_.ctypes.data for t_ in tab])
+        out["roofline"]["wavefront_pairs"] = ("adjacent samples of one curve" if n_tab <= 0 or os.environ.get("TRPL_PAIR_CURVES") == "0" else
+                                              [{"curves": [int(tab[0][k]), int(tab[2][k])], "sample_offsets": [int(tab[1][k]), int(tab[3][k])]}
+                                               for k in range(n_tab)])
     if world > 1:
         out["rccl"] = rccl_record(torch, dist, trpl_amd, args, rank, world, local_rank, dev, cdev, S_total, ev_ag)
     if rank == 0 and world == 1 and not args.no_other_configs and args.workload == "power_scan" and L == 128 \

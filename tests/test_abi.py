@@ -217,6 +217,13 @@ def test_a_library_older_than_its_sources_is_rebuilt_not_used(tmp_path):
     os.utime(dst / "libtrpl_hip.so", (later, later)); os.utime(dst / "libtrpl_hip.so.srchash", (later + 1, later + 1))
     r = run(); assert r.returncode == 0, r.stderr[-1500:]
     assert builds() == 3
+    # where it cannot be rebuilt (TRPL_AUTOBUILD=0, or no compiler) a stale binary is at least not used SILENTLY
+    with open(dst / "csrc" / "trpl_common.hpp", "a") as fh:
+        fh.write("// edited again\n")
+    warn = code.replace("assert m._abi.library_is_current()\n", "")
+    r = subprocess.run([sys.executable, "-W", "always", "-c", warn], env=dict(env, TRPL_AUTOBUILD="0"), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and builds() == 3 and "built from other sources" in r.stderr, r.stderr[-1500:]
 
 
 def test_bundle_flag_encoding_matches_the_header():
