@@ -164,3 +164,29 @@ def test_bracket_times_is_interp1d_bracketing(trpl):
     assert np.array_equal(got, want) and hi.min() >= 1 and hi.max() <= 200 and hi.dtype == np.int32
     y64 = y.astype(np.float64)
     assert np.allclose(((y64[hi] - y64[hi - 1]) / h) * dx + y64[hi - 1], griddata(sim_t, y64, times), rtol=0, atol=1e-15)
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must start two ranks itself (fresh children under
+    torch.distributed.run, 127.0.0.1, a free port) BEFORE importing torch or touching a GPU, and exit with their status --
+    round 2's form spent 30 s on CPU baselines and then exited without a line.  On a host without a GPU the ranks
+    themselves stop with "needs a GPU": both must have been started, the parent must relay their failure, and no CPU
+    baseline may have run first (the whole thing takes seconds)."""
+    import os
+    import subprocess
+    import sys
+    import time
+    import torch
+    from conftest import ROOT
+    if torch.cuda.is_available():
+        pytest.skip("the GPU form of this launch is tests/test_gpu_round2.py::test_bench_two_rank_rehearsal_...")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["TRPL_AUTOBUILD"] = "0"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1",
+                        "--warmup", "0", "--T", "50", "--samples-per-gpu", "64"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-3000:]          # both ranks got as far as the device check
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]            # and no line was invented
+    assert time.time() - t0 < 120
