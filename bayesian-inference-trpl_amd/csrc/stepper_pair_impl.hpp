@@ -27,10 +27,6 @@
 #pragma once
 #include "stepper_impl.hpp"
 
-#ifndef TRPL_E_RING
-#define TRPL_E_RING 0      // 1: field history as a register ring without the per-step shift -- measured, spills
-#endif
-
 namespace trpl {
 namespace pair {
 
@@ -148,13 +144,13 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
 
     // ---- state U^t in registers; U^{t-1..t-4} of N and P in a 4-slot LDS ring (slot = t mod 4), E's in registers ----
     // ring layout [slot][row][lane]{N, P}: a lane's N and P of one row and level are one ds_read_b128 / ds_write_b128
-    // (20 DS instructions per time step instead of 40); the field history is a REGISTER ring, slot (t' mod 4) too
+    // (20 DS instructions per time step instead of 40); the field history hE[m] = E^{t-1-m} stays in registers
     constexpr int HSLOT = 2 * NR * 64;
     constexpr int XCH = (XM & 1) ? 0 : 3 * 64;      // PCR exchange buffer, only for the LDS-staged levels
     __shared__ __attribute__((aligned(16))) double lds[4 * HSLOT + XCH];
     double2 *hist2 = reinterpret_cast<double2 *>(lds);            // hist2[(slot * NR + row) * 64 + lane] = {N, P}
     double *xch = lds + 4 * HSLOT;                  // never dereferenced when XCH == 0
-    double Nk[NR], Pk[NR], Ek[NR], hE[4][NR];       // hE[q]: the field at the newest time t' <= t-1 with t' mod 4 == q
+    double Nk[NR], Pk[NR], Ek[NR], hE[4][NR];
 #pragma unroll
     for (int j = 0; j < NR; j++) {                  // pvSimPCR.py:356-362
         // (a resume takes its state from the checkpoint; dN is not read -- it may be NULL there)
@@ -204,15 +200,10 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
                 const int i = NR * ln + j;
                 Nk[j] = a.resN[(r5 + 4) * L + i]; Pk[j] = a.resP[(r5 + 4) * L + i]; Ek[j] = a.resE[(r5 + 4) * (L + 1) + i];
 #pragma unroll
-                for (int m = 0; m < 4; m++) {       // level t0-1-m lives in slot (t0-1-m) mod 4 of both rings
+                for (int m = 0; m < 4; m++) {       // level t0-1-m: ring slot (t0-1-m) mod 4 for N and P, register level m for E
                     const int slot = (int)((a.t0 - 1 - m) & 3);
                     const double e_ = a.resE[(r5 + 3 - m) * (L + 1) + i];
-#if TRPL_E_RING
-#pragma unroll
-                    for (int q = 0; q < 4; q++) hE[q][j] = slot == q ? e_ : hE[q][j];
-#else
                     hE[m][j] = e_;
-#endif
                     hist2[(slot * NR + j) * 64 + lane] = make_double2(a.resN[(r5 + 3 - m) * L + i], a.resP[(r5 + 3 - m) * L + i]);
                 }
             }
@@ -269,25 +260,8 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
                 bP[j] = a1 * Pk[j] + a2 * h1.y + a3 * h2.y + a4 * h3.y + a5 * h4.y;
                 hist2[(s4 + j) * 64 + lane] = make_double2(Nk[j], Pk[j]);
             }
-            // the field's register ring: slot (t mod 4) holds E^{t-4} and takes E^t; the four phases are four copies of
-            // this short block with the slots as compile-time indices -- nothing is ever moved (the shifted history
-            // cost 32 register moves per time step)
-#if TRPL_E_RING
-            auto rhsE = [&](auto ph) {
-                constexpr int p = decltype(ph)::value;
-#pragma unroll
-                for (int j = 0; j < NR; j++) {
-                    bE[j] = a1 * Ek[j] + a2 * hE[(p + 3) & 3][j] + a3 * hE[(p + 2) & 3][j] + a4 * hE[(p + 1) & 3][j] + a5 * hE[p][j];
-                    hE[p][j] = Ek[j];
-                }
-            };
-            switch ((int)(t & 3)) {
-            case 0: rhsE(std::integral_constant<int, 0>{}); break;
-            case 1: rhsE(std::integral_constant<int, 1>{}); break;
-            case 2: rhsE(std::integral_constant<int, 2>{}); break;
-            default: rhsE(std::integral_constant<int, 3>{}); break;
-            }
-#else
+            // the field's history stays in registers and is shifted here, before the iterations (12 v_mov_b64; no copy of
+            // E^t is carried through them).  A register ring without the shift was measured and spills: DESIGN.md section 8
 #pragma unroll
             for (int j = 0; j < NR; j++) {
                 bE[j] = a1 * Ek[j] + a2 * hE[0][j] + a3 * hE[1][j] + a4 * hE[2][j] + a5 * hE[3][j];
@@ -295,7 +269,6 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
                 for (int m = 3; m >= 1; m--) hE[m][j] = hE[m - 1][j];
                 hE[0][j] = Ek[j];
             }
-#endif
         }
 
         // ---------------- iterate, pvSimPCR.py:93-225, both systems ----------------
