@@ -5,4 +5,4 @@ package.  `oracle.lib` is a ctypes binding of oracle/liboracle.so (built from
 trpl_oracle.c by oracle/Makefile, or by __graft_entry__.build()).
 """
 from .binding import (OracleLib, load, pvsim, fastlog, prob, pcreduce, norm2, scales,  # noqa: F401
-                      simulate_loglik)
+                      simulate_loglik, fma_variant)

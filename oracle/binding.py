@@ -61,6 +61,26 @@ def load():
     return _LIB
 
 
+class fma_variant:
+    """Context manager: inside it every oracle call runs the FMA-contracting build of the same source
+    (oracle/Makefile: liboracle_fma.so) -- the reference's arithmetic as numba-CUDA / nvcc would contract it.  Not the
+    pinned oracle; used to measure the distance between two legitimate evaluations of the reference."""
+
+    def __enter__(self):
+        global _LIB
+        so = os.path.join(_HERE, "liboracle_fma.so")
+        src = os.path.join(_HERE, "trpl_oracle.c")
+        if not os.path.isfile(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle_fma.so"])
+        self._saved = load()
+        _LIB = OracleLib(so)
+        return self
+
+    def __exit__(self, *exc):
+        global _LIB
+        _LIB = self._saved
+
+
 def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
