@@ -276,12 +276,13 @@ int trpl_loglik_from_pl_dev(const void *plI, int32_t elem_bytes, int64_t rows, i
  *           CONTRACT: every system whose sse differs from the reference evaluation's by more than 1e-6 (relative) has
  *           floor_col >= 0 -- verified on the reference's prior box over its full 80 000-step window for both shipped
  *           workloads (profiles/r3_validate_full_config1_T80000.txt: 65 536 samples x 3 curves, 2 473 such samples, all
- *           flagged; profiles/r3_validate_twothick_4096_T80000.txt: 4 096 x 6 curves, 150, all flagged) -- and
- *           floor_col itself is the same column in both arithmetics for every system of both runs.  How closely the
+ *           flagged; profiles/r3_validate_twothick_32768_T80000.txt: 32 768 x 6 curves, 1 259, all flagged) -- and
+ *           floor_col itself is the same column in both arithmetics for all 196 608 systems of the first run and all
+ *           but 2 of the second.  How closely the
  *           floor-free systems agree is set by the grid: the state gap that 1 / r amplifies is ~1e-12 on the 2000 nm
  *           films (largest sse gap of 62 059 floor-free samples 1.03e-8, 99.9th percentile 2.5e-9, every compared PL
  *           value within 2e-8) and ~2e-11 on the 311 nm films, whose stencil D dt / dx^2 is 40 times stiffer (largest
- *           gap 2.0e-7, 99.9th percentile 7e-8).  For the others the same holds on the columns before floor_col,
+ *           gap 6.3e-7, 99.9th percentile 6.5e-8).  For the others the same holds on the columns before floor_col,
  *           and from there on PL -- hence sse -- depends on the evaluation order at the level given above: compare
  *           such samples across implementations on the window before floor_col, or not at all (once PL is on the
  *           clamp their sse grows by ~1e5 per point in one evaluation and by (log10 of rounding noise)^2 in another;
