@@ -301,3 +301,36 @@ def test_likelihoods_do_not_depend_on_the_pairing_rule(gpu, tmp_path):
     for k in ("P", "sse", "it", "st", "fc"):
         assert np.array_equal(out["0"][k], out["1"][k]), k
     assert np.isfinite(out["1"]["P"]).all() and not out["1"]["st"].any()
+
+
+def test_wide_box_fuzz_of_the_two_fast_kernels(gpu):
+    """Differential fuzz (tools/fuzz_pair.py in small): a parameter box 2-4 decades wider than the reference's on every
+    axis, Twothick's six curves, a small iteration cap so that hundreds of systems are flagged -- the one-system and the
+    paired kernel (curves of one sample in a wavefront, flagged partners parked beside live ones) flag the same systems
+    at the same step, agree on the iteration totals of all but a handful of the others and on their sums to rounding;
+    nothing non-finite leaks from a flagged system into its partner."""
+    sm, w = gpu.sampler, gpu.workloads
+    S, T = 3000, 120
+    lo = np.array([1e8, 1e12, 0.01, 0.01, 1e-13, 1e-3, 1e-3, 1e-32, 1e-32, 0.1, 0.1, 0.1, 0])
+    hi = np.array([1e8, 1e18, 500, 500, 1e-8, 1e5, 1e5, 1e-26, 1e-26, 1e4, 1e4, 0.1, 0])
+    lg = np.array([1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0])
+    X = sm.random_grid(lo * sm.UNIT_CONVERSIONS, hi * sm.UNIT_CONVERSIONS, lg, S, rng=np.random.RandomState(123))
+    ini, lens = w.twothick(128)
+    obs = [np.full(T + 1, 18.0) - 0.01 * np.arange(T + 1)] * len(lens)
+    res = {}
+    for k in ("single", "pair"):
+        info = {}
+        gpu.loglik(X, ini, lens, T * DT, 128, T, obs, info=info, MAX=400, kernel=k)
+        res[k] = info
+    a, b = res["single"], res["pair"]
+    flagged = a["status"] != 0
+    assert 50 < flagged.sum() < 0.5 * flagged.size
+    assert np.array_equal(a["status"], b["status"])
+    ok = ~flagged
+    dit = np.abs(a["iters_total"][ok] - b["iters_total"][ok])
+    assert (dit != 0).mean() < 2e-3 and dit.max() <= 3
+    assert np.isfinite(a["sse"][ok]).all() and np.isfinite(b["sse"][ok]).all()
+    assert np.isinf(a["sse"][flagged]).all() and np.isinf(b["sse"][flagged]).all()
+    clear = ok & (a["floor_col"] < 0) & (b["floor_col"] < 0)
+    rel = np.abs(a["sse"][clear] - b["sse"][clear]) / np.abs(a["sse"][clear])
+    assert np.median(rel) < 1e-13 and np.quantile(rel, 0.999) < 1e-7
