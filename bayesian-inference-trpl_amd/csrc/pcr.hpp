@@ -178,6 +178,27 @@ __device__ __forceinline__ double rcp_nr1(double d)      // one Newton step: 2e-
     return __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
 }
 __device__ __forceinline__ float rcp_nr1(float d) { return 1.0f / d; }
+// the reciprocal at the accuracy a build-time knob selects (crosslane.hpp)
+// third-order step: r0 (1 + e + e^2), e = 1 - d r0.  One Newton step leaves r0 (1 - e^2) -- never above 1 / d: a BIAS of up
+// to 2e-15, and in the solver's normalised rows a bias is not a rounding error: every eliminated unknown is substituted
+// (1 - e^2) times too small, a spurious sink of e^2 D dt/dx^2 per elimination that adds up over the steps instead of
+// averaging out (measured: it alone moved the 311 nm films' state by 1e-10 .. 1e-8 over 8000 steps).
+// The cubic step costs one fma more and leaves e^3 ~ 1e-22: the result is the rounding of its last fma.
+__device__ __forceinline__ double rcp_cubic(double d)
+{
+    const double r = __builtin_amdgcn_rcp(d);
+    const double e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(r, __builtin_fma(e, e, e), r);
+}
+template <int STEPS>
+__device__ __forceinline__ double rcp_steps(double d)
+{
+    if constexpr (STEPS == 0) return 1.0 / d;
+    else if constexpr (STEPS == 2) return rcp_nr(d);
+    else if constexpr (STEPS == 3) return rcp_cubic(d);
+    else return rcp_nr1(d);
+}
+__device__ __forceinline__ double rcp_row(double d) { return rcp_steps<TRPL_RCP_ROWS_STEPS>(d); }
 
 // Reciprocals of all NR values of a lane.  v_rcp_f64 costs ~3.5 fp64 multiplies, so values are
 // paired: r = 1/(a*b), 1/a = b*r, 1/b = a*r (one reciprocal + 3 multiplies instead of two
@@ -191,7 +212,7 @@ __device__ __forceinline__ void rcp_rows(const double (&d)[NR], double (&r)[NR])
 #pragma unroll
         for (int j = 0; j < NR; j += 4) {
             const double ab = d[j] * d[j + 1], cd = d[j + 2] * d[j + 3];
-            const double rq = rcp_nr1(ab * cd);
+            const double rq = rcp_row(ab * cd);
             const double rab = cd * rq, rcd = ab * rq;
             r[j] = d[j + 1] * rab;
             r[j + 1] = d[j] * rab;
@@ -201,13 +222,13 @@ __device__ __forceinline__ void rcp_rows(const double (&d)[NR], double (&r)[NR])
     } else if constexpr (NR % 2 == 0 && TRPL_RCP_PAIR != 0) {
 #pragma unroll
         for (int j = 0; j < NR; j += 2) {
-            const double rp = rcp_nr1(d[j] * d[j + 1]);
+            const double rp = rcp_row(d[j] * d[j + 1]);
             r[j] = d[j + 1] * rp;
             r[j + 1] = d[j] * rp;
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < NR; j++) r[j] = rcp_nr1(d[j]);
+        for (int j = 0; j < NR; j++) r[j] = rcp_row(d[j]);
     }
 }
 
@@ -324,7 +345,7 @@ __device__ __forceinline__ void pcr_solve_L(double (&ld)[NR], double (&d)[NR], d
 // eliminations of a diagonally dominant system).  The corner coefficients stay exact zeros (a of
 // row 0 and c of row L-1 propagate), so wrapped neighbour values drop out.
 template <typename T> __device__ __forceinline__ T rcp_fast(T d);
-template <> __device__ __forceinline__ double rcp_fast<double>(double d) { return rcp_nr1(d); }
+template <> __device__ __forceinline__ double rcp_fast<double>(double d) { return rcp_steps<TRPL_RCP_SOLVE_STEPS>(d); }
 template <> __device__ __forceinline__ float rcp_fast<float>(float d)
 {
     const float r = __builtin_amdgcn_rcpf(d);      // v_rcp_f32 (1 ulp) + one Newton step

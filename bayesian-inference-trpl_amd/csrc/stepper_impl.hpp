@@ -13,8 +13,9 @@
 //          with the same association, so residual norms, every convergence decision and the N/P/E
 //          state are bit-identical to the sequentially executed reference.  History in registers.
 //   LAY 2  FAST, L >= 128, interleaved layout i = NR*lane + j: select-free lane shifts (crosslane.hpp),
-//          LDS-staged PCR exchange (pcr.hpp), DPP reductions, reciprocals by v_rcp_f64 + one Newton
-//          step, N/P history in a 4-slot LDS ring, 3 waves per SIMD.
+//          LDS-staged PCR exchange (pcr.hpp), DPP reductions, reciprocals by v_rcp_f64 + one refinement step
+//          (third order and unbiased in the solver's quotients, Newton in the pointwise ones: crosslane.hpp), N/P
+//          history in a 4-slot LDS ring, 3 waves per SIMD.
 //   LAY 1  FAST for L < 128 (blocked layout, DPP unit shifts): small grids, not performance critical.
 // The 12 material parameters are wave-uniform (SGPRs).  HBM traffic per system is 13 doubles in and
 // one double out in likelihood mode: the kernel is bound by fp64 VALU issue and the CU's LDS, not by
@@ -184,7 +185,7 @@ struct PlSink {
     const double *obs;
     const int32_t *obs_hi;   // off-grid observation times (trpl_loglik_obs) or nullptr
     const double *obs_dx, *obs_h;
-    // columns and steps are 32-bit (T < 2^31, checked at the ABI): the per-step bookkeeping is scalar code, and
+    // columns and steps are 32-bit (T <= 2^30 - 16 and plT <= T + 1, enforced at the ABI: no sum below can overflow): the per-step bookkeeping is scalar code, and
     // 64-bit scalar adds / compares are two instructions each; only addresses are formed in 64 bits
     int32_t ncol_ll;         // number of observations of this curve (0 outside likelihood mode)
     int32_t t_last;          // last step that can influence an output
@@ -458,8 +459,15 @@ __device__ __forceinline__ void assemble(const MatPar &m, double a0, const doubl
             // cancellations done on paper (21 instead of 29 operations per interior row):
             //   V tp - tauV np  =  tau_other V^2 + tauV n0p0      (the N P tauV terms cancel exactly)
             //   Co N P + Co np  =  Co (2 np + n0p0)
-            //   -u_m - l_p      =  hD (E_i - E_{i+1}) + 2 D        (interior rows)
             // s = -ds.  Same values to rounding; STRICT keeps the reference's expression tree.
+            // The TRANSPORT part of the diagonal is NOT rewritten: it is minus the two off-diagonal entries of its
+            // column AS ROUNDED (A0[i-1] and A2[i+1], pvSimPCR.py:159), like the reference's.  Rounds 2-3 used the closed
+            // form hD (E_i - E_{i+1}) + 2 D on a lane's inner rows (one operation less): algebraically equal, but each
+            // column sum of the transport operator then misses zero by ~eps D instead of exactly 0, a spurious source
+            // of eps D dt/dx^2 per step that does not average out -- measured on the CPU (tools/forensics): it alone
+            // moved the state of the 311 nm films (D dt/dx^2 ~ 500) by 1e-10 .. 6e-10 from the reference evaluation over
+            // 8000 steps, where every other choice of this arithmetic (solver order, fused multiply-adds, the rewrites
+            // above) stays within 1e-13 .. 1e-12.  An inner row finds both entries in its own lane: no extra operation.
             const double hD = IS_N ? 0.5 * D : -0.5 * D;
             const double tauO = IS_N ? m.tauN : m.tauP;
             const double Co2 = IS_N ? m.Co2N : m.Co2P, Con0 = IS_N ? m.Con0N : m.Con0P, tVn0 = IS_N ? m.tVn0N : m.tVn0P;
@@ -482,15 +490,17 @@ __device__ __forceinline__ void assemble(const MatPar &m, double a0, const doubl
             const double s = __builtin_fma(m.rate, V, X) + Y;
             const double t = __builtin_fma(m.CP, Pk[j], __builtin_fma(m.CN, Nk[j], m.rate)) + inv;
             up[j] = u_i; lo[j] = l_i;
-            if (j >= 1 && j <= NR - 2) {            // a row that is never the system's first or last
-                dg[j] = __builtin_fma(hD, Ek[j] - Ep[j], a0 + 2.0 * D) + s;
-            } else {
-                const double u_m = zero_if_first(__builtin_fma(-hDfj, Ek[j], -Dfj));
-                const double l_p = zero_if_last(__builtin_fma(hDlj, Ep[j], -Dlj));
-                dg[j] = a0 - u_m - l_p + s;
-            }
+            // rows 0 and NR-1: the column's other entries belong to the neighbouring lanes' rows -- the same expression
+            // on the same operands, hence the same bits; inner rows take them from this lane below
+            const double u_m = zero_if_first(__builtin_fma(-hDfj, Ek[j], -Dfj));       // A0[i-1]
+            const double l_p = zero_if_last(__builtin_fma(hDlj, Ep[j], -Dlj));         // A2[i+1]
+            dg[j] = (j >= 1 && j <= NR - 2) ? s : a0 - u_m - l_p + s;
             bb[j] = __builtin_fma(-t, np_, __builtin_fma(s, U, -bU[j]));
         }
+    }
+    if constexpr (!STRICT && NR >= 3) {
+#pragma unroll
+        for (int j = 1; j <= NR - 2; j++) dg[j] = a0 - up[j - 1] - lo[j + 1] + dg[j];
     }
     // surfaces (:164-170 / :192-198): node 0 is (lane 0, row 0), node L-1 is (lane W-1, row NR-1)
     if constexpr (STRICT) {
@@ -509,7 +519,7 @@ __device__ __forceinline__ void assemble(const MatPar &m, double a0, const doubl
         const double Ns = hiHalf ? +Nk[NR - 1] : +Nk[0], Ps = hiHalf ? +Pk[NR - 1] : +Pk[0];
         const double sr = hiHalf ? +m.srL : +m.sr0;
         const double Vs = IS_N ? Ps : Ns, Us = IS_N ? Ns : Ps;
-        const double inv = LAY == 2 ? rcp_nr1(Ns + Ps) : rcp_nr(Ns + Ps);
+        const double inv = LAY == 2 ? rcp_row(Ns + Ps) : rcp_nr(Ns + Ps);
         // ds_s = -sr (V^2 + n0p0) / (N+P)^2,  f_s = sr (N P - n0p0) / (N+P) + ds_s U   (:165-170), with g = sr / (N+P)
         const double g = sr * inv;
         const double dss = -(g * inv) * __builtin_fma(Vs, Vs, m.n0p0);

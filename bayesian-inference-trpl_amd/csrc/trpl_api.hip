@@ -31,12 +31,17 @@ int check_grid(int32_t L, int64_t T, int32_t plT, int32_t max_iter, double time_
 {
     if (!pow2(L) || L < 4 || L > 512) return api_fail(TRPL_ERR_ARG, "L=%d must be a power of two in [4, 512]", L);
     if (T < 1) return api_fail(TRPL_ERR_ARG, "T=%lld must be >= 1", (long long)T);
-    if (T > 0x7ffffff0LL) return api_fail(TRPL_ERR_ARG, "T=%lld is too large", (long long)T);
+    // the steppers keep steps and PL columns in 32-bit scalars: with T <= 2^30 - 16 and plT clamped to T + 1 (kernel_plT)
+    // none of t + plT, pl_col * plT or (t0 + plT - 1) / plT can leave the int32 range
+    if (T > 0x3ffffff0LL) return api_fail(TRPL_ERR_ARG, "T=%lld is too large (at most 2^30 - 16 steps)", (long long)T);
     if (plT < 1) return api_fail(TRPL_ERR_ARG, "plT=%d must be >= 1", plT);
     if (max_iter < 1) return api_fail(TRPL_ERR_ARG, "max_iter=%d must be >= 1", max_iter);
     if (!(time_ns > 0)) return api_fail(TRPL_ERR_ARG, "time_ns must be > 0");
     return TRPL_OK;
 }
+
+// plT as the kernels see it: a stride beyond the window stores column 0 only, whatever its size
+static inline int32_t kernel_plT(int32_t plT, int64_t T) { return (int64_t)plT > T + 1 ? (int32_t)(T + 1) : plT; }
 
 int check_brackets(const int32_t *obs_hi, const double *obs_dx, const double *obs_h, int32_t C, int64_t obs_ld,
                    const int64_t *n_obs, int64_t T)
@@ -206,7 +211,7 @@ int launch(const trpl::StepArgs &a_in, uint32_t flags, hipStream_t st, int64_t s
         if (steps > TRPL_FP32_MAX_STEPS && !(flags & TRPL_FLAG_FP32_LONG))
             return api_fail(TRPL_ERR_UNSUPPORTED, "TRPL_FLAG_FP32 over %lld time steps: an fp32 state loses the decay beyond ~%d steps "
                             "(PL errors of percents, then tens of percents: include/trpl.h); use the fp64 / TRPL_FLAG_MIXED "
-                            "path, or add TRPL_FLAG_FP32_LONG for a screening pass", (long long)steps, TRPL_FP32_MAX_STEPS);
+                            "path, or add TRPL_FLAG_FP32_LONG (Python wrappers: fp32=\"long\") for a screening pass", (long long)steps, TRPL_FP32_MAX_STEPS);
         hipError_t e32 = trpl::launch_stepper_f32(a, st);
         if (e32 != hipSuccess) return api_fail(TRPL_ERR_HIP, "fp32 stepper launch: %s", hipGetErrorString(e32));
         return TRPL_OK;
@@ -297,7 +302,7 @@ static int solve_pl_dev_impl(const double *matpar, int64_t S, double length_nm, 
     a.X = matpar; a.xld = 12; a.dN = dN;      // NULL on a resume: the kernels take the state from res* and never read it
     a.pl = plI; a.pl_bytes = pl_elem_bytes; a.pl_ld = pl_ld;
     a.status = status; a.iters_total = iters_total;
-    a.S = S; a.C = 1; a.L = L; a.T = T; a.plT = plT; a.MAX = max_iter; a.flags = flags;
+    a.S = S; a.C = 1; a.L = L; a.T = T; a.plT = kernel_plT(plT, T); a.MAX = max_iter; a.flags = flags;
     a.TOL = pow(10.0, -(double)tol_exp);                        /* pvSimPCR.py:112 */
     curve_const(length_nm, time_ns, L, T, a.curve[0]);
     if (resume) { a.resN = resN; a.resP = resP; a.resE = resE; a.t0 = t0; }
@@ -574,30 +579,46 @@ static int loglik_dev_impl(const double *X, int64_t S, int32_t C, const double *
 {
     if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
     if (S < 0) return api_fail(TRPL_ERR_ARG, "S must be >= 0");
-    if (C < 1 || C > trpl::kMaxCurves) return api_fail(TRPL_ERR_ARG, "C=%d must be in [1, %d]", C, trpl::kMaxCurves);
+    if (C < 1 || C > TRPL_MAX_CURVES) return api_fail(TRPL_ERR_ARG, "C=%d must be in [1, %d]", C, TRPL_MAX_CURVES);
     if (S == 0) return TRPL_OK;
     if (!X || !lengths_nm || !dN || !obs || !n_obs || !P || !sse) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");
     const bool interp = obs_hi || obs_dx || obs_h;
     if (interp && !(obs_hi && obs_dx && obs_h)) return api_fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h go together");
     if (interp && plT != 1) return api_fail(TRPL_ERR_ARG, "off-grid observations need plT = 1");
-    if (S * (int64_t)C > 0x7fffffffLL) return api_fail(TRPL_ERR_ARG, "S*C too large for one launch");
-    trpl::StepArgs a;
-    memset(&a, 0, sizeof a);
-    a.X = X; a.xld = 13; a.dN = dN; a.obs = obs; a.obs_hi = obs_hi; a.obs_dx = obs_dx; a.obs_h = obs_h;
-    a.obs_ld = obs_ld; a.sse = sse;
-    a.status = status; a.iters_total = iters_total; a.floor_col = floor_col;
-    a.S = S; a.C = C; a.L = L; a.T = T; a.plT = plT; a.MAX = max_iter; a.flags = flags;
-    a.TOL = pow(10.0, -(double)tol_exp);
     const int64_t ncol = T / plT + 1;
     for (int c = 0; c < C; c++) {
         if (!(lengths_nm[c] > 0)) return api_fail(TRPL_ERR_ARG, "lengths_nm[%d] must be > 0", c);
         if (n_obs[c] < 1 || n_obs[c] > obs_ld || (!interp && n_obs[c] > ncol))
             return api_fail(TRPL_ERR_ARG, "n_obs[%d]=%lld out of range (obs_ld %lld, grid columns %lld)", c,
                         (long long)n_obs[c], (long long)obs_ld, (long long)ncol);
-        curve_const(lengths_nm[c], time_ns, L, T, a.curve[c]);
-        a.curve[c].n_obs = n_obs[c];
     }
-    if (int rc = launch(a, flags, (hipStream_t)stream, loglik_steps(interp, C, n_obs, plT, T))) return rc;
+    // A launch carries the constants of at most kMaxCurves curves in its argument block; bayeslib.simulate loops over any
+    // number of curves (bayeslib.py:117), so more are run as consecutive launches of up to kMaxCurves on the same stream,
+    // each writing its own rows of the [C][S] outputs, before ONE reduction over all C in curve order (probs.py:44).  The
+    // stepper variant is chosen once from the whole batch, so a system's bits do not depend on the grouping.
+    const int64_t steps = loglik_steps(interp, C, n_obs, plT, T);
+    if (C > trpl::kMaxCurves) flags = pin_variant(flags, S * (int64_t)C, L, steps);
+    for (int c0 = 0; c0 < C; c0 += trpl::kMaxCurves) {
+        const int Cg = C - c0 < trpl::kMaxCurves ? C - c0 : trpl::kMaxCurves;
+        if (S * (int64_t)Cg > 0x7fffffffLL) return api_fail(TRPL_ERR_ARG, "S*C too large for one launch");
+        trpl::StepArgs a;
+        memset(&a, 0, sizeof a);
+        a.X = X; a.xld = 13; a.dN = dN + (int64_t)c0 * L; a.obs = obs + (int64_t)c0 * obs_ld;
+        a.obs_hi = obs_hi ? obs_hi + (int64_t)c0 * obs_ld : nullptr;
+        a.obs_dx = obs_dx ? obs_dx + (int64_t)c0 * obs_ld : nullptr;
+        a.obs_h = obs_h ? obs_h + (int64_t)c0 * obs_ld : nullptr;
+        a.obs_ld = obs_ld; a.sse = sse + (int64_t)c0 * S;
+        a.status = status ? status + (int64_t)c0 * S : nullptr;
+        a.iters_total = iters_total ? iters_total + (int64_t)c0 * S : nullptr;
+        a.floor_col = floor_col ? floor_col + (int64_t)c0 * S : nullptr;
+        a.S = S; a.C = Cg; a.L = L; a.T = T; a.plT = kernel_plT(plT, T); a.MAX = max_iter; a.flags = flags;
+        a.TOL = pow(10.0, -(double)tol_exp);
+        for (int c = 0; c < Cg; c++) {
+            curve_const(lengths_nm[c0 + c], time_ns, L, T, a.curve[c]);
+            a.curve[c].n_obs = n_obs[c0 + c];
+        }
+        if (int rc = launch(a, flags, (hipStream_t)stream, steps)) return rc;
+    }
     hipError_t e = trpl::launch_reduce_curves(P, sse, S, C, (hipStream_t)stream);
     if (e != hipSuccess) return api_fail(TRPL_ERR_HIP, "reduce_curves launch: %s", hipGetErrorString(e));
     return TRPL_OK;
@@ -631,7 +652,7 @@ static int loglik_host_impl(const double *X, int64_t S, int32_t C, const double 
 {
     if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
     if (S < 0) return api_fail(TRPL_ERR_ARG, "S must be >= 0");
-    if (C < 1 || C > trpl::kMaxCurves) return api_fail(TRPL_ERR_ARG, "C=%d must be in [1, %d]", C, trpl::kMaxCurves);
+    if (C < 1 || C > TRPL_MAX_CURVES) return api_fail(TRPL_ERR_ARG, "C=%d must be in [1, %d]", C, TRPL_MAX_CURVES);
     if (seconds) *seconds = 0.0;
     if (S == 0) return TRPL_OK;
     if (!X || !lengths_nm || !dN || !obs || !n_obs || !P) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");

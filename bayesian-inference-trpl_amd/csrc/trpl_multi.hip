@@ -83,7 +83,7 @@ int trpl_loglik_multi(const double *X, int64_t S, int32_t C, const double *lengt
 {
     if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
     if (S < 0) return api_fail(TRPL_ERR_ARG, "S must be >= 0");
-    if (C < 1 || C > trpl::kMaxCurves) return api_fail(TRPL_ERR_ARG, "C=%d must be in [1, %d]", C, trpl::kMaxCurves);
+    if (C < 1 || C > TRPL_MAX_CURVES) return api_fail(TRPL_ERR_ARG, "C=%d must be in [1, %d]", C, TRPL_MAX_CURVES);
     if (seconds) *seconds = 0.0;
     if (!X || !lengths_nm || !dN || !obs || !n_obs || !P) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");
     if (obs_ld < 1) return api_fail(TRPL_ERR_ARG, "obs_ld must be >= 1");
@@ -402,7 +402,7 @@ int trpl_loglik_multi_dev(trpl_multi_t *h, const double *const *X, int64_t S, in
     if (!h) return api_fail(TRPL_ERR_ARG, "handle must not be NULL");
     if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
     if (S < 0) return api_fail(TRPL_ERR_ARG, "S must be >= 0");
-    if (C < 1 || C > trpl::kMaxCurves) return api_fail(TRPL_ERR_ARG, "C=%d must be in [1, %d]", C, trpl::kMaxCurves);
+    if (C < 1 || C > TRPL_MAX_CURVES) return api_fail(TRPL_ERR_ARG, "C=%d must be in [1, %d]", C, TRPL_MAX_CURVES);
     if (!X || !lengths_nm || !dN || !obs || !n_obs || !P_full) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");
     const bool interp = obs_hi || obs_dx || obs_h;
     if (interp && !(obs_hi && obs_dx && obs_h)) return api_fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h go together");

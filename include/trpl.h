@@ -291,9 +291,11 @@ int trpl_loglik_from_pl_dev(const void *plI, int32_t elem_bytes, int64_t rows, i
  *           (profiles/r3_validate_full_config1_T80000.txt).  Summing sum_i N_i P_i first and subtracting L n0p0 once,
  *           as the reference does, instead of the per-node excess changes none of these figures (measured,
  *           profiles/r3_validate_pl_sum_order_16k_T80000.txt): the gap comes from the states, not from the sum.
- * C <= 16 per call.
+ * Any number of curves up to TRPL_MAX_CURVES (bayeslib.py:117 loops over them all): more than 16 run as consecutive launches of
+ * up to 16 curves on the same stream; a system's bits do not depend on that grouping.
  * ------------------------------------------------------------------------------------- */
 #define TRPL_PL_FLOOR_EXCESS 1e-4
+#define TRPL_MAX_CURVES 1024
 int trpl_loglik(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns,
                 int32_t L, int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter,
                 const double *dN, const double *obs, int64_t obs_ld, const int64_t *n_obs,

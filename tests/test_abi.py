@@ -168,9 +168,9 @@ def _copy_package_with_stand_in_makefile(tmp_path):
     real = os.path.join(pkg, "libtrpl_hip.so")
     (dst / "Makefile").write_text(
         "SRCFILES := $(sort $(wildcard csrc/*.hip csrc/*.hpp)) ../include/trpl.h Makefile\n"
-        "all: libtrpl_hip.so libtrpl_hip.so.srchash\n"
-        "libtrpl_hip.so: $(SRCFILES)\n\techo build >> builds.log; sleep 1; cp %s $@.tmp.$$$$ && mv -f $@.tmp.$$$$ $@\n"
-        "libtrpl_hip.so.srchash: libtrpl_hip.so $(SRCFILES)\n\tcat $(SRCFILES) | sha256sum | cut -d' ' -f1 > $@\n" % real)
+        "all: libtrpl_hip.so\n"
+        "libtrpl_hip.so: $(SRCFILES)\n\techo build >> builds.log; sleep 1; cp %s $@.tmp.$$$$ && mv -f $@.tmp.$$$$ $@ "
+        "&& cat $(SRCFILES) | sha256sum | cut -d' ' -f1 > $@.srchash\n" % real)
     code = ("import importlib.util, sys\n"
             "spec = importlib.util.spec_from_file_location('trpl_tmp', %r, submodule_search_locations=[%r])\n"
             "m = importlib.util.module_from_spec(spec); sys.modules['trpl_tmp'] = m; spec.loader.exec_module(m)\n"
@@ -217,13 +217,21 @@ def test_a_library_older_than_its_sources_is_rebuilt_not_used(tmp_path):
     os.utime(dst / "libtrpl_hip.so", (later, later)); os.utime(dst / "libtrpl_hip.so.srchash", (later + 1, later + 1))
     r = run(); assert r.returncode == 0, r.stderr[-1500:]
     assert builds() == 3
+    # a tree copied WITHOUT the (git-ignored) stamp whose binary is newer than every source: `make` sees nothing to do, and
+    # must not get a stamp from anywhere but a link -- the forced pass rebuilds (round-3 advice: the stamp used to be a
+    # target of its own, which an unforced `make all` wrote next to the old binary)
+    os.remove(dst / "libtrpl_hip.so.srchash")
+    later = os.path.getmtime(dst / "libtrpl_hip.so") + 5
+    os.utime(dst / "libtrpl_hip.so", (later, later))
+    r = run(); assert r.returncode == 0, r.stderr[-1500:]
+    assert builds() == 4
     # where it cannot be rebuilt (TRPL_AUTOBUILD=0, or no compiler) a stale binary is at least not used SILENTLY
     with open(dst / "csrc" / "trpl_common.hpp", "a") as fh:
         fh.write("// edited again\n")
     warn = code.replace("assert m._abi.library_is_current()\n", "")
     r = subprocess.run([sys.executable, "-W", "always", "-c", warn], env=dict(env, TRPL_AUTOBUILD="0"), capture_output=True,
                        text=True, timeout=300)
-    assert r.returncode == 0 and builds() == 3 and "built from other sources" in r.stderr, r.stderr[-1500:]
+    assert r.returncode == 0 and builds() == 4 and "built from other sources" in r.stderr, r.stderr[-1500:]
 
 
 def test_bundle_flag_encoding_matches_the_header():

@@ -25,10 +25,11 @@ def main():
     ap.add_argument("--T", type=int, default=8000)
     ap.add_argument("--tau", type=float, nargs=2, default=[0.3, 3.0], help="tauN = tauP range, ns (log-uniform)")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--workload", default="power_scan", choices=["power_scan", "twothick"])
     a = ap.parse_args()
     import trpl_amd
     w = trpl_amd.workloads
-    ini, lens = w.power_scan(128)
+    ini, lens = w.power_scan(128) if a.workload == "power_scan" else w.twothick(128)
     X = w.samples(a.S, seed=7)
     rng = np.random.default_rng(3)
     tau = 10 ** rng.uniform(np.log10(a.tau[0]), np.log10(a.tau[1]), a.S)
@@ -36,7 +37,7 @@ def main():
     X[:, 10] = tau * 10 ** rng.uniform(-0.3, 0.3, a.S)
     Time = a.T * 0.025
     rows = []
-    for c in range(3):
+    for c in range(len(lens)):
         ref, st, it_ref, _ = trpl_amd.solve_pl(X[:, :12], lens[c], Time, 128, a.T, ini[c], strict=True)
         dx, dt = lens[c] / 128, Time / a.T
         # non-dimensional B L n0p0, re-dimensionalised like PL (pvSimPCR.py:327-331,:393)
@@ -47,7 +48,7 @@ def main():
             pl, st2, it, _ = trpl_amd.solve_pl(X[:, :12], lens[c], Time, 128, a.T, ini[c], kernel=kern)
             dev = np.abs(pl / ref - 1)
             dev[~np.isfinite(dev)] = np.inf
-            row = {"curve": c, "kernel": kern, "iters_equal": int((it == it_ref).sum()), "systems": a.S, "by_r": {}, "by_q": {}}
+            row = {"curve": c, "length_nm": float(lens[c]), "kernel": kern, "iters_equal": int((it == it_ref).sum()), "systems": a.S, "by_r": {}, "by_q": {}}
             for name, v in (("by_r", r), ("by_q", q)):
                 for d in range(2, -17, -1):
                     m = (v >= 10.0 ** d) & (v < 10.0 ** (d + 1)) & (ref > 0)

@@ -10,7 +10,7 @@ for L in (128, 512):
     for c in (0, 2):
         ref = oracle.pvsim(X[:, :-1], length, Time, L, T, ini[c], nthreads=6)
         for tol in (3, 4, 5):
-            pl, st, it, _ = gpu.solve_pl(X[:, :-1], length, Time, L, T, ini[c], tol=tol, fp32=True, MAX=2000)
+            pl, st, it, _ = gpu.solve_pl(X[:, :-1], length, Time, L, T, ini[c], tol=tol, fp32="long", MAX=2000)     # "long": also valid should T be raised beyond TRPL_FP32_MAX_STEPS
             ok = st == 0
             err = np.max(np.abs(pl[ok] / ref["plI"][ok] - 1)) if ok.any() else float("nan")
             print(f"L={L} curve={c} tol={tol}: status={st.tolist()} max rel PL err (converged) {err:.2e} iters {it.tolist()} (fp64 tol7: {ref['iters_total'].tolist()})")
