@@ -17,6 +17,7 @@ OK, ERR_ARG, ERR_HIP, ERR_NODEVICE, ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 FLAG_STRICT, FLAG_PL_F32, FLAG_NORMALIZE, FLAG_FP32 = 0x1, 0x2, 0x4, 0x8
 FLAG_KERNEL_PAIR, FLAG_KERNEL_SINGLE, FLAG_MIXED, FLAG_SNAP_RAW = 0x10, 0x20, 0x40, 0x80
 FLAG_FP32_LONG, FP32_MAX_STEPS = 0x1000, 256
+FLAG_HIST32 = 0x2000
 
 
 def fp32_flags(fp32):
@@ -42,7 +43,7 @@ def flag_bundle(m, L=None):
         raise ValueError("max_sims_per_block must be in [1, %d]%s" % (cap, "" if L is None else " at L = %d" % int(L)))
     return ((int(m) - 1) & 0xF) << 8
 
-KERNEL_FAST, KERNEL_FAST_PAIR, KERNEL_STRICT, KERNEL_FP32, KERNEL_MIXED = 0, 1, 2, 3, 4
+KERNEL_FAST, KERNEL_FAST_PAIR, KERNEL_STRICT, KERNEL_FP32, KERNEL_MIXED, KERNEL_HIST32 = 0, 1, 2, 3, 4, 5
 ABI_VERSION = 3
 MAX_SNAPS = 16
 

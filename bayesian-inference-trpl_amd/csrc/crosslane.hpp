@@ -17,6 +17,9 @@
 #ifndef TRPL_FAST_WAVES
 #define TRPL_FAST_WAVES 3      // waves per SIMD the fast stepper is register-budgeted for
 #endif
+#ifndef TRPL_L512_WAVES
+#define TRPL_L512_WAVES 1      // waves per SIMD the L = 512 steppers are register-budgeted for (2: 256 registers, the rest spills to scratch)
+#endif
 #ifndef TRPL_CR_HYBRID
 #define TRPL_CR_HYBRID 1      // L = 128 fast solve: in-lane cyclic-reduction step + PCR on 64 unknowns
 #endif

@@ -580,14 +580,23 @@ __device__ __forceinline__ void update_field(const MatPar &m, double a0, const d
 // BUNDLE: the reference's max_sims_per_block > 1 -- a.bundle consecutive samples of a curve share ONE
 // convergence test per inner iteration (pvSimPCR.py:211-216,:258-266).  One workgroup = one bundle, one wavefront per
 // system, the per-system verdicts exchanged through LDS with one barrier per iteration.
-template <int L, bool STRICT, bool SNAP = false, bool MIXED = false, bool BUNDLE = false>
-__global__ void __launch_bounds__(BUNDLE ? 64 * bundle_cap(L) : 64, BUNDLE ? 1 : ((STRICT || L > 128) ? (L > 256 ? 1 : 2) : TRPL_FAST_WAVES))
+// HIST32 (TRPL_FLAG_HIST32, L >= 256): the BDF history in DIFFERENCE FORM with fp32 storage.  Every row of the BDF table
+// sums to zero (pvSimPCR.py:241-250), so with d_m = U^m - U^{m+1}
+//     bU = a1 U^t + a2 U^{t-1} + .. + a5 U^{t-4} = -a0 U^t + w1 d_{t-1} + w2 d_{t-2} + w3 d_{t-3} + w4 d_{t-4},
+//     w4 = a5, w3 = a4 + w4, w2 = a3 + w3, w1 = a2 + w2.
+// Only U^t (registers) and U^{t-1} (LDS, fp64) are kept in full; d_{t-1} is formed from them exactly, the three older
+// differences are read from a 3-slot fp32 ring (d_m in slot m mod 3, each rounded ONCE, when it is stored).  All three
+// fields live in LDS: 20 B per node and field instead of 32 B (N, P) / 16 registers (E).  State, assembly, solves,
+// residuals and PL stay fp64.  What it buys and what it costs: DESIGN.md section 8 (round 4).
+template <int L, bool STRICT, bool SNAP = false, bool MIXED = false, bool BUNDLE = false, bool HIST32 = false>
+__global__ void __launch_bounds__(BUNDLE ? 64 * bundle_cap(L) : 64, BUNDLE ? 1 : ((STRICT || L > 128) ? (L > 256 ? TRPL_L512_WAVES : 2) : TRPL_FAST_WAVES))
 stepper_kernel(const StepArgs a)
 {
     constexpr int W = L < 64 ? L : 64;
     constexpr int NR = L / W;
     constexpr int LAY = STRICT ? 0 : (L >= 128 ? 2 : 1);   // node layout / arithmetic flavour
     static_assert(!MIXED || LAY == 2, "the mixed-precision correction exists for the interleaved layout (L >= 128)");
+    static_assert(!HIST32 || (LAY == 2 && !BUNDLE && !SNAP && !MIXED), "the fp32-difference history exists for the plain FAST one-system stepper (L >= 128), without snapshots / resume");
     static_assert(!BUNDLE || (!MIXED && (STRICT || L <= 128)), "bundles: STRICT at any L, FAST up to L = 128 (LDS: one history ring per system)");
     const int wv = BUNDLE ? (int)(threadIdx.x >> 6) : 0;                 // which system of the bundle
     const int lane64 = BUNDLE ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
@@ -623,16 +632,21 @@ stepper_kernel(const StepArgs a)
     constexpr bool HREG = LAY != 2;                 // N / P history in registers
     constexpr int HSLOT = 2 * NR * 64;              // N and P; the E history stays in registers
     constexpr int XCH = LAY != 2 ? 2 : (TRPL_CR_HYBRID != 0 ? 3 * 64 : 3 * L);   // PCR exchange buffer, doubles
-    constexpr int LDSW = HREG ? 2 : 4 * HSLOT + XCH;                // per wavefront
+    // HIST32: {N, P}^{t-1} fp64 [row][lane] | E^{t-1} fp64 | d{N, P} fp32 [3][row][lane] | dE fp32 [3][row][lane], in doubles:
+    constexpr int H32 = NR * 64 * 2 + NR * 64 + 3 * NR * 64 + (3 * NR * 64) / 2;
+    constexpr int LDSW = HREG ? 2 : (HIST32 ? H32 + XCH : 4 * HSLOT + XCH);                // per wavefront
     __shared__ __attribute__((aligned(16))) double lds[LDSW * (BUNDLE ? bundle_cap(L) : 1)];
     double *hist = lds + (BUNDLE ? wv * LDSW : 0);
     // ring layout [slot][row][lane]{N, P}: a lane's N and P of one row and level are ONE 16-byte LDS access
     double2 *hist2 = reinterpret_cast<double2 *>(hist);
-    double *xch = hist + (HREG ? 0 : 4 * HSLOT);    // PCR exchange buffer (LAY 2)
+    double *xch = hist + (HREG ? 0 : (HIST32 ? H32 : 4 * HSLOT));    // PCR exchange buffer (LAY 2)
+    double *prevE = hist + NR * 64 * 2;                               // HIST32 only (hist2[row * 64 + lane] = {N, P}^{t-1})
+    float2 *d32 = reinterpret_cast<float2 *>(prevE + NR * 64);       // d32[(slot * NR + row) * 64 + lane] = {dN, dP}
+    float *dE32 = reinterpret_cast<float *>(d32 + 3 * NR * 64);
     const int hl = lane64;                          // this lane's column of the ring
     double Nk[NR], Pk[NR], Ek[NR];
     double hN[4][NR], hP[4][NR];                    // HREG only: levels t-1 .. t-4
-    double hE[4][NR];                               // field history, registers in both modes
+    double hE[4][NR];                               // field history, registers (not HIST32)
 #pragma unroll
     for (int j = 0; j < NR; j++) {                 // pvSimPCR.py:356-362
         // (a resume takes its state from the checkpoint; dN is not read -- it may be NULL there)
@@ -643,11 +657,18 @@ stepper_kernel(const StepArgs a)
         Nk[j] = N0 + dn;
         Pk[j] = P0 + dn;
         Ek[j] = 0.0;
+        if constexpr (HIST32) {                    // U^{-1} := U^0 (its weight is zero at t = 0), no older differences
+            hist2[j * 64 + hl] = make_double2(Nk[j], Pk[j]);
+            prevE[j * 64 + hl] = 0.0;
 #pragma unroll
-        for (int m = 0; m < 4; m++) {
-            hE[m][j] = 0.0;
-            if constexpr (HREG) { hN[m][j] = 0.0; hP[m][j] = 0.0; }
-            else hist2[(m * NR + j) * 64 + hl] = make_double2(0.0, 0.0);
+            for (int m = 0; m < 3; m++) { d32[(m * NR + j) * 64 + hl] = make_float2(0.0f, 0.0f); dE32[(m * NR + j) * 64 + hl] = 0.0f; }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                hE[m][j] = 0.0;
+                if constexpr (HREG) { hN[m][j] = 0.0; hP[m][j] = 0.0; }
+                else hist2[(m * NR + j) * 64 + hl] = make_double2(0.0, 0.0);
+            }
         }
     }
 
@@ -703,6 +724,7 @@ stepper_kernel(const StepArgs a)
             if (st0) { status = st0; t_begin = sink.t_last + 1; }
         }
     }
+    int h32_slot = 2;                              // HIST32: (t - 1) mod 3 at t = 0
     for (int32_t t = t_begin; t <= sink.t_last; t++) {   // tEvol, pvSimPCR.py:237
         if constexpr (SNAP) {                      // the state at time t, before it is stepped (:283-288)
             if (snap.due(t))
@@ -757,6 +779,28 @@ stepper_kernel(const StepArgs a)
                 for (int m = 3; m >= 1; m--) { hN[m][j] = hN[m - 1][j]; hP[m][j] = hP[m - 1][j]; hE[m][j] = hE[m - 1][j]; }
                 hN[0][j] = Nk[j]; hP[0][j] = Pk[j]; hE[0][j] = Ek[j];
             }
+        } else if constexpr (HIST32) {
+            const double w4 = a5, w3 = a4 + w4, w2 = a3 + w3, w1 = a2 + w2;
+            // d_m sits in slot m mod 3: d_{t-2}, d_{t-3}, d_{t-4}; the new d_{t-1} takes d_{t-4}'s slot
+            const int q2 = h32_slot == 0 ? 2 : h32_slot - 1;                  // (t-2) mod 3, with h32_slot = (t-1) mod 3 (= (t-4) mod 3)
+            const int q3 = q2 == 0 ? 2 : q2 - 1;
+            const int o1 = h32_slot * NR, o2 = q2 * NR, o3 = q3 * NR;
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                const double2 u1 = hist2[j * 64 + hl];
+                const double e1 = prevE[j * 64 + hl];
+                const float2 f2 = d32[(o2 + j) * 64 + hl], f3 = d32[(o3 + j) * 64 + hl], f4 = d32[(o1 + j) * 64 + hl];
+                const float g2 = dE32[(o2 + j) * 64 + hl], g3 = dE32[(o3 + j) * 64 + hl], g4 = dE32[(o1 + j) * 64 + hl];
+                const double dn = u1.x - Nk[j], dp = u1.y - Pk[j], de = e1 - Ek[j];       // d_{t-1}, exact to fp64 rounding
+                bN[j] = -a0 * Nk[j] + w1 * dn + w2 * (double)f2.x + w3 * (double)f3.x + w4 * (double)f4.x;
+                bP[j] = -a0 * Pk[j] + w1 * dp + w2 * (double)f2.y + w3 * (double)f3.y + w4 * (double)f4.y;
+                bE[j] = -a0 * Ek[j] + w1 * de + w2 * (double)g2 + w3 * (double)g3 + w4 * (double)g4;
+                d32[(o1 + j) * 64 + hl] = make_float2((float)dn, (float)dp);
+                dE32[(o1 + j) * 64 + hl] = (float)de;
+                hist2[j * 64 + hl] = make_double2(Nk[j], Pk[j]);
+                prevE[j * 64 + hl] = Ek[j];
+            }
+            h32_slot = h32_slot == 2 ? 0 : h32_slot + 1;
         } else {
             const int s1 = (int)((t + 3) & 3) * NR, s2 = (int)((t + 2) & 3) * NR,
                       s3 = (int)((t + 1) & 3) * NR, s4 = (int)(t & 3) * NR;        // slots of t-1 .. t-4

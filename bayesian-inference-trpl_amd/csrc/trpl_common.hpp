@@ -75,6 +75,7 @@ hipError_t launch_stepper_strict(const StepArgs &a, hipStream_t stream);
 hipError_t launch_stepper_fast(const StepArgs &a, hipStream_t stream);
 hipError_t launch_stepper_f32(const StepArgs &a, hipStream_t stream);   // stepper_f32.hip, L >= 128
 hipError_t launch_stepper_mixed(const StepArgs &a, hipStream_t stream);  // stepper_mixed.hip, L >= 128
+hipError_t launch_stepper_hist32(const StepArgs &a, hipStream_t stream); // stepper_hist32.hip, L = 256 / 512
 // stepper_pair.hip: FAST, L = 128, two systems per wavefront
 hipError_t launch_stepper_pair(const StepArgs &a, hipStream_t stream);
 

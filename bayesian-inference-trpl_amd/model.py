@@ -12,7 +12,7 @@ def _as_f64(a):
 
 def solve_pl(matPar, Length, Time, L, T, dN, plT=1, tol=7, MAX=10000, out=None, dtype=np.float64,
              strict=False, device=0, fp32=False, kernel=None, mixed=False, snap_steps=None, plN=None, plP=None, plE=None,
-             snapshots=None, resume=None, snap_raw=False, bundle=1):
+             snapshots=None, resume=None, snap_raw=False, bundle=1, hist32=False):
     """PL(t) for S systems of one curve.  matPar (S,12) and dN (L,) in nm/ns units.
     Returns (plI, status, iters_total, seconds).
 
@@ -53,7 +53,8 @@ def solve_pl(matPar, Length, Time, L, T, dN, plT=1, tol=7, MAX=10000, out=None, 
     iters = np.zeros(S, dtype=np.int64)
     sec = _abi.C.c_double(0.0)
     flags = (_abi.FLAG_STRICT if strict else 0) | _abi.fp32_flags(fp32) | _abi.kernel_flag(kernel) \
-        | (_abi.FLAG_MIXED if mixed else 0) | (_abi.FLAG_SNAP_RAW if snap_raw else 0) | _abi.flag_bundle(bundle, L)
+        | (_abi.FLAG_MIXED if mixed else 0) | (_abi.FLAG_SNAP_RAW if snap_raw else 0) | _abi.flag_bundle(bundle, L) \
+        | (_abi.FLAG_HIST32 if hist32 else 0)
     steps = None
     n_snap = 0
     if snap_steps is not None and len(snap_steps):

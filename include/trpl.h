@@ -72,8 +72,16 @@ extern "C" {
                                      the reference's norm2), so the accuracy is that of the fp64 solver at the same tol;
                                      an fp32 solve resolves ~1e-5 of a correction, so tol_exp 5-6 converges in the fp64
                                      iteration count (measured: tol_exp 7 too).  Measured on MI355X it is NOT faster than
-                                     the fp64 stepper (a plain fp32 VALU instruction issues at the fp64 rate on CDNA4);
-                                     it exists as the measured point of DESIGN.md section 7.  No reference exists for it */
+                                     the fp64 stepper (a plain fp32 VALU instruction only issues faster than an fp64 one
+                                     with two or more wavefronts per SIMD, tools/ubench_f32_f64.hip; the L = 512 stepper
+                                     holds one); it exists as the measured point of DESIGN.md section 7.  No reference exists for it */
+#define TRPL_FLAG_HIST32 0x2000    /* fp64 state, assembly, solves, residuals, PL and likelihood; the BDF history kept in
+                                     difference form with the older differences stored in fp32 (every row of the BDF table,
+                                     pvSimPCR.py:241-250, sums to zero: only the newest level is needed in full).  One-system
+                                     stepper at L = 256 / 512; no snapshots, resume or bundles; not combinable with STRICT /
+                                     FP32 / MIXED.  An experiment of round 4: same occupancy and speed
+                                     as the fp64 history, PL within ~1e-8 of it -- not selected by default.  No reference
+                                     exists for it */
 #define TRPL_FLAG_SNAP_RAW 0x80   /* trpl_solve_pl_snap / _resume: snapshots in SOLVER units (no division by dx^3 / dx), the
                                      form trpl_solve_pl_resume reads back bit for bit */
 #define TRPL_FLAG_BUNDLE(m) ((uint32_t)(((m) - 1) & 0xF) << 8)
@@ -106,6 +114,7 @@ extern "C" {
 #define TRPL_KERNEL_STRICT 2
 #define TRPL_KERNEL_FP32 3
 #define TRPL_KERNEL_MIXED 4
+#define TRPL_KERNEL_HIST32 5
 int trpl_kernel_variant(int64_t nsys, int32_t L, int64_t steps, uint32_t flags);
 
 /* Who shares a wavefront in the two-systems-per-wavefront stepper of a fused on-grid likelihood launch (a scheduling

