@@ -20,6 +20,12 @@
 #ifndef TRPL_L512_WAVES
 #define TRPL_L512_WAVES 1      // waves per SIMD the L = 512 steppers are register-budgeted for (2: 256 registers, the rest spills to scratch)
 #endif
+#ifndef TRPL_H32_E_REGS
+#define TRPL_H32_E_REGS 0      // HIST32: the field's history in registers (1) or in LDS with N's and P's (0)
+#endif
+#ifndef TRPL_H32_FEEDBACK
+#define TRPL_H32_FEEDBACK 0    // HIST32: carry each stored difference's fp32 rounding residual into the next one (N and P)
+#endif
 #ifndef TRPL_CR_HYBRID
 #define TRPL_CR_HYBRID 1      // L = 128 fast solve: in-lane cyclic-reduction step + PCR on 64 unknowns
 #endif

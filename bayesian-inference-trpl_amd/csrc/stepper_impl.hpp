@@ -335,7 +335,7 @@ struct PlSink {
         if (want_ll) a.sse[orow] = status ? __builtin_inf() : sse;
         if (a.status) a.status[orow] = status;
         if (a.iters_total) a.iters_total[orow] = itot;
-        if (a.floor_col) a.floor_col[orow] = first_floor;
+        if (a.floor_col) a.floor_col[orow] = status ? -2 : first_floor;      // a flagged system: sse = +inf, no column to report
     }
 };
 
@@ -633,7 +633,11 @@ stepper_kernel(const StepArgs a)
     constexpr int HSLOT = 2 * NR * 64;              // N and P; the E history stays in registers
     constexpr int XCH = LAY != 2 ? 2 : (TRPL_CR_HYBRID != 0 ? 3 * 64 : 3 * L);   // PCR exchange buffer, doubles
     // HIST32: {N, P}^{t-1} fp64 [row][lane] | E^{t-1} fp64 | d{N, P} fp32 [3][row][lane] | dE fp32 [3][row][lane], in doubles:
-    constexpr int H32 = NR * 64 * 2 + NR * 64 + 3 * NR * 64 + (3 * NR * 64) / 2;
+    // (TRPL_H32_E_REGS: the field's E^{t-1} and three differences in registers instead -- 16 + 12 VGPR pairs for 10 KB of LDS)
+    // (TRPL_H32_FEEDBACK: + one fp32 rounding residual per node of N and P, carried into the next difference stored -- the
+    // stored differences then telescope to the true change of the state to one rounding, whatever the number of steps)
+    constexpr int H32F = TRPL_H32_FEEDBACK ? NR * 64 : 0;
+    constexpr int H32 = H32F + (TRPL_H32_E_REGS ? NR * 64 * 2 + 3 * NR * 64 : NR * 64 * 2 + NR * 64 + 3 * NR * 64 + (3 * NR * 64) / 2);
     constexpr int LDSW = HREG ? 2 : (HIST32 ? H32 + XCH : 4 * HSLOT + XCH);                // per wavefront
     __shared__ __attribute__((aligned(16))) double lds[LDSW * (BUNDLE ? bundle_cap(L) : 1)];
     double *hist = lds + (BUNDLE ? wv * LDSW : 0);
@@ -641,8 +645,11 @@ stepper_kernel(const StepArgs a)
     double2 *hist2 = reinterpret_cast<double2 *>(hist);
     double *xch = hist + (HREG ? 0 : (HIST32 ? H32 : 4 * HSLOT));    // PCR exchange buffer (LAY 2)
     double *prevE = hist + NR * 64 * 2;                               // HIST32 only (hist2[row * 64 + lane] = {N, P}^{t-1})
-    float2 *d32 = reinterpret_cast<float2 *>(prevE + NR * 64);       // d32[(slot * NR + row) * 64 + lane] = {dN, dP}
+    float2 *d32 = reinterpret_cast<float2 *>(prevE + (TRPL_H32_E_REGS ? 0 : NR * 64));       // d32[(slot * NR + row) * 64 + lane] = {dN, dP}
     float *dE32 = reinterpret_cast<float *>(d32 + 3 * NR * 64);
+    float2 *c32 = reinterpret_cast<float2 *>(hist + H32 - H32F);     // TRPL_H32_FEEDBACK: c32[row * 64 + lane] = rounding residuals {N, P}
+    double pEr[NR];                                 // HIST32 + TRPL_H32_E_REGS: E^{t-1} and d_{t-2}, d_{t-3}, d_{t-4} of the field
+    float dEr[3][NR];
     const int hl = lane64;                          // this lane's column of the ring
     double Nk[NR], Pk[NR], Ek[NR];
     double hN[4][NR], hP[4][NR];                    // HREG only: levels t-1 .. t-4
@@ -659,9 +666,13 @@ stepper_kernel(const StepArgs a)
         Ek[j] = 0.0;
         if constexpr (HIST32) {                    // U^{-1} := U^0 (its weight is zero at t = 0), no older differences
             hist2[j * 64 + hl] = make_double2(Nk[j], Pk[j]);
-            prevE[j * 64 + hl] = 0.0;
+            if constexpr (TRPL_H32_E_REGS) pEr[j] = 0.0; else prevE[j * 64 + hl] = 0.0;
+            if constexpr (TRPL_H32_FEEDBACK != 0) c32[j * 64 + hl] = make_float2(0.0f, 0.0f);
 #pragma unroll
-            for (int m = 0; m < 3; m++) { d32[(m * NR + j) * 64 + hl] = make_float2(0.0f, 0.0f); dE32[(m * NR + j) * 64 + hl] = 0.0f; }
+            for (int m = 0; m < 3; m++) {
+                d32[(m * NR + j) * 64 + hl] = make_float2(0.0f, 0.0f);
+                if constexpr (TRPL_H32_E_REGS) dEr[m][j] = 0.0f; else dE32[(m * NR + j) * 64 + hl] = 0.0f;
+            }
         } else {
 #pragma unroll
             for (int m = 0; m < 4; m++) {
@@ -788,17 +799,26 @@ stepper_kernel(const StepArgs a)
 #pragma unroll
             for (int j = 0; j < NR; j++) {
                 const double2 u1 = hist2[j * 64 + hl];
-                const double e1 = prevE[j * 64 + hl];
+                const double e1 = TRPL_H32_E_REGS ? pEr[j] : prevE[j * 64 + hl];
                 const float2 f2 = d32[(o2 + j) * 64 + hl], f3 = d32[(o3 + j) * 64 + hl], f4 = d32[(o1 + j) * 64 + hl];
-                const float g2 = dE32[(o2 + j) * 64 + hl], g3 = dE32[(o3 + j) * 64 + hl], g4 = dE32[(o1 + j) * 64 + hl];
+                const float g2 = TRPL_H32_E_REGS ? dEr[0][j] : dE32[(o2 + j) * 64 + hl], g3 = TRPL_H32_E_REGS ? dEr[1][j] : dE32[(o3 + j) * 64 + hl],
+                            g4 = TRPL_H32_E_REGS ? dEr[2][j] : dE32[(o1 + j) * 64 + hl];
                 const double dn = u1.x - Nk[j], dp = u1.y - Pk[j], de = e1 - Ek[j];       // d_{t-1}, exact to fp64 rounding
                 bN[j] = -a0 * Nk[j] + w1 * dn + w2 * (double)f2.x + w3 * (double)f3.x + w4 * (double)f4.x;
                 bP[j] = -a0 * Pk[j] + w1 * dp + w2 * (double)f2.y + w3 * (double)f3.y + w4 * (double)f4.y;
                 bE[j] = -a0 * Ek[j] + w1 * de + w2 * (double)g2 + w3 * (double)g3 + w4 * (double)g4;
-                d32[(o1 + j) * 64 + hl] = make_float2((float)dn, (float)dp);
-                dE32[(o1 + j) * 64 + hl] = (float)de;
+                if constexpr (TRPL_H32_FEEDBACK != 0) {
+                    const float2 cr = c32[j * 64 + hl];
+                    const double vn = dn + (double)cr.x, vp = dp + (double)cr.y;
+                    const float fn = (float)vn, fp = (float)vp;
+                    d32[(o1 + j) * 64 + hl] = make_float2(fn, fp);
+                    c32[j * 64 + hl] = make_float2((float)(vn - (double)fn), (float)(vp - (double)fp));
+                } else {
+                    d32[(o1 + j) * 64 + hl] = make_float2((float)dn, (float)dp);
+                }
                 hist2[j * 64 + hl] = make_double2(Nk[j], Pk[j]);
-                prevE[j * 64 + hl] = Ek[j];
+                if constexpr (TRPL_H32_E_REGS) { dEr[2][j] = dEr[1][j]; dEr[1][j] = dEr[0][j]; dEr[0][j] = (float)de; pEr[j] = Ek[j]; }
+                else { dE32[(o1 + j) * 64 + hl] = (float)de; prevE[j * 64 + hl] = Ek[j]; }
             }
             h32_slot = h32_slot == 2 ? 0 : h32_slot + 1;
         } else {

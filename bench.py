@@ -25,7 +25,7 @@ imported torch or touched the GPU; rank 0's JSON line is relayed and the exit st
 line carries `rccl`: the world RCCL saw, every rank's device, the bytes and the time of the one all-gather.
 
 At N = 1 the line also carries `other_configs` -- ONE event-timed pass each of BASELINE configs[2] (Twothick x 65 536
-samples x 6 curves) and of one GPU's share of configs[4] (L = 512 x 32 768 samples, fp64 at tol 1e-6) -- `host_api_block` -- the reference's own call sequence (pvSim -> fastlog -> prob per
+samples x 6 curves) and of one GPU's share of configs[4] (L = 512 x 32 768 of 262 144 samples, fp64 at tol 1e-7 and 1e-6) -- `host_api_block` -- the reference's own call sequence (pvSim -> fastlog -> prob per
 curve, host buffers) on one reference-shaped 1024-sample block, PCIe included -- and `full_length`: ONE extra pass at the production length T = 80 000 over the
 same resident batch (event-timed, ~26 s), so that the full-length rate is measured by every driver run.
 
@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--fp32", action="store_true", help="fp32 solver state (configs[4]); implies --tol 3 at L=512, 4 otherwise")
     ap.add_argument("--mixed", action="store_true",
                     help="fp64 state + fp32 correction solves (TRPL_FLAG_MIXED; the accurate path for configs[4])")
+    ap.add_argument("--hist32", action="store_true",
+                    help="fp64 arithmetic, BDF history as fp32 differences (TRPL_FLAG_HIST32, L = 256 / 512; round-4 experiment)")
     ap.add_argument("--tol", type=int, default=None, help="convergence exponent (default 7, the reference's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcr", action="store_true")
@@ -109,7 +111,7 @@ def main():
                     help="nccl = RCCL over xGMI (one GPU per rank); gloo = rehearsal of the N>1 control flow "
                          "with host-staged collectives (ranks may share a GPU)")
     ap.add_argument("--no-other-configs", action="store_true",
-                    help="skip the one pass each of configs[2] (Twothick) and configs[4]'s share (L = 512) (N = 1 only, ~15 s)")
+                    help="skip the one pass each of configs[2] (Twothick) and configs[4]'s share (L = 512) (N = 1 only, ~22 s)")
     args = ap.parse_args()
 
     if args.single_process:
@@ -161,7 +163,8 @@ def main():
     S = hi - lo
     X_host = wl.samples(S_total)[lo:hi]                      # same seeded draw on every rank, own shard
     flags = (trpl_amd.FLAG_STRICT if args.strict else 0) | (trpl_amd.FLAG_MIXED if args.mixed else 0) \
-        | ((trpl_amd.FLAG_FP32 | trpl_amd.FLAG_FP32_LONG) if args.fp32 else 0)     # a screening-mode number, flagged as such below
+        | ((trpl_amd.FLAG_FP32 | trpl_amd.FLAG_FP32_LONG) if args.fp32 else 0) \
+        | (trpl_amd._abi.FLAG_HIST32 if args.hist32 else 0)     # (--fp32: a screening-mode number, flagged as such below)
     # the stepper variant is a property of the LOGICAL batch (all ranks' samples), not of this rank's shard:
     # a sample's bits then do not depend on how many GPUs the batch is cut over (include/trpl.h)
     flags = trpl_amd._abi.pin_variant(flags, S_total * C, L, T)
@@ -255,8 +258,11 @@ def main():
         kernel_name = "%sstepper_kernel<%d%s> (fused time-stepper + likelihood)" % ("f32::" if args.fp32 else "", L,
                                                                                    ", mixed" if args.mixed else "")
         rocprof_name = ("void trpl::f32::stepper_kernel<%d>" % L) if args.fp32 else \
-            "void trpl::stepper_kernel<%d, %s, false, %s>" % (L, "true" if args.strict else "false",
-                                                              "true" if args.mixed else "false")
+            "void trpl::stepper_kernel<%d, %s, false, %s, false, %s>" % (L, "true" if args.strict else "false",
+                                                                         "true" if args.mixed else "false",
+                                                                         "true" if args.hist32 else "false")
+        if args.hist32:
+            kernel_name = kernel_name.replace(">", ", fp32-difference history>", 1)
     out = {
         "metric": "TRPL timesteps/sec at %d nodes (system = parameter sample x excitation; fused solve + "
                   "log-likelihood; parameter-sample likelihoods/sec in likelihoods_per_s_*)" % L,
@@ -274,7 +280,7 @@ def main():
         "config": {"workload": "%s x %d samples/GPU (%d total), %d curves, L=%d nodes, T=%d steps of dt=0.025 ns, "
                                "tol=1e-%d, MAX=10000, %s, arithmetic=%s"
                                % (args.workload, args.samples_per_gpu, S_total, C, L, T, tol,
-                                  "fp32 state" if args.fp32 else ("fp64 state + fp32 solves" if args.mixed else "fp64"),
+                                  "fp32 state" if args.fp32 else ("fp64 state + fp32 solves" if args.mixed else ("fp64, fp32-difference history" if args.hist32 else "fp64")),
                                   "strict" if args.strict else "fast"),
                    "arithmetic": "strict" if args.strict else "fast", "precision": "fp32 state" if args.fp32 else
                    ("fp64 state + fp32 solves" if args.mixed else "fp64"), "tol_exp": tol,
@@ -492,11 +498,16 @@ def one_pass(torch, tdev, trpl_amd, wl, dev, workload, S, L, T, dt_ns, tol, flag
 def other_configs(torch, tdev, trpl_amd, wl, dev, S, T, dt_ns):
     """The other single-GPU configurations BASELINE.json names, one event-timed pass each at the headline's window:
     configs[2] Twothick (311 / 2000 nm films x 3 powers = 6 curves) x S samples, and ONE GPU's share of configs[4]
-    (L = 512 x 262 144 samples over 8 GPUs = 32 768 per GPU) in fp64 at tol 1e-6 -- the setting DESIGN.md section 7
-    recommends for that grid (an fp32 STATE, as the config is worded, loses the decay over thousands of steps)."""
+    (L = 512 x 262 144 samples over 8 GPUs = 32 768 per GPU, `share_of` names the whole) in fp64 at the reference's
+    tolerance 1e-7 and at tol 1e-6 -- the setting DESIGN.md section 7 recommends for that grid (an fp32 STATE, as the
+    config is worded, loses the decay over thousands of steps)."""
     out = [dict(config="configs[2]", **one_pass(torch, tdev, trpl_amd, wl, dev, "twothick", S, 128, T, dt_ns, 7))]
     torch.cuda.empty_cache()
-    out.append(dict(config="configs[4], one GPU's share of 8", **one_pass(torch, tdev, trpl_amd, wl, dev, "power_scan", 32768, 512, T, dt_ns, 6)))
+    # configs[4]: 262 144 samples over 8 GPUs; at the reference's tolerance (1e-7) and at the recommended 1e-6
+    for tol in (7, 6):
+        torch.cuda.empty_cache()
+        out.append(dict(config="configs[4], one GPU's share of 8", share_of=262144, n_gpus_of_config=8,
+                        **one_pass(torch, tdev, trpl_amd, wl, dev, "power_scan", 32768, 512, T, dt_ns, tol)))
     return out
 
 

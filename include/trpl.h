@@ -281,7 +281,8 @@ int trpl_loglik_from_pl_dev(const void *plI, int32_t elem_bytes, int64_t rows, i
  *           bayeslib.py:157 -- while the default arithmetic, which forms the per-node excess fma(N_i, P_i, -n0p0)
  *           before summing, keeps following the state and lands on the clamp when that turns non-positive).
  *           floor_col[c][s] is the first compared PL column (observation index; the grid step with off-grid
- *           observations) with r < TRPL_PL_FLOOR_EXCESS = 1e-4 (or a non-positive / NaN PL), or -1 if there is none.
+ *           observations) with r < TRPL_PL_FLOOR_EXCESS = 1e-4 (or a non-positive / NaN PL), or -1 if there is none;
+ *           -2 for a system flagged as non-converged (status != 0: its sse is +inf and it has no PL to compare).
  *           CONTRACT: every system whose sse differs from the reference evaluation's by more than 1e-6 (relative) has
  *           floor_col >= 0 -- verified on the reference's prior box over its full 80 000-step window for both shipped
  *           workloads (profiles/r3_validate_full_config1_T80000.txt: 65 536 samples x 3 curves, 2 473 such samples, all

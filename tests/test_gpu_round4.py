@@ -149,9 +149,12 @@ def test_l512_bench_window_against_the_oracle(gpu, oracle, l512_window, arith):
             tol 6 -- the tol-6 oracle's iteration totals, PL within 2e-5 and likelihood within 1e-5 of the tol-7 solution
     mixed:  PL within 1e-7 at tol 7, iteration totals within 4 per system of the oracle's ~18 000 (fp32 correction
             solves)
-    hist32: the BDF history kept as fp32 differences from the newest level (TRPL_FLAG_HIST32): iteration totals within
-            +-1 per system of the oracle's, PL within 2e-7 above the floor at tol 7 (measured 5e-8: the first steps after
-            the excitation, when a level differs from the next by O(1), round at 6e-8 of the state)."""
+    hist32: the BDF history in difference form, the three older differences stored in fp32, each rounded once
+            (TRPL_FLAG_HIST32; the round-3 review's gate): iteration totals within +-1 per system of the oracle's
+            (measured: identical on all 48), PL within 1e-8 above the floor at tol 7 (measured 1.4e-9), likelihood within
+            2e-8 (measured 7e-9).  A first form that re-referenced every difference to the newest level each step (four
+            roundings per level, the newest difference rounded too) measured 5e-8: the first steps after the excitation,
+            when a level differs from the next by O(1), round at 6e-8 of the state."""
     g = l512_window
     kw = dict(kernel="single") if arith == "fp64" else ({"mixed": True} if arith == "mixed" else {"kernel": "single", "hist32": True})
     if arith == "hist32" and not hasattr(gpu._abi, "FLAG_HIST32"):
@@ -188,13 +191,13 @@ def test_l512_bench_window_against_the_oracle(gpu, oracle, l512_window, arith):
                         bound = 1e-9 + 2e-12 / r
                     assert np.max((dev / bound)[r >= 1e-10]) <= 1.0, (c, float(np.max((dev / bound)[r >= 1e-10])))
                 else:
-                    assert dev[above].max() < (1e-7 if arith == "mixed" else 2e-7), (arith, c, float(dev[above].max()))
+                    assert dev[above].max() < (1e-7 if arith == "mixed" else 1e-8), (arith, c, float(dev[above].max()))
             else:
                 assert dev[above].max() < 2e-5, (arith, c, float(dev[above].max()))
             rec["tol%d_curve%d" % (tol, c)] = dict(max_dev_above_floor=float(dev[above].max()), iteration_totals_differ=int((d_it > 0).sum()))
         P = _loglik_from(oracle, pls, obs, mag)
         clear = np.all([first_below(g["ref7"][c]["plI"], FLOOR * scale) < 0 for c in range(3)], axis=0)
-        gate = {("fp64", 7): 1e-8, ("mixed", 7): 1e-7, ("hist32", 7): 2e-7}.get((arith, tol), 1e-5)
+        gate = {("fp64", 7): 1e-8, ("mixed", 7): 1e-7, ("hist32", 7): 2e-8}.get((arith, tol), 1e-5)
         rel = np.abs(P - want_P) / np.abs(want_P)
         assert rel[clear].max() < gate, (arith, tol, float(rel[clear].max()))
         rec["tol%d_loglik_gap" % tol] = float(rel[clear].max())
@@ -249,3 +252,20 @@ def test_more_than_sixteen_curves_per_fused_call(gpu, kernel):
     assert np.isfinite(Po).all()
     with pytest.raises(gpu.TrplError):
         gpu.loglik(X[:2], np.repeat(ini[:1], 1025, axis=0), np.full(1025, 2000.0), Time, L, T, [obs[0]] * 1025)
+
+
+@pytest.mark.parametrize("mode", [dict(strict=True), dict(kernel="single"), dict(kernel="pair")], ids=["strict", "single", "pair"])
+def test_floor_col_of_a_flagged_system_is_the_sentinel(gpu, mode):
+    """A system whose iteration hits MAX (pvSimPCR.py:269) has sse = +inf and no PL to compare: floor_col = -2 there
+    (include/trpl.h), whatever was recorded before the failing step; the others keep their column or -1."""
+    w = gpu.workloads
+    L, T, S = 128, 60, 24
+    ini, lens = w.power_scan(L)
+    X = w.samples(S, seed=3)
+    obs = [np.full(T + 1, 19.0)] * 3
+    info = {}
+    gpu.loglik(X, ini, lens, T * DT, L, T, obs, MAX=4, info=info, **mode)
+    flagged = info["status"] != 0
+    assert flagged.any() and not flagged.all()
+    assert (info["floor_col"][flagged] == -2).all() and np.isinf(info["sse"][flagged]).all()
+    assert (info["floor_col"][~flagged] >= -1).all() and np.isfinite(info["sse"][~flagged]).all()

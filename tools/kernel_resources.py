@@ -12,7 +12,7 @@ CONTRACT = {"strict": "off"}
 
 
 def main():
-    for n in sys.argv[1:] or ["pair", "fast", "strict"]:
+    for n in sys.argv[1:] or ["pair", "fast", "strict", "hist32"]:
         r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950",
                             "-ffp-contract=" + CONTRACT.get(n, "on"), "-c", os.path.join(CSRC, "stepper_%s.hip" % n),
                             "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
