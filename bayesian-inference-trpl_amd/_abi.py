@@ -28,6 +28,8 @@ def fp32_flags(fp32):
     return FLAG_FP32 | (FLAG_FP32_LONG if fp32 == "long" else 0)
 MAX_BUNDLE = 16                 # the flag's range; the library accepts bundle_cap(L) of it
 PL_FLOOR_EXCESS = 1e-4          # TRPL_PL_FLOOR_EXCESS
+PL_ENVELOPE_K_THICK = 5e-13     # TRPL_PL_ENVELOPE_K_THICK: |dPL / PL| <= 1e-9 + K / r on the 2000 nm films (L = 128)
+PL_ENVELOPE_K_THIN = 1e-11      # TRPL_PL_ENVELOPE_K_THIN: the same on the 311 nm films
 
 
 def bundle_cap(L):

@@ -198,14 +198,19 @@ int launch(const trpl::StepArgs &a_in, uint32_t flags, hipStream_t st, int64_t s
     if (int rc = check_variant_flags(flags, a_in.L)) return rc;
     trpl::StepArgs a = a_in;
     a.bundle = (int32_t)((flags >> 8) & 0xF) + 1;             // TRPL_FLAG_BUNDLE(m)
+    if (flags & TRPL_FLAG_HIST32) {
+        if (flags & (TRPL_FLAG_STRICT | TRPL_FLAG_FP32 | TRPL_FLAG_MIXED | TRPL_FLAG_KERNEL_PAIR))
+            return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_HIST32 excludes TRPL_FLAG_STRICT, TRPL_FLAG_FP32, TRPL_FLAG_MIXED and TRPL_FLAG_KERNEL_PAIR");
+        if (a.L != 256 && a.L != 512) return api_fail(TRPL_ERR_UNSUPPORTED, "TRPL_FLAG_HIST32: the fp32-difference history is built for L = 256 and 512 (got %d)", a.L);
+        if (a.n_snap > 0 || a.resN != nullptr || a.bundle > 1)
+            return api_fail(TRPL_ERR_UNSUPPORTED, "snapshots, resume and bundles are not available with TRPL_FLAG_HIST32");
+    }
     if (a.bundle > 1 && (flags & (TRPL_FLAG_FP32 | TRPL_FLAG_MIXED | TRPL_FLAG_KERNEL_PAIR)))
         return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_BUNDLE goes with TRPL_FLAG_STRICT or the plain fp64 one-system stepper only");
     if (a.bundle > 1 && !(flags & TRPL_FLAG_STRICT) && a.L > 128)
         return api_fail(TRPL_ERR_UNSUPPORTED, "TRPL_FLAG_BUNDLE without TRPL_FLAG_STRICT is built for L <= 128 (got %d)", a.L);
     if (a.bundle > trpl::bundle_cap(a.L))
         return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_BUNDLE(%d): at most %d systems per bundle at L = %d", a.bundle, trpl::bundle_cap(a.L), a.L);
-    if ((flags & TRPL_FLAG_HIST32) && (flags & (TRPL_FLAG_FP32 | TRPL_FLAG_MIXED | TRPL_FLAG_KERNEL_PAIR)))
-        return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_HIST32 excludes TRPL_FLAG_FP32, TRPL_FLAG_MIXED and TRPL_FLAG_KERNEL_PAIR");
     if (flags & TRPL_FLAG_FP32) {
         if (flags & (TRPL_FLAG_STRICT | TRPL_FLAG_MIXED)) return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_FP32 excludes TRPL_FLAG_STRICT and TRPL_FLAG_MIXED");
         if (a.L < 128) return api_fail(TRPL_ERR_UNSUPPORTED, "the fp32 stepper is built for L >= 128 (got %d)", a.L);
@@ -226,10 +231,6 @@ int launch(const trpl::StepArgs &a_in, uint32_t flags, hipStream_t st, int64_t s
         return TRPL_OK;
     }
     if (flags & TRPL_FLAG_HIST32) {
-        if (flags & TRPL_FLAG_STRICT) return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_HIST32 and TRPL_FLAG_STRICT exclude each other");
-        if (a.L != 256 && a.L != 512) return api_fail(TRPL_ERR_UNSUPPORTED, "the fp32-difference history is built for L = 256 and 512 (got %d)", a.L);
-        if (a.n_snap > 0 || a.resN != nullptr || a.bundle > 1)
-            return api_fail(TRPL_ERR_UNSUPPORTED, "snapshots, resume and bundles are not available with TRPL_FLAG_HIST32");
         hipError_t eh = trpl::launch_stepper_hist32(a, st);
         if (eh != hipSuccess) return api_fail(TRPL_ERR_HIP, "hist32 stepper launch: %s", hipGetErrorString(eh));
         return TRPL_OK;

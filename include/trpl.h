@@ -79,9 +79,10 @@ extern "C" {
                                      difference form with the older differences stored in fp32 (every row of the BDF table,
                                      pvSimPCR.py:241-250, sums to zero: only the newest level is needed in full).  One-system
                                      stepper at L = 256 / 512; no snapshots, resume or bundles; not combinable with STRICT /
-                                     FP32 / MIXED.  An experiment of round 4: same occupancy and speed
-                                     as the fp64 history, PL within ~1e-8 of it -- not selected by default.  No reference
-                                     exists for it */
+                                     FP32 / MIXED.  An experiment of round 4: the oracle's iteration
+                                     totals and PL within 1.4e-9 over 8000 steps at L = 512, but no occupancy gain (-5 %;
+                                     +1.6 % in the best build variant) -- never selected by default.  No reference exists
+                                     for it */
 #define TRPL_FLAG_SNAP_RAW 0x80   /* trpl_solve_pl_snap / _resume: snapshots in SOLVER units (no division by dx^3 / dx), the
                                      form trpl_solve_pl_resume reads back bit for bit */
 #define TRPL_FLAG_BUNDLE(m) ((uint32_t)(((m) - 1) & 0xF) << 8)
@@ -268,43 +269,26 @@ int trpl_loglik_from_pl_dev(const void *plI, int32_t elem_bytes, int64_t rows, i
  *   dN      [C][L], obs [C][obs_ld] log10 observations, n_obs [C] host int64 (<= T/plT + 1)
  *   sse     [C][S] out;  status [C][S] out (nullable);  iters_total [C][S] out (nullable)
  *   floor_col [C][S] out (nullable): the CANCELLATION FLOOR indicator.  PL = B (sum_i N_i P_i - L n0 p0) is a
- *           difference of two nearly equal numbers once the excess carriers have decayed.  With
+ *           difference of nearly equal numbers once the excess carriers have decayed.  With
  *               r(t) = PL(t) / (B L n0 p0)        (mean excess product per node over the equilibrium product)
- *           two correct fp64 evaluations of the same scheme -- this library's default arithmetic and the reference's
- *           order of operations (TRPL_FLAG_STRICT, which reproduces the sequentially executed reference bit for
- *           bit), or the reference with and without FMA contraction -- hold states that differ by ~1e-12 relative
- *           (the solver tolerance is 1e-7), and the subtraction amplifies that to
- *               |dPL / PL|  <~  1e-9 + 1e-12 / r(t)
- *           (measured, profiles/r3_floor_study.json: 1e-9 at r = 1e-3, 1e-8 at 1e-4, 1e-6 at 1e-6, O(1) at 1e-12;
- *           below r ~ 1e-13 the reference's own value is the sign and size of the last rounding of its 128-term
- *           sum, pvSimPCR.py:276-281 -- negative about half the time, i.e. clamped to DBL_MIN by fastlog,
- *           bayeslib.py:157 -- while the default arithmetic, which forms the per-node excess fma(N_i, P_i, -n0p0)
- *           before summing, keeps following the state and lands on the clamp when that turns non-positive).
- *           floor_col[c][s] is the first compared PL column (observation index; the grid step with off-grid
- *           observations) with r < TRPL_PL_FLOOR_EXCESS = 1e-4 (or a non-positive / NaN PL), or -1 if there is none;
- *           -2 for a system flagged as non-converged (status != 0: its sse is +inf and it has no PL to compare).
- *           CONTRACT: every system whose sse differs from the reference evaluation's by more than 1e-6 (relative) has
- *           floor_col >= 0 -- verified on the reference's prior box over its full 80 000-step window for both shipped
- *           workloads (profiles/r3_validate_full_config1_T80000.txt: 65 536 samples x 3 curves, 2 473 such samples, all
- *           flagged; profiles/r3_validate_twothick_32768_T80000.txt: 32 768 x 6 curves, 1 259, all flagged) -- and
- *           floor_col itself is the same column in both arithmetics for all 196 608 systems of the first run and all
- *           but 2 of the second.  How closely the
- *           floor-free systems agree is set by the grid: the state gap that 1 / r amplifies is ~1e-12 on the 2000 nm
- *           films (largest sse gap of 62 059 floor-free samples 1.03e-8, 99.9th percentile 2.5e-9, every compared PL
- *           value within 2e-8) and ~2e-11 on the 311 nm films, whose stencil D dt / dx^2 is 40 times stiffer (largest
- *           gap 6.3e-7, 99.9th percentile 6.5e-8).  For the others the same holds on the columns before floor_col,
- *           and from there on PL -- hence sse -- depends on the evaluation order at the level given above: compare
- *           such samples across implementations on the window before floor_col, or not at all (once PL is on the
- *           clamp their sse grows by ~1e5 per point in one evaluation and by (log10 of rounding noise)^2 in another;
- *           either way their posterior weight is 0: |log-likelihood| >= 6.5e5 against a median of 5.6e4).  Every one
- *           of the 2 473 samples whose likelihood differs by more than 1e-6 between the two arithmetics is flagged
- *           (profiles/r3_validate_full_config1_T80000.txt).  Summing sum_i N_i P_i first and subtracting L n0p0 once,
- *           as the reference does, instead of the per-node excess changes none of these figures (measured,
- *           profiles/r3_validate_pl_sum_order_16k_T80000.txt): the gap comes from the states, not from the sum.
+ *           this library's default arithmetic and the reference's order of operations (TRPL_FLAG_STRICT, the
+ *           sequentially executed reference bit for bit) agree to
+ *               |dPL / PL|  <=  1e-9 + K / r(t),    K = TRPL_PL_ENVELOPE_K_THICK = 5e-13 on the 2000 nm films (L = 128),
+ *                                                   K = TRPL_PL_ENVELOPE_K_THIN  = 1e-11 on the 311 nm films
+ *           (K grows with the stencil's stiffness D dt / dx^2; measured 2e-13 / 3.7e-12, tests hold the constants).
+ *           floor_col[c][s] = first compared PL column (observation index; the grid step with off-grid observations)
+ *           with r < TRPL_PL_FLOOR_EXCESS = 1e-4 or a non-positive / NaN PL; -1 if there is none; -2 for a system
+ *           flagged as non-converged (status != 0: sse = +inf, nothing to compare).
+ *           CONTRACT: a system with floor_col = -1 has sse within 1e-8 (relative) of the reference evaluation's; every
+ *           system whose sse differs by more than 1e-6 has floor_col >= 0, and from that column on its PL depends on
+ *           the evaluation order at the level above -- compare such systems across implementations on the columns
+ *           before floor_col, or not at all (their posterior weight is 0).  Measurements: DESIGN.md section 2.
  * Any number of curves up to TRPL_MAX_CURVES (bayeslib.py:117 loops over them all): more than 16 run as consecutive launches of
  * up to 16 curves on the same stream; a system's bits do not depend on that grouping.
  * ------------------------------------------------------------------------------------- */
 #define TRPL_PL_FLOOR_EXCESS 1e-4
+#define TRPL_PL_ENVELOPE_K_THICK 5e-13
+#define TRPL_PL_ENVELOPE_K_THIN 1e-11
 #define TRPL_MAX_CURVES 1024
 int trpl_loglik(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns,
                 int32_t L, int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter,

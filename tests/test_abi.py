@@ -290,3 +290,26 @@ def test_pair_table_covers_every_system_of_a_period_once(trpl):
         for a, oa, b, ob in t:
             assert lengths[a] == lengths[b] and n_obs[a] == n_obs[b] and ((a != b and oa == ob) or (a == b and (oa, ob) == (0, 1)))
     assert lib.trpl_pair_table(None, None, 3, 128, 8000, 200.0, None, None, None, None) == -trpl._abi.ERR_ARG
+
+
+def test_python_constants_equal_the_headers_defines():
+    """Every flag, kernel id and documented constant of include/trpl.h that the Python binding restates has the same
+    value there (the header is the contract; the envelope constants are what the -m gpu parity tests assert)."""
+    from trpl_amd import _abi as A
+    hdr = open(os.path.join(ROOT, "include", "trpl.h")).read()
+    defs = dict(re.findall(r"^#define (TRPL_[A-Z0-9_]+) +([0-9][0-9a-fA-Fx.e+-]*)\b", hdr, flags=re.M))
+    num = lambda v: int(v, 0) if re.fullmatch(r"0[xX][0-9a-fA-F]+|\d+", v) else float(v)
+    pairs = {"TRPL_FLAG_STRICT": A.FLAG_STRICT, "TRPL_FLAG_PL_F32": A.FLAG_PL_F32, "TRPL_FLAG_NORMALIZE": A.FLAG_NORMALIZE,
+             "TRPL_FLAG_FP32": A.FLAG_FP32, "TRPL_FLAG_KERNEL_PAIR": A.FLAG_KERNEL_PAIR, "TRPL_FLAG_KERNEL_SINGLE": A.FLAG_KERNEL_SINGLE,
+             "TRPL_FLAG_MIXED": A.FLAG_MIXED, "TRPL_FLAG_SNAP_RAW": A.FLAG_SNAP_RAW, "TRPL_FLAG_FP32_LONG": A.FLAG_FP32_LONG,
+             "TRPL_FLAG_HIST32": A.FLAG_HIST32, "TRPL_FP32_MAX_STEPS": A.FP32_MAX_STEPS,
+             "TRPL_KERNEL_FAST": A.KERNEL_FAST, "TRPL_KERNEL_FAST_PAIR": A.KERNEL_FAST_PAIR, "TRPL_KERNEL_STRICT": A.KERNEL_STRICT,
+             "TRPL_KERNEL_FP32": A.KERNEL_FP32, "TRPL_KERNEL_MIXED": A.KERNEL_MIXED, "TRPL_KERNEL_HIST32": A.KERNEL_HIST32,
+             "TRPL_PL_FLOOR_EXCESS": A.PL_FLOOR_EXCESS, "TRPL_PL_ENVELOPE_K_THICK": A.PL_ENVELOPE_K_THICK,
+             "TRPL_PL_ENVELOPE_K_THIN": A.PL_ENVELOPE_K_THIN, "TRPL_ABI_VERSION": A.ABI_VERSION}
+    for name, val in pairs.items():
+        assert name in defs, name
+        assert num(defs[name]) == val, (name, defs[name], val)
+    flags = [v for k, v in pairs.items() if k.startswith("TRPL_FLAG_")]
+    assert len(set(flags)) == len(flags) and all(f & (f - 1) == 0 for f in flags)          # distinct single bits
+    assert not any(f & 0xF00 for f in flags)                                                # TRPL_FLAG_BUNDLE's field

@@ -241,7 +241,7 @@ def test_two_legitimate_evaluations_of_the_reference_part_company_as_the_floor_c
     contracts (numba-CUDA and nvcc do by default) evaluates the SAME source to slightly different states.  The oracle
     built with -ffp-contract=fast -mfma stands for that evaluation: against the pinned build it takes the same number of
     inner iterations on every system, its PL agrees to ~1e-12 while the excess carriers are there -- and loses digits
-    exactly as include/trpl.h says any second evaluation does once they have decayed: |dPL / PL| <= 1e-9 + 2e-12 / r,
+    exactly as include/trpl.h says a second evaluation does once they have decayed: |dPL / PL| <= 1e-9 + K / r, K = 5e-13,
     r = PL / (B L n0p0).  (What `floor_col` reports is a property of the arithmetic problem, not of this library.)"""
     import trpl_amd
     w = trpl_amd.workloads
@@ -268,5 +268,5 @@ def test_two_legitimate_evaluations_of_the_reference_part_company_as_the_floor_c
     assert high.any() and dev[high].max() < 1e-10                         # excess carriers present: rounding level
     physical = r >= 1e-10
     assert (r[:, -1] < 1e-6).sum() >= S // 2                              # most of these systems get deep into the decay
-    assert (dev[physical] <= 1e-9 + 2e-12 / r[physical]).all()
+    assert (dev[physical] <= 1e-9 + 5e-13 / r[physical]).all()          # TRPL_PL_ENVELOPE_K_THICK (measured here: ~5e-15 / r)
     assert dev[(r < 1e-6) & physical].max() > 1e-8                        # ... and there the two evaluations do differ

@@ -22,8 +22,10 @@ for k, v in sorted(res.items()):
     print("   %-28s %.4g" % (k, v))
 wc = res['SQ_WAVE_CYCLES']; gui = res['GRBM_GUI_ACTIVE'] / 8
 print('kernel cycles %.4g ; avg resident waves/SIMD %.2f' % (gui, wc * 4 / gui / 1024))
-print('VALU active / SIMD-cycle %.3f   LDS busy / CU-cycle %.3f' % (res['SQ_ACTIVE_INST_VALU'] * 4 / 1024 / gui, res['SQ_LDS_IDX_ACTIVE'] / 256 / gui))
-print('wave-time shares: valu %.3f lds %.3f scalar %.3f wait_any %.3f wait_inst_any %.3f wait_inst_lds %.3f' % tuple(res[k] / wc for k in ('SQ_ACTIVE_INST_VALU', 'SQ_ACTIVE_INST_LDS', 'SQ_ACTIVE_INST_SCA', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_WAIT_INST_LDS')))
+print('VALU active / SIMD-cycle %.3f   LDS busy / CU-cycle %s' % (res['SQ_ACTIVE_INST_VALU'] * 4 / 1024 / gui, ('%.3f' % (res['SQ_LDS_IDX_ACTIVE'] / 256 / gui)) if 'SQ_LDS_IDX_ACTIVE' in res else 'n/a (pass 2 not collected)'))
+print('wave-time shares: valu %.3f lds %.3f scalar %.3f wait_any %.3f wait_inst_any %.3f wait_inst_lds %.3f' % tuple(res.get(k, float('nan')) / wc for k in ('SQ_ACTIVE_INST_VALU', 'SQ_ACTIVE_INST_LDS', 'SQ_ACTIVE_INST_SCA', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_WAIT_INST_LDS')))
+if 'SQ_INSTS_VALU' not in res:
+    sys.exit(0)          # PMC_SETS="1 4": occupancy and busy shares only
 print('cycles per VALU inst (active) %.2f ; SIMD-cycles per VALU inst %.2f ; VALU/LDS/SALU insts per wave %.4g / %.4g / %.4g' % (4 * res['SQ_ACTIVE_INST_VALU'] / res['SQ_INSTS_VALU'], 1024 * gui / res['SQ_INSTS_VALU'], res['SQ_INSTS_VALU'] / res['SQ_WAVES'], res['SQ_INSTS_LDS'] / res['SQ_WAVES'], res['SQ_INSTS_SALU'] / res['SQ_WAVES']))
 if '--steps' in opts:
     T = float(opts['--steps']); waves = res['SQ_WAVES']
