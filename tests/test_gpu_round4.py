@@ -291,7 +291,7 @@ def test_hist32_at_256_nodes_and_what_the_flag_refuses(gpu):
         assert not np.array_equal(pl32, pl64)                      # it IS another arithmetic
     ini = w.beer_lambert(w.POWER_SCAN_A_CM3[0], length, L)
     assert gpu._abi.lib().trpl_kernel_variant(S, L, T, gpu._abi.FLAG_HIST32) == gpu._abi.KERNEL_HIST32
-    for bad in (dict(L=128), dict(strict=True), dict(mixed=True), dict(fp32=True), dict(bundle=2), dict(snap_steps=[3])):
+    for bad in (dict(L=128), dict(strict=True), dict(mixed=True), dict(fp32=True), dict(bundle=2), dict(snap_steps=[3], snapshots={})):
         kw = dict(hist32=True)
         kw.update({k: v for k, v in bad.items() if k != "L"})
         Lb = bad.get("L", L)
