@@ -61,6 +61,12 @@ orders = {"as drawn": ident,
 dmin = np.minimum(Xh[:, 2], Xh[:, 3]).reshape(-1, 2).min(axis=1)
 pred = np.argsort(dmin, kind="stable")
 orders["smaller diffusivity ascending (a predictor)"] = np.stack([2 * pred, 2 * pred + 1], 1).ravel()
+# round 4: SAMPLES sorted individually (adjacent positions = similar samples: the leftover curve of an odd group pairs
+# two adjacent samples in one wavefront, so this order also shrinks that pair's divergence)
+orders["samples sorted individually, heaviest first (perfect knowledge)"] = np.argsort(-tot, kind="stable")
+dmin1 = np.minimum(Xh[:, 2], Xh[:, 3])
+orders["samples sorted individually by the smaller diffusivity, ascending"] = np.argsort(dmin1, kind="stable")
+orders["samples sorted individually by the hole diffusivity, ascending"] = np.argsort(Xh[:, 3], kind="stable")
 res = {"S": S, "T": T, "iterations_per_sample": {"min": int(tot.min()), "median": float(np.median(tot)), "max": int(tot.max())}, "orders": {}}
 for name, o in orders.items():
     ms, P, _ = run(o)
