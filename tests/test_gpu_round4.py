@@ -298,3 +298,27 @@ def test_hist32_at_256_nodes_and_what_the_flag_refuses(gpu):
         with pytest.raises(gpu.TrplError) as e:
             gpu.solve_pl(X[:, :12], length, 10 * DT, Lb, 10, w.beer_lambert(w.POWER_SCAN_A_CM3[0], length, Lb), **kw)
         assert "HIST32" in str(e.value) or "hist32" in str(e.value) or "history" in str(e.value), (bad, str(e.value))
+
+
+@pytest.mark.parametrize("kernel", ["single", "pair"])
+def test_twothick_bench_window_offgrid_observations_against_the_oracle(gpu, oracle, twothick_window, kernel):
+    """The caller-side data path at the bench's window: observation times OFF the simulation grid (the reference
+    interpolates every PL row with scipy griddata, bayeslib.py:184-191; here the bracketing is fused into the stepper,
+    trpl_loglik_obs) and self-normalisation (:150-154), Twothick x 32 samples x 6 curves x T = 8000, against the oracle's
+    restatement of bayeslib.simulate.  Floor-free samples: the oracle's likelihood to 1e-8 in fp64 and to 2e-5 with the
+    reference's float32 PL staging (one float32 ulp of log10 PL enters every residual)."""
+    g = twothick_window
+    rng = np.random.default_rng(23)
+    times = [np.sort(rng.uniform(0.0, g["Time"], 211)) for _ in range(6)]
+    obs = [np.interp(times[c], np.linspace(0.0, g["Time"], g["T"] + 1), g["obs"][c]) + 0.01 for c in range(6)]
+    for normalize, f32 in ((False, False), (True, False), (False, True)):
+        want = oracle.simulate_loglik(g["X"], g["ini"], g["lens"], g["Time"], g["L"], g["T"], [(times, obs)],
+                                      pl_dtype=np.float32 if f32 else np.float64, normalize=normalize, nthreads=nthreads())[0]
+        info = {}
+        P = gpu.loglik(g["X"], g["ini"], g["lens"], g["Time"], g["L"], g["T"], obs, times=times, pl_f32=f32,
+                       normalize=normalize, kernel=kernel, info=info)
+        assert not info["status"].any()
+        clear = (info["floor_col"] < 0).all(axis=0)
+        assert clear.sum() >= 0.8 * g["S"]
+        rel = np.abs(P - want) / np.abs(want)
+        assert rel[clear].max() < (2e-5 if f32 else 1e-8), (normalize, f32, float(rel[clear].max()))
