@@ -39,6 +39,14 @@
 #ifndef TRPL_PCR_SETPRIO
 #define TRPL_PCR_SETPRIO 2        // s_setprio level inside the cross-lane PCR levels (0 = off)
 #endif
+#ifndef TRPL_PAIR_OPTIMISTIC
+#define TRPL_PAIR_OPTIMISTIC 1    // paired kernel: iterate without the seam selects, repeat a time step with them when a
+                                  // system is flagged in it (stepper_pair_impl.hpp); 0 = the selects in every iteration
+#endif
+#ifndef TRPL_NORM_VOTE
+#define TRPL_NORM_VOTE 1          // FAST residual tests: the sign of sum(|r| - TOL |b|) from a lane vote where all lanes agree
+                                  // (no reduction); 0 = always reduce.  Same decisions either way.
+#endif
 #ifndef TRPL_RCP_QUAD
 #define TRPL_RCP_QUAD 1       // four row reciprocals from one v_rcp_f64 (rcp_rows, NR % 4 == 0); measured, see DESIGN.md section 8
 #endif
@@ -307,6 +315,21 @@ __device__ __forceinline__ double wave_sum(double v)
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
     return __hiloint2double(hi, lo);
+}
+
+// Is the wave-wide sum of v negative?  Where every lane's term is negative the sum is, where every lane's term is >= 0 it
+// is not -- whatever the order of summation -- and a vote (two v_cmp, scalar compares) replaces the 6-step DPP reduction.
+// Only with mixed signs (or a NaN, which fails both votes) does the sum itself decide.  In the steppers the terms are
+// |r| - TOL |b| per lane: in a time step's first iteration every lane is far above zero, in its last one nearly always
+// every lane is below.
+__device__ __forceinline__ bool wave_sum_negative(double v)
+{
+    if constexpr (TRPL_NORM_VOTE != 0) {
+        const unsigned long long neg = __builtin_amdgcn_ballot_w64(v < 0.0), nonneg = __builtin_amdgcn_ballot_w64(v >= 0.0);
+        if (neg == ~0ull) return true;
+        if (nonneg == ~0ull) return false;
+    }
+    return wave_sum(v) < 0.0;
 }
 
 // (value of the lower-half lane, value of the upper-half lane) of each lane pair (l, l^32), in

@@ -108,7 +108,10 @@ __device__ __forceinline__ bool residual_below(const double (&l)[NR], const doub
         double q[NR];
 #pragma unroll
         for (int j = 0; j < NR; j++) q[j] = __builtin_fma(-TOL, ab[j], r[j]);
-        return sum_nodes<LAY, NR, W>(q) < 0.0;
+        double s = q[0];
+#pragma unroll
+        for (int j = 1; j < NR; j++) s += q[j];
+        return wave_sum_negative(s);
     } else {
         const double sr = sum_nodes<LAY, NR, W>(r);
         const double sb = sum_nodes<LAY, NR, W>(ab);
@@ -152,7 +155,10 @@ __device__ __forceinline__ bool residual_vec(const double (&l)[NR], const double
         r[j] = b[j] - (l[j] * cm[j] + dg[j] * c[j] + u[j] * cp[j]);
         q[j] = __builtin_fma(-TOL, fabs(b[j]), fabs(r[j]));
     }
-    return sum_nodes<2, NR, 64>(q) < 0.0;
+    double s = q[0];
+#pragma unroll
+    for (int j = 1; j < NR; j++) s += q[j];
+    return wave_sum_negative(s);
 }
 
 // One correction of iterate c of the system (lo, dg, up | bb): delta from the fp32 solve of A delta = r,

@@ -52,11 +52,13 @@ __device__ __forceinline__ void half_sums(double v, double &lo, double &hi)
     hi = lane_value(v, 63);
 }
 
-// norm2 (pvSimPCR.py:14-40) of both systems: ok = sum|A c - b| < TOL * sum|b|, one reduction each
+// norm2 (pvSimPCR.py:14-40) of both systems: ok = sum|A c - b| < TOL * sum|b|, one reduction each -- or none: where all
+// 32 lanes of a system agree on the sign of their term, that is the sign of its sum (wave_sum_negative, crosslane.hpp).
+// needA / needB: the systems whose verdict is used (a frozen or parked system's is not, and must not force a reduction).
 template <bool ISO>
 __device__ __forceinline__ void residual_below2(const double (&l)[NR], const double (&dg)[NR], const double (&u)[NR],
                                                 const double (&b)[NR], const double (&c)[NR], double TOL, int lane,
-                                                bool &okA, bool &okB)
+                                                bool needA, bool needB, bool &okA, bool &okB)
 {
     double cm[NR], cp[NR];
     nbrB_dn<double, NR, 1>(c, cm, lane);
@@ -70,6 +72,21 @@ __device__ __forceinline__ void residual_below2(const double (&l)[NR], const dou
         const double r = fabs(__builtin_fma(l[j], cm[j], __builtin_fma(dg[j], c[j], __builtin_fma(u[j], cp[j], -b[j]))));
         const double qj = __builtin_fma(-TOL, fabs(b[j]), r);
         q = j == 0 ? qj : q + qj;
+    }
+    if constexpr (TRPL_NORM_VOTE != 0) {
+        const unsigned long long neg = __builtin_amdgcn_ballot_w64(q < 0.0), nonneg = __builtin_amdgcn_ballot_w64(q >= 0.0);
+        // the upper halves behind an empty asm: the optimiser would otherwise fold the `>> 32` test into a 64-bit unsigned
+        // compare, which only the VALU has
+        const unsigned negA = (unsigned)neg, nnA = (unsigned)nonneg;
+        unsigned negB = (unsigned)(neg >> 32), nnB = (unsigned)(nonneg >> 32);
+        asm volatile("" : "+s"(negB), "+s"(nnB));
+        const bool allnegA = negA == ~0u, allnegB = negB == ~0u;
+        const bool decidedA = !needA || allnegA || nnA == ~0u, decidedB = !needB || allnegB || nnB == ~0u;
+        if (decidedA && decidedB) {
+            okA = allnegA;
+            okB = allnegB;
+            return;
+        }
     }
     double sA, sB;
     half_sums(q, sA, sB);
@@ -281,16 +298,17 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
         // -ffp-contract=on (fusion decided by the syntax of each expression, not by the optimiser's view of the
         // surrounding code), so a system's arithmetic is bit-identical in the two -- its result must not depend
         // on when its partner converges.
-        auto iterate_once = [&](auto frozen_c, int iters) {
+        auto iterate_once = [&](auto frozen_c, auto seam_c, int iters) {
             constexpr bool FROZEN = decltype(frozen_c)::value;
+            constexpr bool SEAM = decltype(seam_c)::value;     // void what crosses the seam inside the iteration
             const bool act = FROZEN ? (hi ? !doneB : !doneA) : true;   // lanes of a system that is still iterating
             double lo_[NR], dg[NR], up[NR], bb[NR], Ep[NR], x[NR];
             nbrB_up<double, NR, 1>(Ek, Ep, lane);   // a system's last lane reads the partner's E_0 = 0: E_L = 0
             bool okNA, okNB, okPA, okPB;
             // ---- electrons (:148-175) ----
             assemble<LAY, true, NR, WS, L, true>(mp, a0, Nk, Pk, Ek, Ep, bN, lo_, dg, up, bb, ln);
-            residual_below2<ISO>(lo_, dg, up, bb, Nk, TOL, lane, okNA, okNB);                      // :172
-            cr_pcr_solve<double, NR, WS, ISO, XM>(lo_, dg, up, bb, x, lane, xch);                       // :175
+            residual_below2<SEAM>(lo_, dg, up, bb, Nk, TOL, lane, FROZEN ? !doneA : true, FROZEN ? !doneB : true, okNA, okNB);   // :172
+            cr_pcr_solve<double, NR, WS, SEAM, XM>(lo_, dg, up, bb, x, lane, xch);                      // :175
 #pragma unroll
             for (int j = 0; j < NR; j++) Nk[j] = act ? x[j] : Nk[j];
             // ---- holes, with the updated electrons (:178-202) ----
@@ -298,10 +316,11 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
             // the holes' norm only matters if the electrons' passed for a system that is still iterating (:213):
             // on the first iteration of a time step it practically never has (a wave-uniform branch)
             if (FROZEN ? ((!doneA && okNA) || (!doneB && okNB)) : (okNA || okNB))
-                residual_below2<ISO>(lo_, dg, up, bb, Pk, TOL, lane, okPA, okPB);                  // :200
+                residual_below2<SEAM>(lo_, dg, up, bb, Pk, TOL, lane, FROZEN ? (!doneA && okNA) : okNA, FROZEN ? (!doneB && okNB) : okNB,
+                                      okPA, okPB);                                                  // :200
             else
                 okPA = okPB = false;
-            cr_pcr_solve<double, NR, WS, ISO, XM>(lo_, dg, up, bb, x, lane, xch);                       // :202
+            cr_pcr_solve<double, NR, WS, SEAM, XM>(lo_, dg, up, bb, x, lane, xch);                      // :202
 #pragma unroll
             for (int j = 0; j < NR; j++) Pk[j] = act ? x[j] : Pk[j];
             // ---- field on edges 1..L-1 (:205-209) ----
@@ -312,9 +331,35 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
         // within a time step a system only ever goes from iterating to done: first the iterations with both
         // systems active, then those with one of them frozen (two loops, not a branch inside one: the register
         // allocator handles them separately; a branch inside the loop spilled 89 VGPRs)
-        int iters = 0;
-        for (; iters < MAX && !(doneA || doneB); iters++) iterate_once(std::false_type{}, iters);
-        for (; iters < MAX && !(doneA && doneB); iters++) iterate_once(std::true_type{}, iters);
+        auto iterate_step = [&](auto seam_c) {
+            int iters = 0;
+            for (; iters < MAX && !(doneA || doneB); iters++) iterate_once(std::false_type{}, seam_c, iters);
+            for (; iters < MAX && !(doneA && doneB); iters++) iterate_once(std::true_type{}, seam_c, iters);
+        };
+        if constexpr (ISO && TRPL_PAIR_OPTIMISTIC != 0) {
+            // OPTIMISTIC SEAM.  Everything that crosses the seam inside an iteration meets an exact-zero coefficient
+            // (update_field2's edge 0 apart, which is always voided), so while both systems are finite the voiding
+            // selects change no bit -- they only keep a NaN / Inf of one system out of the other (0 * NaN).  A system
+            // that produces a non-finite value does not converge in that time step (its residual norm is NaN from then
+            // on) and is flagged at the step's end; live systems are finite at every step boundary (a flagged one is
+            // parked at equilibrium).  So: iterate WITHOUT the selects (36 of the iteration's 46 v_cndmask), and if a
+            // system ends the step flagged, put both back to U^t -- N and P from the ring slot written above, E from
+            // hE[0] -- and repeat the step with them.  The repeat is the arithmetic of the always-voiding kernel, hence
+            // so is every result; the common step pays nothing.
+            iterate_step(std::false_type{});
+            if ((!deadA && itA >= MAX) || (!deadB && itB >= MAX)) {
+                const int s4 = (int)(t & 3) * NR;
+#pragma unroll
+                for (int j = 0; j < NR; j++) {
+                    const double2 h = hist2[(s4 + j) * 64 + lane];
+                    Nk[j] = h.x; Pk[j] = h.y; Ek[j] = hE[0][j];
+                }
+                doneA = deadA; doneB = deadB; itA = itB = MAX;
+                iterate_step(std::true_type{});
+            }
+        } else {
+            iterate_step(std::integral_constant<bool, ISO>{});
+        }
         bool killA = false, killB = false;
         // :269-274 -- like the reference, converging only in iteration MAX itself counts as a failure
         if (!deadA) { itotA += itA; if (itA >= MAX) { statusA = 1 + (int)t; killA = true; } }

@@ -322,3 +322,39 @@ def test_twothick_bench_window_offgrid_observations_against_the_oracle(gpu, orac
         assert clear.sum() >= 0.8 * g["S"]
         rel = np.abs(P - want) / np.abs(want)
         assert rel[clear].max() < (2e-5 if f32 else 1e-8), (normalize, f32, float(rel[clear].max()))
+
+
+def test_paired_kernel_repeated_steps_leave_the_partners_bits_alone(gpu):
+    """The paired kernel iterates without the seam selects and repeats a time step with them when a system is flagged in
+    it (stepper_pair_impl.hpp, "optimistic seam").  Under a small iteration cap many systems are flagged at different
+    steps, so many steps are repeated; with samples whose solve turns non-finite in between.  Dropping the first sample
+    gives every system another wavefront partner and the other half of the wavefront: status, iteration totals, squared
+    errors and likelihoods of every sample must not change by a bit, flagged or not."""
+    w = gpu.workloads
+    S, T, Time = 5121, 30, 0.75
+    lib = gpu._abi.lib()
+    assert lib.trpl_kernel_variant(3 * S, 128, T, 0) == gpu._abi.KERNEL_FAST_PAIR
+    X = w.samples(S, seed=11)
+    X[40, 9] = np.nan              # tau_n: non-finite from the first iteration on
+    X[77, 4] = np.inf              # radiative rate
+    X[301, 2] = -1e9               # negative diffusivity
+    ini, lengths = w.power_scan(128)
+    obs = [np.full(T + 1, 20.0)] * 3
+    a, b = {}, {}
+    pa = gpu.loglik(X, ini, lengths, Time, 128, T, obs, info=a, MAX=60)
+    pb = gpu.loglik(X[1:], ini, lengths, Time, 128, T, obs, info=b, MAX=60)
+    frac = (a["status"] > 0).mean()
+    assert 0.02 < frac < 0.98, frac                  # the cap bites on some systems only: steps are repeated
+    assert (a["status"][:, [40, 77]] > 0).all()
+    assert np.array_equal(a["status"][:, 1:], b["status"])
+    assert np.array_equal(a["iters_total"][:, 1:], b["iters_total"])
+    assert np.array_equal(a["sse"][:, 1:], b["sse"])
+    assert np.array_equal(pa[1:], pb)
+    # and without the cap: the partners of the three broken samples against a run that never had them
+    clean = w.samples(S, seed=11)
+    c, d = {}, {}
+    pc = gpu.loglik(clean, ini, lengths, Time, 128, T, obs, info=c)
+    pd = gpu.loglik(X, ini, lengths, Time, 128, T, obs, info=d)
+    ok = np.setdiff1d(np.arange(S), [40, 77, 301])
+    assert np.array_equal(pd[ok], pc[ok]) and np.array_equal(d["sse"][:, ok], c["sse"][:, ok])
+    assert np.array_equal(d["iters_total"][:, ok], c["iters_total"][:, ok]) and not c["status"].any()
