@@ -47,6 +47,9 @@
 #define TRPL_NORM_VOTE 1          // FAST residual tests: the sign of sum(|r| - TOL |b|) from a lane vote where all lanes agree
                                   // (no reduction); 0 = always reduce.  Same decisions either way.
 #endif
+#ifndef TRPL_VOTE_STATS
+#define TRPL_VOTE_STATS 0         // measurement build only: the paired kernel packs its count of residual reductions into iters_total
+#endif
 #ifndef TRPL_RCP_QUAD
 #define TRPL_RCP_QUAD 1       // four row reciprocals from one v_rcp_f64 (rcp_rows, NR % 4 == 0); measured, see DESIGN.md section 8
 #endif

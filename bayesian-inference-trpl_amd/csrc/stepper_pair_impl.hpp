@@ -58,7 +58,7 @@ __device__ __forceinline__ void half_sums(double v, double &lo, double &hi)
 template <bool ISO>
 __device__ __forceinline__ void residual_below2(const double (&l)[NR], const double (&dg)[NR], const double (&u)[NR],
                                                 const double (&b)[NR], const double (&c)[NR], double TOL, int lane,
-                                                bool needA, bool needB, bool &okA, bool &okB)
+                                                bool needA, bool needB, bool &okA, bool &okB, int *reductions = nullptr)
 {
     double cm[NR], cp[NR];
     nbrB_dn<double, NR, 1>(c, cm, lane);
@@ -88,6 +88,7 @@ __device__ __forceinline__ void residual_below2(const double (&l)[NR], const dou
             return;
         }
     }
+    if (reductions) (*reductions)++;
     double sA, sB;
     half_sums(q, sA, sB);
     okA = sA < 0.0;
@@ -191,6 +192,12 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
     int statusA = 0, statusB = 0;
     bool deadA = false, deadB = !validB;            // dead: flagged non-converged (or the odd tail's duplicate)
     int64_t itotA = 0, itotB = 0;
+#if TRPL_VOTE_STATS
+    int nredN = 0, nredP = 0;                      // measurement build: reductions the votes did not save
+#define TRPL_STAT(x) &x
+#else
+#define TRPL_STAT(x) nullptr
+#endif
     SnapSink snap(a, cc);
     // park this lane's system at equilibrium (finite, converges trivially): a flagged system for the rest of the run
     auto park = [&](bool mine) {
@@ -307,7 +314,8 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
             bool okNA, okNB, okPA, okPB;
             // ---- electrons (:148-175) ----
             assemble<LAY, true, NR, WS, L, true>(mp, a0, Nk, Pk, Ek, Ep, bN, lo_, dg, up, bb, ln);
-            residual_below2<SEAM>(lo_, dg, up, bb, Nk, TOL, lane, FROZEN ? !doneA : true, FROZEN ? !doneB : true, okNA, okNB);   // :172
+            residual_below2<SEAM>(lo_, dg, up, bb, Nk, TOL, lane, FROZEN ? !doneA : true, FROZEN ? !doneB : true, okNA, okNB,
+                                  TRPL_STAT(nredN));                                                 // :172
             cr_pcr_solve<double, NR, WS, SEAM, XM>(lo_, dg, up, bb, x, lane, xch);                      // :175
 #pragma unroll
             for (int j = 0; j < NR; j++) Nk[j] = act ? x[j] : Nk[j];
@@ -317,7 +325,7 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
             // on the first iteration of a time step it practically never has (a wave-uniform branch)
             if (FROZEN ? ((!doneA && okNA) || (!doneB && okNB)) : (okNA || okNB))
                 residual_below2<SEAM>(lo_, dg, up, bb, Pk, TOL, lane, FROZEN ? (!doneA && okNA) : okNA, FROZEN ? (!doneB && okNB) : okNB,
-                                      okPA, okPB);                                                  // :200
+                                      okPA, okPB, TRPL_STAT(nredP));                                // :200
             else
                 okPA = okPB = false;
             cr_pcr_solve<double, NR, WS, SEAM, XM>(lo_, dg, up, bb, x, lane, xch);                      // :202
@@ -390,6 +398,10 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
         if (statusA && !hi) snap.template fail_fill<L>(sinkA.orow, statusA, ln, WS);
         if (statusB && hi && validB) snap.template fail_fill<L>(sinkB.orow, statusB, ln, WS);
     }
+#if TRPL_VOTE_STATS
+    // iteration totals stay below 2^24 in the measured windows: reductions of the N tests << 24, of the P tests << 44
+    itotA += ((int64_t)nredN << 24) + ((int64_t)nredP << 44);
+#endif
     sinkA.finish(statusA, itotA);
     if (validB) sinkB.finish(statusB, itotB);
 }
