@@ -47,6 +47,16 @@
 #define TRPL_NORM_VOTE 1          // FAST residual tests: the sign of sum(|r| - TOL |b|) from a lane vote where all lanes agree
                                   // (no reduction); 0 = always reduce.  Same decisions either way.
 #endif
+#ifndef TRPL_NORM_VOTE_DEFER
+#define TRPL_NORM_VOTE_DEFER 0    // paired kernel: take a residual test's verdict where it is first used (1) or where its terms are
+                                  // formed (0).  Measured, same box: deferring costs 0.3 % (profiles/r4_ab_vote_defer.txt)
+#endif
+#ifndef TRPL_NORM_VOTE_DEFER1
+#define TRPL_NORM_VOTE_DEFER1 0   // the same choice for the one-system steppers
+#endif
+#ifndef TRPL_PAIRSTEP_ADD
+#define TRPL_PAIRSTEP_ADD 1       // final pair step of the CR + PCR solve: the coupling as A + C (one of them is an exact zero)
+#endif
 #ifndef TRPL_VOTE_STATS
 #define TRPL_VOTE_STATS 0         // measurement build only: the paired kernel packs its count of residual reductions into iters_total
 #endif

@@ -529,7 +529,10 @@ __device__ __forceinline__ void cr_pcr_solve(T (&ld)[NR], T (&d)[NR], T (&ud)[NR
     if constexpr (TRPL_PCR_SETPRIO > 0) __builtin_amdgcn_s_setprio(TRPL_PCR_SETPRIO);
     pcr64_levels<T, 1, WS, ISO, XM>(A, D, C, Bv, lane, xch);
     const bool low = (lane & (WS / 2)) == 0;       // pairs by Cramer's rule, own unknown only
-    const T c_own = low ? C : A;
+    // the coupling to the partner row: C in the lower half, A in the upper.  After the levels S = 1 .. WS/4 the other one
+    // is an exact zero (rows below 2 S have lost their sub-diagonal, rows above WS - 2 S their super-diagonal: products
+    // with the exact zeros of rows 0 and WS - 1), so A + C is that coupling, bit for bit -- one add instead of two selects
+    const T c_own = TRPL_PAIRSTEP_ADD != 0 ? A + C : (low ? C : A);
     T D_oth, B_oth, c_oth;
     if constexpr (WS == 64) {
         D_oth = partner32(D, low); B_oth = partner32(Bv, low); c_oth = partner32(c_own, low);

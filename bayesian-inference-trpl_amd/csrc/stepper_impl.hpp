@@ -120,6 +120,43 @@ __device__ __forceinline__ bool residual_below(const double (&l)[NR], const doub
     }
 }
 
+// The FAST (LAY 2) test in two parts, for the one-system steppers: the lanes' terms with their two votes, and the verdict --
+// taken by the caller where it is first needed (after the solve that follows), so that the vote's branch does not cut the
+// iteration's basic block between the residual and the solve (TRPL_NORM_VOTE_DEFER1, crosslane.hpp).
+struct Terms1 {
+    double q;                                   // this lane's sum over its rows of |r| - TOL |b|
+    unsigned long long neg, nonneg;             // lanes with q < 0 / q >= 0 (a NaN is in neither)
+};
+template <int NR>
+__device__ __forceinline__ Terms1 residual_terms(const double (&l)[NR], const double (&dg)[NR], const double (&u)[NR],
+                                                 const double (&b)[NR], const double (&c)[NR], double TOL, int ln)
+{
+    double cm[NR], cp[NR];
+    nbrB_dn<double, NR, 1>(c, cm, ln);
+    nbrB_up<double, NR, 1>(c, cp, ln);
+    double q = 0.0;
+#pragma unroll
+    for (int j = 0; j < NR; j++) {             // the same expressions as residual_below<2>
+        const double r = fabs(__builtin_fma(l[j], cm[j], __builtin_fma(dg[j], c[j], __builtin_fma(u[j], cp[j], -b[j]))));
+        const double qj = __builtin_fma(-TOL, fabs(b[j]), r);
+        q = j == 0 ? qj : q + qj;
+    }
+    Terms1 t = {q, 0ull, 0ull};
+    if constexpr (TRPL_NORM_VOTE != 0) {
+        t.neg = __builtin_amdgcn_ballot_w64(q < 0.0);
+        t.nonneg = __builtin_amdgcn_ballot_w64(q >= 0.0);
+    }
+    return t;
+}
+__device__ __forceinline__ bool residual_verdict(const Terms1 &t)
+{
+    if constexpr (TRPL_NORM_VOTE != 0) {
+        if (t.neg == ~0ull) return true;
+        if (t.nonneg == ~0ull) return false;
+    }
+    return wave_sum(t.q) < 0.0;
+}
+
 // STRICT, bundled systems (max_sims_per_block > 1): the quotient itself, because shared_array_max (pvSimPCR.py:83-90)
 // treats a NaN differently in the first system of a bundle (it sticks) and in the others (`>` skips it)
 template <int NR, int W>
@@ -848,6 +885,9 @@ stepper_kernel(const StepArgs a)
             double lo_[NR], dg[NR], up[NR], bb[NR], Ep[NR];
             shift_up1<LAY, NR, W>(Ek, Ep, ln);
             bool okN, okP;
+            // FAST, one system per workgroup: the residual tests' verdicts are taken where they are first used
+            constexpr bool DEFER = LAY == 2 && !MIXED && !BUNDLE && TRPL_NORM_VOTE_DEFER1 != 0;
+            Terms1 tN = {0.0, 0ull, ~0ull}, tP = {0.0, 0ull, ~0ull};       // "not below", decided without a reduction
             // ---- electrons (:148-175) ----
             assemble<LAY, true, NR, W, L>(mp, a0, Nk, Pk, Ek, Ep, bN, lo_, dg, up, bb, ln);
             if constexpr (MIXED) {
@@ -856,6 +896,9 @@ stepper_kernel(const StepArgs a)
                 const double e = residual_err_strict<NR, W>(lo_, dg, up, bb, Nk, ln);
                 okN = wv == 0 ? e < TOL : !(e >= TOL);
                 solve_lay<LAY, NR, W, L>(lo_, dg, up, bb, Nk, ln, xch);
+            } else if constexpr (DEFER) {
+                tN = residual_terms<NR>(lo_, dg, up, bb, Nk, TOL, ln);                             // :172
+                solve_lay<LAY, NR, W, L>(lo_, dg, up, bb, Nk, ln, xch);                                 // :175
             } else {
                 okN = residual_below<LAY, NR, W>(lo_, dg, up, bb, Nk, TOL, ln);                    // :172
                 solve_lay<LAY, NR, W, L>(lo_, dg, up, bb, Nk, ln, xch);                                 // :175
@@ -873,6 +916,9 @@ stepper_kernel(const StepArgs a)
                         const double e = residual_err_strict<NR, W>(lo_, dg, up, bb, Pk, ln);
                         okP = wv == 0 ? e < TOL : !(e >= TOL);
                     }
+                } else if constexpr (DEFER) {
+                    okN = residual_verdict(tN);
+                    if (okN) tP = residual_terms<NR>(lo_, dg, up, bb, Pk, TOL, ln);                 // :200
                 } else {
                     okP = okN ? residual_below<LAY, NR, W>(lo_, dg, up, bb, Pk, TOL, ln) : false;   // :200
                 }
@@ -880,6 +926,7 @@ stepper_kernel(const StepArgs a)
             }
             // ---- field on edges 1..L-1 (:205-209) ----
             update_field<LAY, NR, W>(mp, a0, Nk, Pk, bE, Ek, ln);
+            if constexpr (DEFER) okP = residual_verdict(tP);
             if constexpr (BUNDLE) {                // max over the bundle of errN and errP below TOL (:211-216)
                 if (lane64 == 0) agree[phase & 1][wv] = !valid || (okN && okP);
                 __syncthreads();

@@ -52,13 +52,23 @@ __device__ __forceinline__ void half_sums(double v, double &lo, double &hi)
     hi = lane_value(v, 63);
 }
 
-// norm2 (pvSimPCR.py:14-40) of both systems: ok = sum|A c - b| < TOL * sum|b|, one reduction each -- or none: where all
-// 32 lanes of a system agree on the sign of their term, that is the sign of its sum (wave_sum_negative, crosslane.hpp).
+// norm2 (pvSimPCR.py:14-40) of both systems: ok = sum|A c - b| < TOL * sum|b|, i.e. sum(|r| - TOL |b|) < 0, in two parts.
+//   residual_terms2: every lane's term q and the two lane votes (q < 0, q >= 0);
+//   residual_verdict2: where all 32 lanes of a system agree on the sign of their term, that is the sign of its sum
+//     (wave_sum_negative, crosslane.hpp); only otherwise the half-wave reduction.
+// The verdict is taken where it is first needed (the electrons': before the holes' test, i.e. after the electrons' solve
+// and the holes' assembly; the holes': at the end of the iteration), so that the iteration stays one basic block up to
+// there and the rare reduction sits in a side block.  With TRPL_NORM_VOTE_DEFER = 0 it follows the terms directly.
 // needA / needB: the systems whose verdict is used (a frozen or parked system's is not, and must not force a reduction).
+struct Terms2 {
+    double q;                                   // this lane's sum over its rows of |r| - TOL |b|
+    unsigned long long neg, nonneg;             // lanes with q < 0 / q >= 0 (a NaN is in neither)
+};
+__device__ __forceinline__ Terms2 no_terms2() { return {0.0, 0ull, ~0ull}; }      // "not below", decided without a reduction
+
 template <bool ISO>
-__device__ __forceinline__ void residual_below2(const double (&l)[NR], const double (&dg)[NR], const double (&u)[NR],
-                                                const double (&b)[NR], const double (&c)[NR], double TOL, int lane,
-                                                bool needA, bool needB, bool &okA, bool &okB, int *reductions = nullptr)
+__device__ __forceinline__ Terms2 residual_terms2(const double (&l)[NR], const double (&dg)[NR], const double (&u)[NR],
+                                                  const double (&b)[NR], const double (&c)[NR], double TOL, int lane)
 {
     double cm[NR], cp[NR];
     nbrB_dn<double, NR, 1>(c, cm, lane);
@@ -73,12 +83,22 @@ __device__ __forceinline__ void residual_below2(const double (&l)[NR], const dou
         const double qj = __builtin_fma(-TOL, fabs(b[j]), r);
         q = j == 0 ? qj : q + qj;
     }
+    Terms2 t = {q, 0ull, 0ull};
     if constexpr (TRPL_NORM_VOTE != 0) {
-        const unsigned long long neg = __builtin_amdgcn_ballot_w64(q < 0.0), nonneg = __builtin_amdgcn_ballot_w64(q >= 0.0);
+        t.neg = __builtin_amdgcn_ballot_w64(q < 0.0);
+        t.nonneg = __builtin_amdgcn_ballot_w64(q >= 0.0);
+    }
+    return t;
+}
+
+__device__ __forceinline__ void residual_verdict2(const Terms2 &t, bool needA, bool needB, bool &okA, bool &okB,
+                                                  int *reductions = nullptr)
+{
+    if constexpr (TRPL_NORM_VOTE != 0) {
         // the upper halves behind an empty asm: the optimiser would otherwise fold the `>> 32` test into a 64-bit unsigned
         // compare, which only the VALU has
-        const unsigned negA = (unsigned)neg, nnA = (unsigned)nonneg;
-        unsigned negB = (unsigned)(neg >> 32), nnB = (unsigned)(nonneg >> 32);
+        const unsigned negA = (unsigned)t.neg, nnA = (unsigned)t.nonneg;
+        unsigned negB = (unsigned)(t.neg >> 32), nnB = (unsigned)(t.nonneg >> 32);
         asm volatile("" : "+s"(negB), "+s"(nnB));
         const bool allnegA = negA == ~0u, allnegB = negB == ~0u;
         const bool decidedA = !needA || allnegA || nnA == ~0u, decidedB = !needB || allnegB || nnB == ~0u;
@@ -90,7 +110,7 @@ __device__ __forceinline__ void residual_below2(const double (&l)[NR], const dou
     }
     if (reductions) (*reductions)++;
     double sA, sB;
-    half_sums(q, sA, sB);
+    half_sums(t.q, sA, sB);
     okA = sA < 0.0;
     okB = sB < 0.0;
 }
@@ -312,27 +332,34 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
             double lo_[NR], dg[NR], up[NR], bb[NR], Ep[NR], x[NR];
             nbrB_up<double, NR, 1>(Ek, Ep, lane);   // a system's last lane reads the partner's E_0 = 0: E_L = 0
             bool okNA, okNB, okPA, okPB;
+            constexpr bool DEFER = TRPL_NORM_VOTE_DEFER != 0;
+            const bool needNA = FROZEN ? !doneA : true, needNB = FROZEN ? !doneB : true;
             // ---- electrons (:148-175) ----
             assemble<LAY, true, NR, WS, L, true>(mp, a0, Nk, Pk, Ek, Ep, bN, lo_, dg, up, bb, ln);
-            residual_below2<SEAM>(lo_, dg, up, bb, Nk, TOL, lane, FROZEN ? !doneA : true, FROZEN ? !doneB : true, okNA, okNB,
-                                  TRPL_STAT(nredN));                                                 // :172
+            const Terms2 tN = residual_terms2<SEAM>(lo_, dg, up, bb, Nk, TOL, lane);                // :172
+            if constexpr (!DEFER) residual_verdict2(tN, needNA, needNB, okNA, okNB, TRPL_STAT(nredN));
             cr_pcr_solve<double, NR, WS, SEAM, XM>(lo_, dg, up, bb, x, lane, xch);                      // :175
 #pragma unroll
             for (int j = 0; j < NR; j++) Nk[j] = act ? x[j] : Nk[j];
             // ---- holes, with the updated electrons (:178-202) ----
             assemble<LAY, false, NR, WS, L, true>(mp, a0, Nk, Pk, Ek, Ep, bP, lo_, dg, up, bb, ln);
+            if constexpr (DEFER) residual_verdict2(tN, needNA, needNB, okNA, okNB, TRPL_STAT(nredN));
             // the holes' norm only matters if the electrons' passed for a system that is still iterating (:213):
             // on the first iteration of a time step it practically never has (a wave-uniform branch)
-            if (FROZEN ? ((!doneA && okNA) || (!doneB && okNB)) : (okNA || okNB))
-                residual_below2<SEAM>(lo_, dg, up, bb, Pk, TOL, lane, FROZEN ? (!doneA && okNA) : okNA, FROZEN ? (!doneB && okNB) : okNB,
-                                      okPA, okPB, TRPL_STAT(nredP));                                // :200
-            else
+            const bool needPA = needNA && okNA, needPB = needNB && okNB;
+            Terms2 tP = no_terms2();
+            if (needPA || needPB) {
+                tP = residual_terms2<SEAM>(lo_, dg, up, bb, Pk, TOL, lane);                         // :200
+                if constexpr (!DEFER) residual_verdict2(tP, needPA, needPB, okPA, okPB, TRPL_STAT(nredP));
+            } else if constexpr (!DEFER) {
                 okPA = okPB = false;
+            }
             cr_pcr_solve<double, NR, WS, SEAM, XM>(lo_, dg, up, bb, x, lane, xch);                      // :202
 #pragma unroll
             for (int j = 0; j < NR; j++) Pk[j] = act ? x[j] : Pk[j];
             // ---- field on edges 1..L-1 (:205-209) ----
             update_field2<ISO>(mp, a0, Nk, Pk, bE, Ek, lane, act);
+            if constexpr (DEFER) residual_verdict2(tP, needPA, needPB, okPA, okPB, TRPL_STAT(nredP));
             if (!doneA && okNA && okPA) { doneA = true; itA = iters + 1; }                         // :213-216
             if (!doneB && okNB && okPB) { doneB = true; itB = iters + 1; }
         };
