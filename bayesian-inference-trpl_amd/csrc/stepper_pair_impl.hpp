@@ -381,17 +381,24 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
             // system ends the step flagged, put both back to U^t -- N and P from the ring slot written above, E from
             // hE[0] -- and repeat the step with them.  The repeat is the arithmetic of the always-voiding kernel, hence
             // so is every result; the common step pays nothing.
-            iterate_step(std::false_type{});
-            if ((!deadA && itA >= MAX) || (!deadB && itB >= MAX)) {
-                const int s4 = (int)(t & 3) * NR;
+            // A parked system (flagged earlier; the odd tail's duplicate) still executes the arithmetic on its lanes, with
+            // whatever its parameters are -- a NaN lifetime gives NaN coefficients at every step: beside one, the step runs
+            // with the selects from the start.
+            bool seam = deadA || deadB;
+            if (!seam) {
+                iterate_step(std::false_type{});
+                if (itA >= MAX || itB >= MAX) {
+                    const int s4 = (int)(t & 3) * NR;
 #pragma unroll
-                for (int j = 0; j < NR; j++) {
-                    const double2 h = hist2[(s4 + j) * 64 + lane];
-                    Nk[j] = h.x; Pk[j] = h.y; Ek[j] = hE[0][j];
+                    for (int j = 0; j < NR; j++) {
+                        const double2 h = hist2[(s4 + j) * 64 + lane];
+                        Nk[j] = h.x; Pk[j] = h.y; Ek[j] = hE[0][j];
+                    }
+                    doneA = deadA; doneB = deadB; itA = itB = MAX;
+                    seam = true;
                 }
-                doneA = deadA; doneB = deadB; itA = itB = MAX;
-                iterate_step(std::true_type{});
             }
+            if (seam) iterate_step(std::true_type{});
         } else {
             iterate_step(std::integral_constant<bool, ISO>{});
         }

@@ -350,11 +350,22 @@ def test_paired_kernel_repeated_steps_leave_the_partners_bits_alone(gpu):
     assert np.array_equal(a["iters_total"][:, 1:], b["iters_total"])
     assert np.array_equal(a["sse"][:, 1:], b["sse"])
     assert np.array_equal(pa[1:], pb)
-    # and without the cap: the partners of the three broken samples against a run that never had them
+    # and without the cap: the partners of the broken samples against a run that never had them.  A flagged system is
+    # parked, but its lanes go on computing with its parameters (a NaN lifetime: NaN coefficients at every step), so beside
+    # it the steps must run with the seam selects from the start -- not be repeated one by one after MAX iterations each:
+    # the launch with the broken samples may not take much longer than the clean one (600 steps; 10 000 iterations per
+    # repeated step would make it 100 x).
+    T2 = 600
+    obs2 = [np.full(T2 + 1, 20.0)] * 3
+    X[500, 0] = np.nan             # n0: even the parked state is not finite
+    X[900, 1] = np.inf             # p0
     clean = w.samples(S, seed=11)
     c, d = {}, {}
-    pc = gpu.loglik(clean, ini, lengths, Time, 128, T, obs, info=c)
-    pd = gpu.loglik(X, ini, lengths, Time, 128, T, obs, info=d)
-    ok = np.setdiff1d(np.arange(S), [40, 77, 301])
+    pc = gpu.loglik(clean, ini, lengths, T2 * 0.025, 128, T2, obs2, info=c)
+    pd = gpu.loglik(X, ini, lengths, T2 * 0.025, 128, T2, obs2, info=d)
+    broken = [40, 77, 301, 500, 900]
+    ok = np.setdiff1d(np.arange(S), broken)
     assert np.array_equal(pd[ok], pc[ok]) and np.array_equal(d["sse"][:, ok], c["sse"][:, ok])
     assert np.array_equal(d["iters_total"][:, ok], c["iters_total"][:, ok]) and not c["status"].any()
+    assert (d["status"][:, [40, 77, 500, 900]] > 0).all() and np.isfinite(pd[ok]).all()
+    assert d["seconds"] < 3.0 * c["seconds"] + 0.05, (d["seconds"], c["seconds"])
