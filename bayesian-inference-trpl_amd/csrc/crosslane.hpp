@@ -54,6 +54,10 @@
 #ifndef TRPL_NORM_VOTE_DEFER1
 #define TRPL_NORM_VOTE_DEFER1 0   // the same choice for the one-system steppers
 #endif
+#ifndef TRPL_PCR_BPERMUTE
+#define TRPL_PCR_BPERMUTE 0       // one-system fp64 steppers, PCR strides >= 2: 0 = staged through LDS (3 writes + 6 reads of 8 bytes
+                                  // per level), 1 = ds_bpermute (12 per level, a single LDS trip)
+#endif
 #ifndef TRPL_PAIRSTEP_ADD
 #define TRPL_PAIRSTEP_ADD 1       // final pair step of the CR + PCR solve: the coupling as A + C (one of them is an exact zero)
 #endif

@@ -435,6 +435,13 @@ __device__ __forceinline__ void pcr64_levels(T &A, T &D, T &C, T &Bv, int lane, 
             Bm = seam_first<ISO, WS>(lane_dn<1>(nB, lane), lane);
             Ap = seam_last<ISO, WS>(lane_up<1>(nA, lane), lane); Cp = seam_last<ISO, WS>(lane_up<1>(nC, lane), lane);
             Bp = seam_last<ISO, WS>(lane_up<1>(nB, lane), lane);
+        } else if constexpr (TRPL_PCR_BPERMUTE != 0 && sizeof(T) == 8) {
+            // one LDS trip instead of two (ds_bpermute: the crossbar alone; write + read staging: memory in between) for
+            // twice the DS instructions: the latency of a lone wave against the throughput of a full SIMD
+            const int dn = ISO ? (((lane - S) & (WS - 1)) | (lane & (64 - WS))) : ((lane - S) & 63);
+            const int up = ISO ? (((lane + S) & (WS - 1)) | (lane & (64 - WS))) : ((lane + S) & 63);
+            Am = __shfl(nA, dn, 64); Cm = __shfl(nC, dn, 64); Bm = __shfl(nB, dn, 64);
+            Ap = __shfl(nA, up, 64); Cp = __shfl(nC, up, 64); Bp = __shfl(nB, up, 64);
         } else {                                   // staged through LDS, one value per lane and array
             xch[0 * 64 + lane] = nA;
             xch[1 * 64 + lane] = nC;

@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
                   ln == 0 ? 1.0 : 0.0, ln == WS - 1 ? 1.0 : 0.0};
     mp_.fast_constants();
     mp_.boundary_constants();
-    const MatPar mp = mp_;
+    MatPar mp = mp_;                               // constant but for park(): a flagged system's lanes get benign parameters
     const double mag = a.xld > 12 ? xs[12] : 0.0;
     const double TOL = a.TOL;
     const int MAX = a.MAX;
@@ -219,16 +219,28 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
 #define TRPL_STAT(x) nullptr
 #endif
     SnapSink snap(a, cc);
-    // park this lane's system at equilibrium (finite, converges trivially): a flagged system for the rest of the run
+    // Park this lane's system for the rest of the run: a flagged system (or one found flagged in a checkpoint) is REPLACED
+    // by a benign one at its equilibrium -- unit densities, diffusivities and lifetimes, no recombination coefficients, no
+    // field coupling.  Its lanes go on executing every iteration (results discarded), and with the sample's own parameters
+    // (a NaN lifetime, an infinite rate) they would form non-finite coefficients at every later step, which the optimistic
+    // seam below must not meet; with these they form finite ones, converge trivially and cross the seam as finite values
+    // times exact zeros.
     auto park = [&](bool mine) {
+        if (mine) {
+            MatPar b_ = {1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 1.0, 0.0, 1.0,
+                         ln == 0 ? 1.0 : 0.0, ln == WS - 1 ? 1.0 : 0.0};
+            b_.fast_constants();
+            b_.boundary_constants();
+            mp = b_;
+        }
 #pragma unroll
         for (int j = 0; j < NR; j++) {
             if (mine) {
-                Nk[j] = N0; Pk[j] = P0; Ek[j] = 0.0;
+                Nk[j] = 1.0; Pk[j] = 1.0; Ek[j] = 0.0;
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
                     hE[m][j] = 0.0;
-                    hist2[(m * NR + j) * 64 + lane] = make_double2(N0, P0);
+                    hist2[(m * NR + j) * 64 + lane] = make_double2(1.0, 1.0);
                 }
             }
         }
@@ -381,24 +393,19 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
             // system ends the step flagged, put both back to U^t -- N and P from the ring slot written above, E from
             // hE[0] -- and repeat the step with them.  The repeat is the arithmetic of the always-voiding kernel, hence
             // so is every result; the common step pays nothing.
-            // A parked system (flagged earlier; the odd tail's duplicate) still executes the arithmetic on its lanes, with
-            // whatever its parameters are -- a NaN lifetime gives NaN coefficients at every step: beside one, the step runs
-            // with the selects from the start.
-            bool seam = deadA || deadB;
-            if (!seam) {
-                iterate_step(std::false_type{});
-                if (itA >= MAX || itB >= MAX) {
-                    const int s4 = (int)(t & 3) * NR;
+            // A parked system (flagged earlier) is a benign finite one (park()), the odd tail's duplicate a copy of its
+            // partner: neither can put a non-finite value on the seam.
+            iterate_step(std::false_type{});
+            if ((!deadA && itA >= MAX) || (!deadB && itB >= MAX)) {
+                const int s4 = (int)(t & 3) * NR;
 #pragma unroll
-                    for (int j = 0; j < NR; j++) {
-                        const double2 h = hist2[(s4 + j) * 64 + lane];
-                        Nk[j] = h.x; Pk[j] = h.y; Ek[j] = hE[0][j];
-                    }
-                    doneA = deadA; doneB = deadB; itA = itB = MAX;
-                    seam = true;
+                for (int j = 0; j < NR; j++) {
+                    const double2 h = hist2[(s4 + j) * 64 + lane];
+                    Nk[j] = h.x; Pk[j] = h.y; Ek[j] = hE[0][j];
                 }
+                doneA = deadA; doneB = deadB; itA = itB = MAX;
+                iterate_step(std::true_type{});
             }
-            if (seam) iterate_step(std::true_type{});
         } else {
             iterate_step(std::integral_constant<bool, ISO>{});
         }
