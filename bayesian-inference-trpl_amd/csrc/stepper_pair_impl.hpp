@@ -8,10 +8,13 @@
 // measured +29 % node throughput for this shape (the L = 256 kernel), at 2 waves per SIMD.
 //
 // The two systems are numerically independent: every value that crosses the seam between lanes 31 | 32
-// (or wraps 63 | 0) is multiplied by a coefficient that is exactly zero (first-row sub-diagonal,
-// last-row super-diagonal and their PCR/CR descendants), and with ISO = true it is replaced by 0
-// first, so not even a NaN/Inf of one system can reach the other.  Each system is computed by the
-// same instruction sequence whichever half it sits in: results do not depend on the pairing.
+// (or wraps 63 | 0) inside an iteration is multiplied by a coefficient that is exactly zero (first-row
+// sub-diagonal, last-row super-diagonal and their PCR/CR descendants), and the one that is not (edge 0 of the
+// field update) is always replaced by 0.  A NaN / Inf would still cross (0 * NaN): the SEAM flavour of the
+// iteration clears every crossing value first; the kernel runs the flavour without those selects and repeats a
+// time step in the SEAM flavour when a system is flagged in it ("optimistic seam", see the time loop) -- the
+// results are those of a kernel that always clears.  Each system is computed by the same instruction sequence
+// whichever half it sits in: results do not depend on the pairing.
 //
 // WHICH two systems share a wavefront does not change their bits (tested), only how many iterations the wave runs:
 // each time step costs max(itA, itB).  Default pairing: the two curves of ONE sample that the host table names
@@ -22,7 +25,7 @@
 //
 // Convergence is per system (pvSimPCR.py:213-216): a system that has converged in this time step is
 // frozen (its lanes keep their state) while its partner iterates on; a system that hits MAX is
-// flagged (:269) and parked in its equilibrium state for the rest of the run.
+// flagged (:269) and parked -- replaced by a benign system at its equilibrium (see park()) -- for the rest of the run.
 // Reference for the arithmetic: see stepper_impl.hpp (assemble / PlSink are shared with it).
 #pragma once
 #include "stepper_impl.hpp"
@@ -56,9 +59,9 @@ __device__ __forceinline__ void half_sums(double v, double &lo, double &hi)
 //   residual_terms2: every lane's term q and the two lane votes (q < 0, q >= 0);
 //   residual_verdict2: where all 32 lanes of a system agree on the sign of their term, that is the sign of its sum
 //     (wave_sum_negative, crosslane.hpp); only otherwise the half-wave reduction.
-// The verdict is taken where it is first needed (the electrons': before the holes' test, i.e. after the electrons' solve
-// and the holes' assembly; the holes': at the end of the iteration), so that the iteration stays one basic block up to
-// there and the rare reduction sits in a side block.  With TRPL_NORM_VOTE_DEFER = 0 it follows the terms directly.
+// The verdict follows the terms directly; taking it only where it is first needed (TRPL_NORM_VOTE_DEFER = 1: the electrons'
+// after their solve and the holes' assembly, the holes' at the end of the iteration, so that the iteration stays one basic
+// block up to there) was measured 0.3 % slower.
 // needA / needB: the systems whose verdict is used (a frozen or parked system's is not, and must not force a reduction).
 struct Terms2 {
     double q;                                   // this lane's sum over its rows of |r| - TOL |b|
@@ -389,7 +392,7 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
             // selects change no bit -- they only keep a NaN / Inf of one system out of the other (0 * NaN).  A system
             // that produces a non-finite value does not converge in that time step (its residual norm is NaN from then
             // on) and is flagged at the step's end; live systems are finite at every step boundary (a flagged one is
-            // parked at equilibrium).  So: iterate WITHOUT the selects (36 of the iteration's 46 v_cndmask), and if a
+            // parked as a benign one).  So: iterate WITHOUT the selects (33 of the iteration's 46 v_cndmask), and if a
             // system ends the step flagged, put both back to U^t -- N and P from the ring slot written above, E from
             // hE[0] -- and repeat the step with them.  The repeat is the arithmetic of the always-voiding kernel, hence
             // so is every result; the common step pays nothing.
