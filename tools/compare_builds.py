@@ -38,7 +38,7 @@ def child(a):
         lo = np.array([1e8, 1e12, 0.01, 0.01, 1e-13, 1e-3, 1e-3, 1e-32, 1e-32, 0.1, 0.1, 0.1, 0])
         hi = np.array([1e8, 1e18, 500, 500, 1e-8, 1e5, 1e5, 1e-26, 1e-26, 1e4, 1e4, 0.1, 0])
         lg = np.array([1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0])
-        X = sm.random_grid(lo * sm.UNIT_CONVERSIONS, hi * sm.UNIT_CONVERSIONS, lg, a.S, rng=np.random.RandomState(123))
+        X = sm.random_grid(lo * sm.UNIT_CONVERSIONS, hi * sm.UNIT_CONVERSIONS, lg, a.S, rng=np.random.RandomState(a.seed))
     if a.broken:                       # samples that are flagged: the repeated-step path of the paired kernel
         X[5, 9] = np.nan
         X[1000, 4] = np.inf
@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--MAX", type=int, default=0)
     ap.add_argument("--broken", action="store_true")
     ap.add_argument("--wide", action="store_true")
+    ap.add_argument("--seed", type=int, default=123, help="seed of the wide box's draw")
     ap.add_argument("--workload", default="power_scan", choices=["power_scan", "twothick"])
     ap.add_argument("--out", default=None, help=argparse.SUPPRESS)
     a = ap.parse_args()
@@ -75,11 +76,11 @@ def main():
             out = os.path.join(d, "b%d.npz" % i)
             env = dict(os.environ, TRPL_LIBRARY=os.path.abspath(lib), TRPL_AUTOBUILD="0")
             cmd = [sys.executable, os.path.abspath(__file__), "--out", out, "--S", str(a.S), "--T", str(a.T), "--L", str(a.L),
-                   "--tol", str(a.tol), "--MAX", str(a.MAX), "--workload", a.workload] + (["--broken"] if a.broken else []) + (["--wide"] if a.wide else [])
+                   "--tol", str(a.tol), "--MAX", str(a.MAX), "--workload", a.workload] + (["--broken"] if a.broken else []) + (["--wide", "--seed", str(a.seed)] if a.wide else [])
             subprocess.run(cmd, env=env, check=True)
             res.append(dict(np.load(out)))
     ref = res[0]
-    report = {"workload": a.workload, "S": a.S, "T": a.T, "L": a.L, "tol": a.tol, "MAX": a.MAX, "broken": a.broken, "wide_box": a.wide,
+    report = {"workload": a.workload, "S": a.S, "T": a.T, "L": a.L, "tol": a.tol, "MAX": a.MAX, "broken": a.broken, "wide_box": a.wide, "seed": a.seed if a.wide else None,
               "reference": os.path.basename(a.libs[0]), "arrays": sorted(ref.keys()),
               "flagged_systems": int((ref["status"] != 0).sum()) if "status" in ref else None, "builds": {}}
     ok = True
