@@ -12,9 +12,9 @@
 // sub-diagonal, last-row super-diagonal and their PCR/CR descendants), and the one that is not (edge 0 of the
 // field update) is always replaced by 0.  A NaN / Inf would still cross (0 * NaN): the SEAM flavour of the
 // iteration clears every crossing value first; the kernel runs the flavour without those selects and repeats a
-// time step in the SEAM flavour when a system is flagged in it ("optimistic seam", see the time loop) -- the
-// results are those of a kernel that always clears.  Each system is computed by the same instruction sequence
-// whichever half it sits in: results do not depend on the pairing.
+// time step in the SEAM flavour when a system is flagged in it or leaves it with a non-finite state ("optimistic
+// seam", see the time loop) -- the results are those of a kernel that always clears.  Each system is computed by the
+// same instruction sequence whichever half it sits in: results do not depend on the pairing.
 //
 // WHICH two systems share a wavefront does not change their bits (tested), only how many iterations the wave runs:
 // each time step costs max(itA, itB).  Default pairing: the two curves of ONE sample that the host table names
@@ -389,17 +389,25 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
         if constexpr (ISO && TRPL_PAIR_OPTIMISTIC != 0) {
             // OPTIMISTIC SEAM.  Everything that crosses the seam inside an iteration meets an exact-zero coefficient
             // (update_field2's edge 0 apart, which is always voided), so while both systems are finite the voiding
-            // selects change no bit -- they only keep a NaN / Inf of one system out of the other (0 * NaN).  A system
-            // that produces a non-finite value does not converge in that time step (its residual norm is NaN from then
-            // on) and is flagged at the step's end; live systems are finite at every step boundary (a flagged one is
-            // parked as a benign one).  So: iterate WITHOUT the selects (33 of the iteration's 46 v_cndmask), and if a
-            // system ends the step flagged, put both back to U^t -- N and P from the ring slot written above, E from
-            // hE[0] -- and repeat the step with them.  The repeat is the arithmetic of the always-voiding kernel, hence
-            // so is every result; the common step pays nothing.
-            // A parked system (flagged earlier) is a benign finite one (park()), the odd tail's duplicate a copy of its
-            // partner: neither can put a non-finite value on the seam.
-            iterate_step(std::false_type{});
-            if ((!deadA && itA >= MAX) || (!deadB && itB >= MAX)) {
+            // selects change no bit -- they only keep a NaN / Inf of one system out of the other (0 * NaN).  So: iterate
+            // WITHOUT the selects (33 of the iteration's 46 v_cndmask), look at the outcome, and if a non-finite value may
+            // have been on the seam put both systems back to U^t -- N and P from the ring slot written above, E from
+            // hE[0] -- and repeat the step WITH them.  The repeat is the arithmetic of the always-voiding kernel, hence so
+            // is every result; the common step pays nothing.  What can put a non-finite value on the seam: a live system
+            // whose state turns non-finite in this step -- it either never converges (flagged at the step's end) or passes
+            // an iteration's test and turns non-finite in that iteration's solve (its partner, polluted in the same
+            // solve, is then marked converged as well): both show below.  A parked system (flagged earlier) is a benign
+            // finite one (park()), the odd tail's duplicate a copy of its partner: neither can.
+            iterate_step(std::integral_constant<bool, TRPL_PAIR_OPTIMISTIC == 3>{});      // (3: debugging, first pass voids too)
+            // repeat the step if a live system is flagged in it -- or if a system's new state is not finite: the test of an
+            // iteration precedes its solve, so a system can pass it and turn non-finite in that same, last iteration
+            // (it is then flagged in the NEXT step), and its partner, polluted in that solve, is marked converged too.
+            // The witness costs one compare: the field update forms the reciprocals of a lane's four A_j (each holding that
+            // row's N and P, times Lambda D -- a zero factor keeps a NaN) from ONE v_rcp_f64 of their product (rcp_rows), so a
+            // non-finite N or P anywhere in the lane makes every new E of the lane non-finite, the last row's included.
+            const double wit = TRPL_RCP_QUAD != 0 ? Ek[NR - 1] : (Ek[0] + Ek[1]) + (Ek[2] + Ek[3]);
+            const bool finite2 = __builtin_amdgcn_ballot_w64(__builtin_isfinite(wit)) == ~0ull;
+            if (TRPL_PAIR_OPTIMISTIC == 2 || (!deadA && itA >= MAX) || (!deadB && itB >= MAX) || !finite2) {      // (2: debugging, always repeat)
                 const int s4 = (int)(t & 3) * NR;
 #pragma unroll
                 for (int j = 0; j < NR; j++) {

@@ -369,3 +369,33 @@ def test_paired_kernel_repeated_steps_leave_the_partners_bits_alone(gpu):
     assert np.array_equal(d["iters_total"][:, ok], c["iters_total"][:, ok]) and not c["status"].any()
     assert (d["status"][:, [40, 77, 500, 900]] > 0).all() and np.isfinite(pd[ok]).all()
     assert d["seconds"] < 3.0 * c["seconds"] + 0.05, (d["seconds"], c["seconds"])
+
+
+def test_paired_kernel_partner_that_turns_nonfinite_in_its_last_iteration(gpu):
+    """The hole a first form of the optimistic seam had (found by tools/compare_builds.py --extreme): an iteration's
+    convergence test precedes its solve, so a system can pass the test and turn non-finite in that same solve -- it is
+    flagged only in the NEXT step, and without the seam selects its partner, polluted in the same solve, was marked
+    converged with a NaN state.  The kernel now also repeats a step whose new state is not finite.  This sample (hostile:
+    back-surface velocity 1e300, hole diffusivity 3e14) does exactly that on the strongest 2000 nm curve of Twothick at
+    step 12 -> 13; its weaker curves live on.  They must come out as they do beside any other partner, bit for bit."""
+    w = gpu.workloads
+    x = np.array([[8.34540522577893e-05, 1.2115714113097759e-22, 8.558192569710279, 340469303561722.0, 350.2753963083046,
+                   1.4435043418920274e-21, 1e+300, 1.425211096921706e-15, 28227.298775403244, 0.0015061769014185513,
+                   35.96906672432525, 1.9644484713841463e-14, 0.0]])
+    ini, lens = w.twothick(128)
+    T = 40
+    obs = [np.full(T + 1, 18.0)]
+    runs = {}
+    for name, curves in (("3+5", [3, 5]), ("3+1", [3, 1]), ("1+5", [1, 5])):
+        info = {}
+        gpu.loglik(x, ini[curves], lens[curves], T * 0.025, 128, T, obs * 2, info=info, MAX=1000, kernel="pair")
+        runs[name] = info
+    a, b, c = runs["3+5"], runs["3+1"], runs["1+5"]
+    assert a["status"][1, 0] == 14 and c["status"][1, 0] == 14            # curve 5 is flagged in step 13, whoever is beside it
+    assert a["iters_total"][1, 0] == c["iters_total"][1, 0] == 1016
+    assert a["status"][0, 0] == 0 and b["status"][0, 0] == 0 and b["status"][1, 0] == 0 and c["status"][0, 0] == 0
+    # curve 3 beside curve 5 (which turns non-finite) = curve 3 beside curve 1 (which does not); curve 1 likewise
+    for k in ("sse", "iters_total", "floor_col"):
+        assert a[k][0, 0].tobytes() == b[k][0, 0].tobytes(), k
+        assert b[k][1, 0].tobytes() == c[k][0, 0].tobytes(), k
+    assert a["iters_total"][0, 0] == T + 4                                 # one iteration per step after the first

@@ -39,6 +39,14 @@ def child(a):
         hi = np.array([1e8, 1e18, 500, 500, 1e-8, 1e5, 1e5, 1e-26, 1e-26, 1e4, 1e4, 0.1, 0])
         lg = np.array([1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0])
         X = sm.random_grid(lo * sm.UNIT_CONVERSIONS, hi * sm.UNIT_CONVERSIONS, lg, a.S, rng=np.random.RandomState(a.seed))
+    if a.extreme:                      # hostile inputs: every parameter log-uniform over 40 decades around its box, with zeros,
+        rng = np.random.RandomState(a.seed)       # negative values, infinities and NaNs sprinkled in (one sample in eight)
+        X = w.samples(a.S, seed=7)
+        mag = 10.0 ** rng.uniform(-20, 20, size=(a.S, 12))
+        X[:, :12] *= mag
+        special = np.array([0.0, -1.0, np.inf, -np.inf, np.nan, 1e-310, 1e300, -1e-300])
+        rows = rng.choice(a.S, size=a.S // 8, replace=False)
+        X[rows, rng.randint(0, 12, size=rows.size)] = special[rng.randint(0, special.size, size=rows.size)]
     if a.broken:                       # samples that are flagged: the repeated-step path of the paired kernel
         X[5, 9] = np.nan
         X[1000, 4] = np.inf
@@ -52,6 +60,8 @@ def child(a):
         kw["MAX"] = a.MAX
     P = trpl_amd.loglik(X, ini, lens, Time, L, T, obs, tol=a.tol, info=info, **kw)
     np.savez(a.out, P=P, **{k: np.asarray(v) for k, v in info.items() if isinstance(v, np.ndarray)})
+    if os.environ.get('TRPL_DUMP_X'):
+        np.save(os.environ['TRPL_DUMP_X'], X)
 
 
 def main():
@@ -64,6 +74,7 @@ def main():
     ap.add_argument("--MAX", type=int, default=0)
     ap.add_argument("--broken", action="store_true")
     ap.add_argument("--wide", action="store_true")
+    ap.add_argument("--extreme", action="store_true")
     ap.add_argument("--seed", type=int, default=123, help="seed of the wide box's draw")
     ap.add_argument("--workload", default="power_scan", choices=["power_scan", "twothick"])
     ap.add_argument("--out", default=None, help=argparse.SUPPRESS)
@@ -76,11 +87,11 @@ def main():
             out = os.path.join(d, "b%d.npz" % i)
             env = dict(os.environ, TRPL_LIBRARY=os.path.abspath(lib), TRPL_AUTOBUILD="0")
             cmd = [sys.executable, os.path.abspath(__file__), "--out", out, "--S", str(a.S), "--T", str(a.T), "--L", str(a.L),
-                   "--tol", str(a.tol), "--MAX", str(a.MAX), "--workload", a.workload] + (["--broken"] if a.broken else []) + (["--wide", "--seed", str(a.seed)] if a.wide else [])
+                   "--tol", str(a.tol), "--MAX", str(a.MAX), "--workload", a.workload] + (["--broken"] if a.broken else []) + (["--wide", "--seed", str(a.seed)] if a.wide else []) + (["--extreme", "--seed", str(a.seed)] if a.extreme else [])
             subprocess.run(cmd, env=env, check=True)
             res.append(dict(np.load(out)))
     ref = res[0]
-    report = {"workload": a.workload, "S": a.S, "T": a.T, "L": a.L, "tol": a.tol, "MAX": a.MAX, "broken": a.broken, "wide_box": a.wide, "seed": a.seed if a.wide else None,
+    report = {"workload": a.workload, "S": a.S, "T": a.T, "L": a.L, "tol": a.tol, "MAX": a.MAX, "broken": a.broken, "wide_box": a.wide, "extreme_inputs": a.extreme, "seed": a.seed if (a.wide or a.extreme) else None,
               "reference": os.path.basename(a.libs[0]), "arrays": sorted(ref.keys()),
               "flagged_systems": int((ref["status"] != 0).sum()) if "status" in ref else None, "builds": {}}
     ok = True
