@@ -405,7 +405,13 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
             // The witness costs one compare: the field update forms the reciprocals of a lane's four A_j (each holding that
             // row's N and P, times Lambda D -- a zero factor keeps a NaN) from ONE v_rcp_f64 of their product (rcp_rows), so a
             // non-finite N or P anywhere in the lane makes every new E of the lane non-finite, the last row's included.
+#if TRPL_WITNESS_P
+            // (measured alternative: the holes' solve is the only one whose pollution no later test of the same step sees --
+            // the electrons' shows in the holes' test -- so its four results would do, and are ready before the field update)
+            const double wit = (Pk[0] + Pk[1]) + (Pk[2] + Pk[3]);
+#else
             const double wit = TRPL_RCP_QUAD != 0 ? Ek[NR - 1] : (Ek[0] + Ek[1]) + (Ek[2] + Ek[3]);
+#endif
             const bool finite2 = __builtin_amdgcn_ballot_w64(__builtin_isfinite(wit)) == ~0ull;
             if (TRPL_PAIR_OPTIMISTIC == 2 || (!deadA && itA >= MAX) || (!deadB && itB >= MAX) || !finite2) {      // (2: debugging, always repeat)
                 const int s4 = (int)(t & 3) * NR;
