@@ -58,6 +58,8 @@ def child(a):
     kw = {}
     if a.MAX:
         kw["MAX"] = a.MAX
+    if a.kernel:
+        kw["kernel"] = a.kernel
     P = trpl_amd.loglik(X, ini, lens, Time, L, T, obs, tol=a.tol, info=info, **kw)
     np.savez(a.out, P=P, **{k: np.asarray(v) for k, v in info.items() if isinstance(v, np.ndarray)})
     if os.environ.get('TRPL_DUMP_X'):
@@ -75,6 +77,7 @@ def main():
     ap.add_argument("--broken", action="store_true")
     ap.add_argument("--wide", action="store_true")
     ap.add_argument("--extreme", action="store_true")
+    ap.add_argument("--kernel", default=None, choices=["pair", "single"], help="force the L = 128 FAST stepper")
     ap.add_argument("--seed", type=int, default=123, help="seed of the wide box's draw")
     ap.add_argument("--workload", default="power_scan", choices=["power_scan", "twothick"])
     ap.add_argument("--out", default=None, help=argparse.SUPPRESS)
@@ -87,11 +90,11 @@ def main():
             out = os.path.join(d, "b%d.npz" % i)
             env = dict(os.environ, TRPL_LIBRARY=os.path.abspath(lib), TRPL_AUTOBUILD="0")
             cmd = [sys.executable, os.path.abspath(__file__), "--out", out, "--S", str(a.S), "--T", str(a.T), "--L", str(a.L),
-                   "--tol", str(a.tol), "--MAX", str(a.MAX), "--workload", a.workload] + (["--broken"] if a.broken else []) + (["--wide", "--seed", str(a.seed)] if a.wide else []) + (["--extreme", "--seed", str(a.seed)] if a.extreme else [])
+                   "--tol", str(a.tol), "--MAX", str(a.MAX), "--workload", a.workload] + (["--broken"] if a.broken else []) + (["--wide", "--seed", str(a.seed)] if a.wide else []) + (["--extreme", "--seed", str(a.seed)] if a.extreme else []) + (["--kernel", a.kernel] if a.kernel else [])
             subprocess.run(cmd, env=env, check=True)
             res.append(dict(np.load(out)))
     ref = res[0]
-    report = {"workload": a.workload, "S": a.S, "T": a.T, "L": a.L, "tol": a.tol, "MAX": a.MAX, "broken": a.broken, "wide_box": a.wide, "extreme_inputs": a.extreme, "seed": a.seed if (a.wide or a.extreme) else None,
+    report = {"workload": a.workload, "S": a.S, "T": a.T, "L": a.L, "tol": a.tol, "MAX": a.MAX, "broken": a.broken, "wide_box": a.wide, "extreme_inputs": a.extreme, "kernel": a.kernel, "seed": a.seed if (a.wide or a.extreme) else None,
               "reference": os.path.basename(a.libs[0]), "arrays": sorted(ref.keys()),
               "flagged_systems": int((ref["status"] != 0).sum()) if "status" in ref else None, "builds": {}}
     ok = True
