@@ -61,6 +61,9 @@
 #ifndef TRPL_PAIRSTEP_ADD
 #define TRPL_PAIRSTEP_ADD 1       // final pair step of the CR + PCR solve: the coupling as A + C (one of them is an exact zero)
 #endif
+#ifndef TRPL_PAIR_WITNESS
+#define TRPL_PAIR_WITNESS 1       // optimistic seam: 0 drops the finiteness witness (the first, flawed form; to show that the tests see it)
+#endif
 #ifndef TRPL_WITNESS_P
 #define TRPL_WITNESS_P 0          // optimistic seam's finiteness witness: 0 = the last row's new field, 1 = the sum of the lane's new P
 #endif

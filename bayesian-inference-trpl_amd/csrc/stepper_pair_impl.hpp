@@ -143,7 +143,9 @@ __device__ __forceinline__ void update_field2(const MatPar &m, double a0, const 
     for (int j = 1; j < NR; j++) Ek[j] = act ? b[j] * rA[j] : Ek[j];
 }
 
-template <bool ISO, int XM, bool SNAP = false>
+// OPT: the optimistic seam (see the time loop); false = the selects in every iteration, the form rounds 1-3 shipped.  Both
+// are in the library: the second as the reference of the differential tests (TRPL_PAIR_ALWAYS_SEAM=1 selects it per process).
+template <bool ISO, int XM, bool SNAP = false, bool OPT = (TRPL_PAIR_OPTIMISTIC != 0)>
 __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
 {
     constexpr int LAY = 2;
@@ -386,7 +388,7 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
             for (; iters < MAX && !(doneA || doneB); iters++) iterate_once(std::false_type{}, seam_c, iters);
             for (; iters < MAX && !(doneA && doneB); iters++) iterate_once(std::true_type{}, seam_c, iters);
         };
-        if constexpr (ISO && TRPL_PAIR_OPTIMISTIC != 0) {
+        if constexpr (ISO && OPT) {
             // OPTIMISTIC SEAM.  Everything that crosses the seam inside an iteration meets an exact-zero coefficient
             // (update_field2's edge 0 apart, which is always voided), so while both systems are finite the voiding
             // selects change no bit -- they only keep a NaN / Inf of one system out of the other (0 * NaN).  So: iterate
@@ -412,7 +414,7 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
 #else
             const double wit = TRPL_RCP_QUAD != 0 ? Ek[NR - 1] : (Ek[0] + Ek[1]) + (Ek[2] + Ek[3]);
 #endif
-            const bool finite2 = __builtin_amdgcn_ballot_w64(__builtin_isfinite(wit)) == ~0ull;
+            const bool finite2 = TRPL_PAIR_WITNESS == 0 || __builtin_amdgcn_ballot_w64(__builtin_isfinite(wit)) == ~0ull;
             if (TRPL_PAIR_OPTIMISTIC == 2 || (!deadA && itA >= MAX) || (!deadB && itB >= MAX) || !finite2) {      // (2: debugging, always repeat)
                 const int s4 = (int)(t & 3) * NR;
 #pragma unroll
@@ -472,8 +474,17 @@ hipError_t launch_stepper_pair_t(const StepArgs &a, hipStream_t stream)
     if (a.L != pair::L) return hipErrorInvalidValue;
     const int64_t nblk = ((a.S + 1) / 2) * a.C;      // with and without a pairing table
     if (nblk <= 0) return hipSuccess;
-    if (a.n_snap > 0 || a.resN != nullptr) hipLaunchKernelGGL((pair::stepper_pair_kernel<ISO, XM, true>), dim3((unsigned)nblk), dim3(64), 0, stream, a);
-    else              hipLaunchKernelGGL((pair::stepper_pair_kernel<ISO, XM, false>), dim3((unsigned)nblk), dim3(64), 0, stream, a);
+    // measurement / test switch, read once per process: the always-isolating kernel instead of the optimistic one
+    static const bool always_seam = getenv("TRPL_PAIR_ALWAYS_SEAM") && atoi(getenv("TRPL_PAIR_ALWAYS_SEAM")) != 0;
+    const bool snap = a.n_snap > 0 || a.resN != nullptr;
+    const dim3 grid((unsigned)nblk), block(64);
+    if (always_seam) {
+        if (snap) hipLaunchKernelGGL((pair::stepper_pair_kernel<ISO, XM, true, false>), grid, block, 0, stream, a);
+        else      hipLaunchKernelGGL((pair::stepper_pair_kernel<ISO, XM, false, false>), grid, block, 0, stream, a);
+    } else {
+        if (snap) hipLaunchKernelGGL((pair::stepper_pair_kernel<ISO, XM, true>), grid, block, 0, stream, a);
+        else      hipLaunchKernelGGL((pair::stepper_pair_kernel<ISO, XM, false>), grid, block, 0, stream, a);
+    }
     return hipGetLastError();
 }
 

@@ -399,3 +399,44 @@ def test_paired_kernel_partner_that_turns_nonfinite_in_its_last_iteration(gpu):
         assert a[k][0, 0].tobytes() == b[k][0, 0].tobytes(), k
         assert b[k][1, 0].tobytes() == c[k][0, 0].tobytes(), k
     assert a["iters_total"][0, 0] == T + 4                                 # one iteration per step after the first
+
+
+@pytest.mark.parametrize("workload,seed", [("twothick", 12), ("power_scan", 31), ("twothick", 32)])
+def test_optimistic_seam_equals_the_always_isolating_kernel_on_hostile_inputs(gpu, tmp_path, workload, seed):
+    """Differential test of the paired kernel's optimistic seam against its always-isolating form -- both are in the
+    library, TRPL_PAIR_ALWAYS_SEAM=1 selects the second per process (two child processes).  Inputs that are meant to break
+    things (tools/compare_builds.py --extreme): every parameter of the box spread over 40 decades, one sample in eight
+    with a zero, a negative value, an infinity, a NaN, 1e300 or a denormal in one column; a small iteration cap.  Tens of
+    thousands of systems are flagged at every step of the window, beside partners that are not.  Every output array must
+    be the same bits.  (Seed 12 of Twothick holds the sample by which the first form of the optimistic seam differed.)"""
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np\n"
+            "sys.path.insert(0, %r)\n"
+            "import trpl_amd\n"
+            "w = trpl_amd.workloads\n"
+            "workload, seed, S, T = sys.argv[2], int(sys.argv[3]), 12001, 120\n"
+            "ini, lens = w.twothick(128) if workload == 'twothick' else w.power_scan(128)\n"
+            "rng = np.random.RandomState(seed)\n"
+            "X = w.samples(20001, seed=7)\n"                      # the generator of tools/compare_builds.py --extreme, its first S rows
+            "X[:, :12] *= 10.0 ** rng.uniform(-20, 20, size=(20001, 12))\n"
+            "special = np.array([0.0, -1.0, np.inf, -np.inf, np.nan, 1e-310, 1e300, -1e-300])\n"
+            "rows = rng.choice(20001, size=20001 // 8, replace=False)\n"
+            "X[rows, rng.randint(0, 12, size=rows.size)] = special[rng.randint(0, special.size, size=rows.size)]\n"
+            "X = np.ascontiguousarray(X[:S]) if seed != 12 else np.ascontiguousarray(X[6000:6000 + S])\n"     # seed 12: rows around sample 6598
+            "obs = [np.full(T + 1, 18.0)] * len(lens)\n"
+            "info = {}\n"
+            "P = trpl_amd.loglik(X, ini, lens, T * 0.025, 128, T, obs, info=info, MAX=1000, kernel='pair')\n"
+            "np.savez(sys.argv[1], P=P, sse=info['sse'], it=info['iters_total'], st=info['status'], fc=info['floor_col'])\n") % ROOT
+    out = {}
+    for v in ("0", "1"):
+        path = str(tmp_path / ("seam%s.npz" % v))
+        env = dict(os.environ, TRPL_PAIR_ALWAYS_SEAM=v, TRPL_AUTOBUILD="0")
+        r = subprocess.run([sys.executable, "-c", code, path, workload, str(seed)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[v] = np.load(path)
+    flagged = int((out["1"]["st"] != 0).sum())
+    assert flagged > 1000 and flagged < out["1"]["st"].size, flagged
+    for k in ("P", "sse", "it", "st", "fc"):
+        assert out["0"][k].tobytes() == out["1"][k].tobytes(), k
+    record("optimistic_vs_always_seam_%s_%d" % (workload, seed), {"systems": int(out["1"]["st"].size), "flagged": flagged})
