@@ -40,8 +40,10 @@
 #define TRPL_PCR_SETPRIO 2        // s_setprio level inside the cross-lane PCR levels (0 = off)
 #endif
 #ifndef TRPL_PAIR_OPTIMISTIC
-#define TRPL_PAIR_OPTIMISTIC 1    // paired kernel: iterate without the seam selects, repeat a time step with them when a
-                                  // system is flagged in it (stepper_pair_impl.hpp); 0 = the selects in every iteration
+#define TRPL_PAIR_OPTIMISTIC 1    // paired kernel: iterate without the seam selects, repeat a time step with them when a system is
+                                  // flagged in it or leaves it non-finite (stepper_pair_impl.hpp); 0 = the selects in every iteration
+                                  // (that form is in the library anyway: TRPL_PAIR_ALWAYS_SEAM=1); debugging: 2 = repeat every
+                                  // step, 3 = the first pass clears too
 #endif
 #ifndef TRPL_NORM_VOTE
 #define TRPL_NORM_VOTE 1          // FAST residual tests: the sign of sum(|r| - TOL |b|) from a lane vote where all lanes agree
