@@ -253,7 +253,9 @@ def main():
     variant = trpl_amd._abi.lib().trpl_kernel_variant(S_total * C, L, T, flags)
     if variant == trpl_amd._abi.KERNEL_FAST_PAIR:
         kernel_name = "pair::stepper_pair_kernel (2 x L=128 systems per wavefront; fused time-stepper + likelihood)"
-        rocprof_name = "void trpl::pair::stepper_pair_kernel<true, 1, false>"
+        # <ISO, XM, SNAP, OPT>: the optimistic-seam instantiation unless TRPL_PAIR_ALWAYS_SEAM=1 selects the other one
+        rocprof_name = "void trpl::pair::stepper_pair_kernel<true, 1, false, %s>" % (
+            "false" if os.environ.get("TRPL_PAIR_ALWAYS_SEAM", "0") not in ("", "0") else "true")
     else:
         kernel_name = "%sstepper_kernel<%d%s> (fused time-stepper + likelihood)" % ("f32::" if args.fp32 else "", L,
                                                                                    ", mixed" if args.mixed else "")
