@@ -63,6 +63,9 @@
 #ifndef TRPL_PAIRSTEP_ADD
 #define TRPL_PAIRSTEP_ADD 1       // final pair step of the CR + PCR solve: the coupling as A + C (one of them is an exact zero)
 #endif
+#ifndef TRPL_VOTE_FASTPATH
+#define TRPL_VOTE_FASTPATH 1      // paired kernel's verdict: whole-wave outcomes tested first (one 64-bit scalar compare each): +0.2 %
+#endif
 #ifndef TRPL_PAIR_WITNESS
 #define TRPL_PAIR_WITNESS 1       // optimistic seam: 0 drops the finiteness witness (the first, flawed form; to show that the tests see it)
 #endif

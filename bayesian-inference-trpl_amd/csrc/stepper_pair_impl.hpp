@@ -98,6 +98,12 @@ __device__ __forceinline__ void residual_verdict2(const Terms2 &t, bool needA, b
                                                   int *reductions = nullptr)
 {
     if constexpr (TRPL_NORM_VOTE != 0) {
+#if TRPL_VOTE_FASTPATH
+        // the two common outcomes with one 64-bit scalar compare each: every lane of the wave >= 0 (the first iteration
+        // of a time step: both systems far from converged) / every lane < 0 (its last one)
+        if (t.nonneg == ~0ull) { okA = okB = false; return; }
+        if (t.neg == ~0ull) { okA = okB = true; return; }
+#endif
         // the upper halves behind an empty asm: the optimiser would otherwise fold the `>> 32` test into a 64-bit unsigned
         // compare, which only the VALU has
         const unsigned negA = (unsigned)t.neg, nnA = (unsigned)t.nonneg;
