@@ -18,6 +18,17 @@ FLAG_STRICT, FLAG_PL_F32, FLAG_NORMALIZE, FLAG_FP32 = 0x1, 0x2, 0x4, 0x8
 FLAG_KERNEL_PAIR, FLAG_KERNEL_SINGLE, FLAG_MIXED, FLAG_SNAP_RAW = 0x10, 0x20, 0x40, 0x80
 FLAG_FP32_LONG, FP32_MAX_STEPS = 0x1000, 256
 FLAG_HIST32 = 0x2000
+FLAG_PAIR_ALWAYS_SEAM, FLAG_PAIR_ADJACENT, FLAG_MULTI_FORCE_PAD = 0x20000, 0x40000, 0x80000   # tests / measurements
+MULTI_ALLOW_DUPLICATE_DEVICES = 0x1     # trpl_multi_create_ex
+
+
+def flag_bdf_order(k):
+    """TRPL_FLAG_BDF_ORDER(k): cap the BDF order ramp of pvSimPCR.py:241-250 at k = 1 .. 5 (None / 0: the reference's
+    ramp); 2 is the scheme of Legacy/pvSim.py:94-97."""
+    k = 0 if k is None else int(k)
+    if not 0 <= k <= 5:
+        raise ValueError("bdf_order must be None or 1 .. 5")
+    return (k & 0x7) << 14
 
 
 def fp32_flags(fp32):
@@ -30,6 +41,7 @@ MAX_BUNDLE = 16                 # the flag's range; the library accepts bundle_c
 PL_FLOOR_EXCESS = 1e-4          # TRPL_PL_FLOOR_EXCESS
 PL_ENVELOPE_K_THICK = 5e-13     # TRPL_PL_ENVELOPE_K_THICK: |dPL / PL| <= 1e-9 + K / r on the 2000 nm films (L = 128)
 PL_ENVELOPE_K_THIN = 1e-11      # TRPL_PL_ENVELOPE_K_THIN: the same on the 311 nm films
+PL_ENVELOPE_K_L512 = 2e-12      # TRPL_PL_ENVELOPE_K_L512: the same on the 2000 nm film at L = 512
 
 
 def bundle_cap(L):
@@ -46,7 +58,7 @@ def flag_bundle(m, L=None):
     return ((int(m) - 1) & 0xF) << 8
 
 KERNEL_FAST, KERNEL_FAST_PAIR, KERNEL_STRICT, KERNEL_FP32, KERNEL_MIXED, KERNEL_HIST32 = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_SNAPS = 16
 
 
@@ -93,6 +105,7 @@ SIGNATURES = {
     "trpl_loglik_multi": [_vp, _i64, _i32, _vp, _f64, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64,
                           _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _i32, _pd],
     "trpl_multi_create": [_vp, _i32, _vp],
+    "trpl_multi_create_ex": [_vp, _i32, _u32, _vp],
     "trpl_multi_destroy": [_vp],
     "trpl_multi_device_count": [_vp],
     "trpl_multi_synchronize": [_vp],
@@ -103,6 +116,7 @@ SIGNATURES = {
     "trpl_shard_bounds": [_i64, _i32, _i32, _vp, _vp],
     "trpl_shard_of": [_i64, _i32, _i64],
     "trpl_kernel_variant": [_i64, _i32, _i64, _u32],
+    "trpl_kernel_name": [_i64, _i32, _i64, _u32, _i32, _vp, _i64],
     "trpl_sample_box": [_u32, _i64, _i32, _vp, _vp, _vp, _u32, _vp, _i32, _pd],
     "trpl_sample_box_dev": [_u32, _i64, _i32, _vp, _vp, _vp, _u32, _vp, _vp],
     "trpl_posterior_workspace_bytes": [_i32],
@@ -227,10 +241,15 @@ def lib():
         _share_torch_hip_runtime()
         dll = C.CDLL(LIB_PATH)
         dll.trpl_abi_version.restype = C.c_int
-        if dll.trpl_abi_version() != ABI_VERSION:
+        # A/B tools compare an older build under the current binding (tools/compare_builds.py, tools/ab_multi.sh with
+        # TRPL_LIBRARY=<old .so> TRPL_LIBRARY_ANY_ABI=1): entry points the old build lacks are then simply absent
+        any_abi = "TRPL_LIBRARY" in os.environ and os.environ.get("TRPL_LIBRARY_ANY_ABI") == "1"
+        if dll.trpl_abi_version() != ABI_VERSION and not any_abi:
             raise ImportError("%s has ABI version %d, this binding needs %d: rebuild it (`make -C %s`)"
                               % (LIB_PATH, dll.trpl_abi_version(), ABI_VERSION, _HERE))
         for name, argtypes in SIGNATURES.items():
+            if any_abi and not hasattr(dll, name):
+                continue
             fn = getattr(dll, name)
             fn.argtypes = argtypes
             fn.restype = C.c_char_p if name == "trpl_last_error" else (
@@ -252,6 +271,15 @@ def kernel_flag(kernel):
         return {"pair": FLAG_KERNEL_PAIR, "single": FLAG_KERNEL_SINGLE}[kernel]
     except KeyError:
         raise ValueError("kernel must be None, 'pair' or 'single', got %r" % (kernel,))
+
+
+def kernel_name(nsys, L, steps, flags=0, snapshots=False):
+    """trpl_kernel_name: the C++ name of the time-stepper kernel such a launch runs (what rocprofv3 lists after "void ")."""
+    if not hasattr(lib(), "trpl_kernel_name"):          # an older build under TRPL_LIBRARY_ANY_ABI
+        return "unknown"
+    buf = C.create_string_buffer(256)
+    check(lib().trpl_kernel_name(int(nsys), int(L), int(steps), int(flags), int(bool(snapshots)), C.addressof(buf), 256))
+    return buf.value.decode()
 
 
 def pin_variant(flags, nsys_total, L, steps):

@@ -61,13 +61,11 @@ struct DevBuf {                      // RAII device allocation for the host-buff
     template <typename T> T *as() { return (T *)p; }
 };
 
-// Thresholds (bytes) above which a host-buffer call pins the caller's memory for its duration; a negative
-// value switches the mechanism off.  Environment overrides exist for A/B measurements (tools/bench_dropin.py).
-inline long long host_threshold(const char *env, long long dflt)
-{
-    const char *v = getenv(env);
-    return v ? atoll(v) : dflt;
-}
+// Thresholds (bytes) above which a host-buffer call pins (HostPin) / maps (HostMap) the caller's memory for its duration.
+// Measured with environment overrides in round 2 (profiles/r2_dropin_simulate.txt); constants since round 5: the
+// library reads no process-wide switch but TRPL_RCCL_LIBRARY.
+constexpr long long kHostPinMinBytes = (long long)8 << 20;
+constexpr long long kHostDirectMinBytes = (long long)8 << 20;
 
 // The caller's (pageable) host buffer pinned for the duration of a call, so that copies to and from it are
 // real asynchronous DMA at PCIe rate instead of being staged through the runtime's bounce buffers.  Pinning
@@ -87,7 +85,7 @@ struct HostPin {
     }
     void pin(const void *ptr, size_t bytes, unsigned flags = hipHostRegisterDefault)
     {
-        static const long long min_bytes = host_threshold("TRPL_HOST_PIN_MIN", (long long)8 << 20);
+        constexpr long long min_bytes = kHostPinMinBytes;
         if (!ptr || min_bytes < 0 || bytes < (size_t)min_bytes || already_pinned(ptr)) return;
         if (hipHostRegister((void *)ptr, bytes, flags) == hipSuccess) { p = (void *)ptr; pinned = true; }
         else (void)hipGetLastError();            // clear the sticky error of a refused registration
@@ -102,7 +100,7 @@ struct HostMap {
     // device-visible alias of [ptr, ptr + bytes), or nullptr (too small, refused, switched off)
     void *map(void *ptr, size_t bytes)
     {
-        static const long long min_bytes = host_threshold("TRPL_HOST_DIRECT_MIN", (long long)8 << 20);
+        constexpr long long min_bytes = kHostDirectMinBytes;
         if (!ptr || min_bytes < 0 || bytes < (size_t)min_bytes) return nullptr;
         if (!HostPin::already_pinned(ptr)) {
             if (hipHostRegister(ptr, bytes, hipHostRegisterMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }

@@ -12,82 +12,35 @@
 
 #include "trpl_common.hpp"
 
-// Build-time choices, each the measured winner of a same-box A/B; the alternatives
-// compute the same results and stay selectable for re-measurement.
-#ifndef TRPL_FAST_WAVES
-#define TRPL_FAST_WAVES 3      // waves per SIMD the fast stepper is register-budgeted for
-#endif
-#ifndef TRPL_L512_WAVES
-#define TRPL_L512_WAVES 1      // waves per SIMD the L = 512 steppers are register-budgeted for (2: 256 registers, the rest spills to scratch)
-#endif
-#ifndef TRPL_H32_E_REGS
-#define TRPL_H32_E_REGS 0      // HIST32: the field's history in registers (1) or in LDS with N's and P's (0)
-#endif
-#ifndef TRPL_H32_FEEDBACK
-#define TRPL_H32_FEEDBACK 0    // HIST32: carry each stored difference's fp32 rounding residual into the next one (N and P)
-#endif
-#ifndef TRPL_CR_HYBRID
-#define TRPL_CR_HYBRID 1      // L = 128 fast solve: in-lane cyclic-reduction step + PCR on 64 unknowns
-#endif
-#ifndef TRPL_PARTNER_BPERMUTE
-#define TRPL_PARTNER_BPERMUTE 1   // lane^32 exchange: 0 = v_permlane32_swap (VALU), 1 = ds_bpermute (LDS; +1.9 % measured:
-                                  // the VALU is the saturated unit, the LDS has slack)
-#endif
-#ifndef TRPL_PCR_S1_LDS
-#define TRPL_PCR_S1_LDS 0         // stride-1 level of the 64-unknown PCR: 0 = DPP rotates, 1 = staged through LDS
-#endif
-#ifndef TRPL_PCR_SETPRIO
-#define TRPL_PCR_SETPRIO 2        // s_setprio level inside the cross-lane PCR levels (0 = off)
-#endif
+// Build-time switches that remain (round 5 removed those of rejected experiments -- TRPL_FAST_WAVES, TRPL_L512_WAVES,
+// TRPL_H32_*, TRPL_CR_HYBRID, TRPL_PARTNER_BPERMUTE, TRPL_PCR_S1_LDS, TRPL_PCR_SETPRIO, TRPL_NORM_VOTE_DEFER[1], TRPL_PCR_BPERMUTE,
+// TRPL_PAIRSTEP_ADD, TRPL_VOTE_FASTPATH, TRPL_WITNESS_P, TRPL_RCP_QUAD / _PAIR, TRPL_PAIR_XM, TRPL_PCRB_*: the measured winner of
+// each is now simply the code; the alternatives and their numbers are in git history and DESIGN_HISTORY.md section 8).
 #ifndef TRPL_PAIR_OPTIMISTIC
 #define TRPL_PAIR_OPTIMISTIC 1    // paired kernel: iterate without the seam selects, repeat a time step with them when a system is
                                   // flagged in it or leaves it non-finite (stepper_pair_impl.hpp); 0 = the selects in every iteration
-                                  // (that form is in the library anyway: TRPL_PAIR_ALWAYS_SEAM=1); debugging: 2 = repeat every
-                                  // step, 3 = the first pass clears too
+                                  // (that form is in the library anyway: TRPL_FLAG_PAIR_ALWAYS_SEAM)
 #endif
 #ifndef TRPL_NORM_VOTE
 #define TRPL_NORM_VOTE 1          // FAST residual tests: the sign of sum(|r| - TOL |b|) from a lane vote where all lanes agree
                                   // (no reduction); 0 = always reduce.  Same decisions either way.
 #endif
-#ifndef TRPL_NORM_VOTE_DEFER
-#define TRPL_NORM_VOTE_DEFER 0    // paired kernel: take a residual test's verdict where it is first used (1) or where its terms are
-                                  // formed (0).  Measured, same box: deferring costs 0.3 % (profiles/r4_ab_vote_defer.txt)
-#endif
-#ifndef TRPL_NORM_VOTE_DEFER1
-#define TRPL_NORM_VOTE_DEFER1 0   // the same choice for the one-system steppers
-#endif
-#ifndef TRPL_PCR_BPERMUTE
-#define TRPL_PCR_BPERMUTE 0       // one-system fp64 steppers, PCR strides >= 2: 0 = staged through LDS (3 writes + 6 reads of 8 bytes
-                                  // per level), 1 = ds_bpermute (12 per level, a single LDS trip)
-#endif
-#ifndef TRPL_PAIRSTEP_ADD
-#define TRPL_PAIRSTEP_ADD 1       // final pair step of the CR + PCR solve: the coupling as A + C (one of them is an exact zero)
-#endif
-#ifndef TRPL_VOTE_FASTPATH
-#define TRPL_VOTE_FASTPATH 1      // paired kernel's verdict: whole-wave outcomes tested first (one 64-bit scalar compare each): +0.2 %
-#endif
 #ifndef TRPL_PAIR_WITNESS
 #define TRPL_PAIR_WITNESS 1       // optimistic seam: 0 drops the finiteness witness (the first, flawed form; to show that the tests see it)
 #endif
-#ifndef TRPL_WITNESS_P
-#define TRPL_WITNESS_P 0          // optimistic seam's finiteness witness: 0 = the last row's new field, 1 = the sum of the lane's new P
+#if TRPL_PAIR_WITNESS == 0 && !defined(TRPL_DEBUG)
+#error "TRPL_PAIR_WITNESS=0 is the known-flawed form of the optimistic seam: it only builds with -DTRPL_DEBUG (to show that the differential tests catch it)"
 #endif
 #ifndef TRPL_VOTE_STATS
 #define TRPL_VOTE_STATS 0         // measurement build only: the paired kernel packs its count of residual reductions into iters_total
 #endif
-#ifndef TRPL_RCP_QUAD
-#define TRPL_RCP_QUAD 1       // four row reciprocals from one v_rcp_f64 (rcp_rows, NR % 4 == 0); measured, see DESIGN.md section 8
-#endif
-#ifndef TRPL_RCP_PAIR
-#define TRPL_RCP_PAIR 1       // pair reciprocals (rcp_rows); 0 only for A/B measurements
-#endif
 // Refinement of v_rcp_f64 (1: one Newton step, 2e-15 relative and always BELOW 1 / x; 2: two steps; 3: one third-order step,
 // ~1 ulp, unbiased; 0: the IEEE divide expansion), separately for the quotients of the tridiagonal solver (rcp_fast<double>:
 // CR and PCR levels, the final pairs) and for the pointwise reciprocals of the assembly and the field update (rcp_rows, the
-// surface term).  Round 4 (tools/build_variants.sh, tools/thinfilm_gap.py): in the solver the one-step
-// form's bias acts as a spurious sink proportional to the grid's stiffness D dt/dx^2 -- with 3 the paired kernel's distance
-// from the reference evaluation over 8000 steps drops from 1e-10 (median) / 7e-9 (max) to 3e-13 / 2e-11 on the 311 nm films
-// for 1.5 % of throughput (2 steps: the same accuracy for 3.5 %); in the pointwise reciprocals it changes nothing measurable.
+// surface term).  Round 4: in the solver the one-step form's bias acts as a spurious sink proportional to
+// the grid's stiffness D dt/dx^2 -- with 3 the paired kernel's distance from the reference evaluation over 8000 steps drops from
+// 1e-10 (median) / 7e-9 (max) to 3e-13 / 2e-11 on the 311 nm films for 1.5 % of throughput (2 steps: the same accuracy for
+// 3.5 %); in the pointwise reciprocals it changes nothing measurable.
 #ifndef TRPL_RCP_SOLVE_STEPS
 #define TRPL_RCP_SOLVE_STEPS 3
 #endif

@@ -1,9 +1,8 @@
 // Tridiagonal solvers by parallel cyclic reduction, one wavefront per system (reference:
-// pcreduce, pvSimPCR.py:42-81).  Three flavours:
+// pcreduce, pvSimPCR.py:42-81).  Three flavours (a fourth, pure PCR in the interleaved layout, lost to cr_pcr_solve in
+// round 1 and left the tree in round 5):
 //   pcr_solve       STRICT, blocked layout: the reference's operation order, IEEE divides, guards
 //   pcr_solve_fast  FAST, blocked layout (L < 128): normalised rows, Newton-refined reciprocals
-//   pcr_solve_L     FAST, interleaved layout (L >= 128): as above + exchange staged through LDS for
-//                   lane shifts >= 2, DPP for shifts <= 1, v_permlane32_swap + Cramer for the final pairs
 //   cr_pcr_solve    FAST, L >= 128, fp64 or fp32: log2(NR) in-lane cyclic-reduction levels, then PCR on
 //                   64 unknowns (one row per lane), back-substitution -- the production path
 #pragma once
@@ -206,7 +205,7 @@ __device__ __forceinline__ double rcp_row(double d) { return rcp_steps<TRPL_RCP_
 template <int NR>
 __device__ __forceinline__ void rcp_rows(const double (&d)[NR], double (&r)[NR])
 {
-    if constexpr (NR % 4 == 0 && TRPL_RCP_QUAD != 0) {
+    if constexpr (NR % 4 == 0) {
         // four values share ONE reciprocal: r = 1/(ab cd), 1/(ab) = cd r, 1/(cd) = ab r, then as for pairs
         // (9 multiplies + 1 reciprocal instead of 6 + 2; the operands are O(1e-4 .. 1e4))
 #pragma unroll
@@ -219,7 +218,7 @@ __device__ __forceinline__ void rcp_rows(const double (&d)[NR], double (&r)[NR])
             r[j + 2] = d[j + 3] * rcd;
             r[j + 3] = d[j + 2] * rcd;
         }
-    } else if constexpr (NR % 2 == 0 && TRPL_RCP_PAIR != 0) {
+    } else if constexpr (NR % 2 == 0) {
 #pragma unroll
         for (int j = 0; j < NR; j += 2) {
             const double rp = rcp_row(d[j] * d[j + 1]);
@@ -230,104 +229,6 @@ __device__ __forceinline__ void rcp_rows(const double (&d)[NR], double (&r)[NR])
 #pragma unroll
         for (int j = 0; j < NR; j++) r[j] = rcp_row(d[j]);
     }
-}
-
-// PCR in the interleaved layout with the neighbour exchange STAGED THROUGH LDS: each level the
-// wave stores its normalised rows (ld, ud, B)/d as three node-indexed arrays (one 16-byte store
-// per array: a lane's NR rows are adjacent nodes) and loads the rows at i-RF and i+RF with one
-// 16-byte load per array and direction: 9 DS instructions per level instead of 24
-// ds_bpermute_b32.  A wavefront executes its DS instructions in order, so no barrier is needed
-// and the 3*L-double buffer is reused by every level.  The LDS (shared by the CU's 4 SIMDs) and
-// the VALU are the two near-saturated resources of this kernel (tools/iter_bench.hip), so the
-// strides whose lane shift is 0 or 1 stay on DPP rotates and the final pairing on
-// v_permlane32_swap; only lane shifts 2..16 go through LDS.  Out-of-range neighbours wrap to
-// in-array values that are multiplied by exact zeros.
-template <int NR>
-struct vecN { double v[NR]; };
-
-template <int NR, int L>
-__device__ __forceinline__ void xch_store(double *xch, int arr, int lane, const double (&x)[NR])
-{
-    vecN<NR> t;
-#pragma unroll
-    for (int j = 0; j < NR; j++) t.v[j] = x[j];
-    *reinterpret_cast<vecN<NR> *>(xch + arr * L + NR * lane) = t;
-}
-template <int NR, int L>
-__device__ __forceinline__ void xch_load(const double *xch, int arr, int node0, double (&y)[NR])
-{
-    const vecN<NR> t = *reinterpret_cast<const vecN<NR> *>(xch + arr * L + node0);
-#pragma unroll
-    for (int j = 0; j < NR; j++) y[j] = t.v[j];
-}
-
-template <int NR, int L, int RF>
-__device__ __forceinline__ void pcr_levels_L(double (&ld)[NR], double (&d)[NR], double (&ud)[NR], double (&B)[NR],
-                                             int lane, double *xch)
-{
-    if constexpr (L > 2 * RF) {
-        double nl[NR], nu[NR], nB[NR], rd[NR];
-        rcp_rows<NR>(d, rd);
-#pragma unroll
-        for (int j = 0; j < NR; j++) { nl[j] = ld[j] * rd[j]; nu[j] = ud[j] * rd[j]; nB[j] = B[j] * rd[j]; }
-        double l_m[NR], u_m[NR], B_m[NR], l_p[NR], u_p[NR], B_p[NR];
-        if constexpr (RF / NR <= 1) {              // lane shift 0 or 1: in-lane moves / DPP rotates (VALU only)
-            nbrB_dn<double, NR, RF>(nl, l_m, lane);
-            nbrB_dn<double, NR, RF>(nu, u_m, lane);
-            nbrB_dn<double, NR, RF>(nB, B_m, lane);
-            nbrB_up<double, NR, RF>(nl, l_p, lane);
-            nbrB_up<double, NR, RF>(nu, u_p, lane);
-            nbrB_up<double, NR, RF>(nB, B_p, lane);
-        } else {
-            xch_store<NR, L>(xch, 0, lane, nl);
-            xch_store<NR, L>(xch, 1, lane, nu);
-            xch_store<NR, L>(xch, 2, lane, nB);
-            const int dn = (NR * lane - RF) & (L - 1), up = (NR * lane + RF) & (L - 1);
-            xch_load<NR, L>(xch, 0, dn, l_m);
-            xch_load<NR, L>(xch, 1, dn, u_m);
-            xch_load<NR, L>(xch, 2, dn, B_m);
-            xch_load<NR, L>(xch, 0, up, l_p);
-            xch_load<NR, L>(xch, 1, up, u_p);
-            xch_load<NR, L>(xch, 2, up, B_p);
-        }
-#pragma unroll
-        for (int j = 0; j < NR; j++) {
-            // rows i < RF have ld == 0 and rows i >= L-RF have ud == 0 exactly: wrapped values drop out
-            d[j] = d[j] - ld[j] * u_m[j] - ud[j] * l_p[j];
-            B[j] = B[j] - ld[j] * B_m[j] - ud[j] * B_p[j];
-            ld[j] = -ld[j] * l_m[j];
-            ud[j] = -ud[j] * u_p[j];
-        }
-        pcr_levels_L<NR, L, RF * 2>(ld, d, ud, B, lane, xch);
-    }
-}
-
-// PCR solve, interleaved layout, L >= 128 (the final pairs i, i+L/2 sit in lanes l, l^32).
-template <int NR, int L>
-__device__ __forceinline__ void pcr_solve_L(double (&ld)[NR], double (&d)[NR], double (&ud)[NR], double (&B)[NR],
-                                            double (&x)[NR], int lane, double *xch)
-{
-    pcr_levels_L<NR, L, 1>(ld, d, ud, B, lane, xch);
-    // final 2x2 solves (pvSimPCR.py:75-79) between lanes l and l^32, by Cramer's rule so that each
-    // lane computes only its own unknown with ONE reciprocal:
-    //     [ d_lo  ud_lo ] [x_lo]   [B_lo]        x_own = (B_own d_oth - c_own B_oth) / (d_own d_oth - c_own c_oth)
-    //     [ ld_hi d_hi  ] [x_hi] = [B_hi]        c = coupling to the partner row (ud for the lower, ld for the upper)
-    // v_permlane32_swap delivers the partner's values on the VALU (the LDS is the scarcer resource).
-    const bool low = lane < 32;
-    double det[NR], num[NR], rdet[NR];
-#pragma unroll
-    for (int j = 0; j < NR; j++) {
-        const double c_own = low ? +ud[j] : +ld[j];
-        double d_oth, B_oth, c_oth, lo_h, hi_h;
-        pair32(d[j], lo_h, hi_h);  d_oth = low ? hi_h : lo_h;
-        pair32(B[j], lo_h, hi_h);  B_oth = low ? hi_h : lo_h;
-        pair32(c_own, lo_h, hi_h); c_oth = low ? hi_h : lo_h;
-        det[j] = d[j] * d_oth - c_own * c_oth;
-        num[j] = B[j] * d_oth - c_own * B_oth;
-    }
-    rcp_rows<NR>(det, rdet);
-#pragma unroll
-    for (int j = 0; j < NR; j++) x[j] = num[j] * rdet[j];
 }
 
 // FAST solve for L >= 128, interleaved layout (lane l holds the NR = 2^k adjacent rows NR*l .. NR*l+NR-1):
@@ -352,25 +253,10 @@ template <> __device__ __forceinline__ float rcp_fast<float>(float d)
     return __builtin_fmaf(r, __builtin_fmaf(-d, r, 1.0f), r);
 }
 
-// value held by lane ^ 32
-#if TRPL_PARTNER_BPERMUTE
-// through the LDS crossbar: the VALU is this kernel's saturated unit (97 % busy), the LDS is not
-__device__ __forceinline__ double partner32(double v, bool) { return __shfl_xor(v, 32, 64); }
-__device__ __forceinline__ float partner32(float v, bool) { return __shfl_xor(v, 32, 64); }
-#else
-__device__ __forceinline__ double partner32(double v, bool low)
-{
-    double lo_h, hi_h;
-    pair32(v, lo_h, hi_h);
-    return low ? hi_h : lo_h;
-}
-__device__ __forceinline__ float partner32(float v, bool low)
-{
-    const unsigned a = __builtin_bit_cast(unsigned, v);
-    const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);   // r[0] = (lo,lo), r[1] = (hi,hi)
-    return __builtin_bit_cast(float, low ? r[1] : r[0]);
-}
-#endif
+// value held by lane ^ 32, through the LDS crossbar (ds_bpermute): the VALU is this kernel's saturated unit, the LDS is not
+// (v_permlane32_swap measured 1.9 % slower, and 0.9 % slower for the lone wave of the L = 512 stepper)
+__device__ __forceinline__ double partner32(double v) { return __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ float partner32(float v) { return __shfl_xor(v, 32, 64); }
 
 // Two systems per wavefront (stepper_pair_impl.hpp) run this solver on WS = 32 lanes each: the wave's
 // 2 x 32 reduced unknowns form one block-diagonal system whose coupling across the seams is exactly
@@ -417,32 +303,26 @@ __device__ __forceinline__ T seam_last(T v, int lane)       // v arrived from la
     else return v;
 }
 
-// XM (32-lane systems only) moves exchanges onto ds_swizzle rotates: bit 0 the strides >= 2 and the
-// pair step, bit 1 the stride-1 PCR level, bit 2 the stride-1 fetches of the CR levels.
-template <typename T, int S, int WS = 64, bool ISO = false, int XM = 0>
+// SWZ (32-lane systems only): the strides >= 2 and the pair step on ds_swizzle rotates instead of the LDS exchange buffer
+// (+2.8 %; the stride-1 level and the stride-1 fetches of the CR levels stay on DPP: on ds_swizzle 0 / -1 %, measured twice).
+template <typename T, int S, int WS = 64, bool ISO = false, bool SWZ = false>
 __device__ __forceinline__ void pcr64_levels(T &A, T &D, T &C, T &Bv, int lane, T *xch)
 {
-    static_assert(XM == 0 || (WS == 32 && XM < 8), "swizzle rotates work on 32-lane groups");
+    static_assert(!SWZ || WS == 32, "swizzle rotates work on 32-lane groups");
     if constexpr (S < WS / 2) {
         const T r = rcp_fast<T>(D);
         const T nA = A * r, nC = C * r, nB = Bv * r;
         T Am, Cm, Bm, Ap, Cp, Bp;
-        if constexpr ((S == 1 && (XM & 2) != 0) || (S > 1 && (XM & 1) != 0)) {   // rotate inside the system's 32 lanes
+        if constexpr (S > 1 && SWZ) {             // rotate inside the system's 32 lanes
             Am = rot32_dn<S>(nA); Cm = rot32_dn<S>(nC); Bm = rot32_dn<S>(nB);
             Ap = rot32_up<S>(nA); Cp = rot32_up<S>(nC); Bp = rot32_up<S>(nB);
-        } else if constexpr (S == 1 && TRPL_PCR_S1_LDS == 0) {   // DPP wave rotates
+        } else if constexpr (S == 1) {            // DPP wave rotates
             Am = seam_first<ISO, WS>(lane_dn<1>(nA, lane), lane); Cm = seam_first<ISO, WS>(lane_dn<1>(nC, lane), lane);
             Bm = seam_first<ISO, WS>(lane_dn<1>(nB, lane), lane);
             Ap = seam_last<ISO, WS>(lane_up<1>(nA, lane), lane); Cp = seam_last<ISO, WS>(lane_up<1>(nC, lane), lane);
             Bp = seam_last<ISO, WS>(lane_up<1>(nB, lane), lane);
-        } else if constexpr (TRPL_PCR_BPERMUTE != 0 && sizeof(T) == 8) {
-            // one LDS trip instead of two (ds_bpermute: the crossbar alone; write + read staging: memory in between) for
-            // twice the DS instructions: the latency of a lone wave against the throughput of a full SIMD
-            const int dn = ISO ? (((lane - S) & (WS - 1)) | (lane & (64 - WS))) : ((lane - S) & 63);
-            const int up = ISO ? (((lane + S) & (WS - 1)) | (lane & (64 - WS))) : ((lane + S) & 63);
-            Am = __shfl(nA, dn, 64); Cm = __shfl(nC, dn, 64); Bm = __shfl(nB, dn, 64);
-            Ap = __shfl(nA, up, 64); Cp = __shfl(nC, up, 64); Bp = __shfl(nB, up, 64);
-        } else {                                   // staged through LDS, one value per lane and array
+        } else {                                   // staged through LDS, one value per lane and array (3 writes + 6 reads of 8 bytes
+                                                   // per level; ds_bpermute -- one LDS trip, 12 instructions -- measured 8-10 % slower)
             xch[0 * 64 + lane] = nA;
             xch[1 * 64 + lane] = nC;
             xch[2 * 64 + lane] = nB;
@@ -456,19 +336,19 @@ __device__ __forceinline__ void pcr64_levels(T &A, T &D, T &C, T &Bv, int lane, 
         Bv = Bv - A * Bm - C * Bp;
         A = -A * Am;
         C = -C * Cp;
-        pcr64_levels<T, S * 2, WS, ISO, XM>(A, D, C, Bv, lane, xch);
+        pcr64_levels<T, S * 2, WS, ISO, SWZ>(A, D, C, Bv, lane, xch);
     }
 }
 
 // one forward cyclic-reduction level with in-lane stride H (rows H, 3H, .. eliminated)
-template <typename T, int NR, int H, int WS = 64, bool ISO = false, int XM = 0>
+template <typename T, int NR, int H, int WS = 64, bool ISO = false>
 __device__ __forceinline__ void cr_forward(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], int lane)
 {
     if constexpr (H < NR) {
         // normalise the eliminated rows in place: (ld, ud, B)[q] become (a^, c^, b^); in fp64 two rows share
         // one v_rcp_f64 (r = 1/(d_q d_q'), 1/d_q = d_q' r: the diagonals are O(1..1e3))
         constexpr int NQ = (NR - H + 2 * H - 1) / (2 * H);          // rows H, 3H, 5H, ...
-        if constexpr (sizeof(T) == 8 && NQ % 2 == 0 && TRPL_RCP_PAIR != 0) {
+        if constexpr (sizeof(T) == 8 && NQ % 2 == 0) {
 #pragma unroll
             for (int q = H; q < NR; q += 4 * H) {
                 const int q2 = q + 2 * H;
@@ -485,14 +365,9 @@ __device__ __forceinline__ void cr_forward(T (&ld)[NR], T (&d)[NR], T (&ud)[NR],
             }
         }
         // the left neighbour of row 0 is row NR-H of lane l-1
-        T aL0, cL0, bL0;
-        if constexpr ((XM & 4) != 0) {
-            aL0 = rot32_dn<1>(ld[NR - H]); cL0 = rot32_dn<1>(ud[NR - H]); bL0 = rot32_dn<1>(B[NR - H]);
-        } else {
-            aL0 = seam_first<ISO, WS>(lane_dn<1>(ld[NR - H], lane), lane);
-            cL0 = seam_first<ISO, WS>(lane_dn<1>(ud[NR - H], lane), lane);
-            bL0 = seam_first<ISO, WS>(lane_dn<1>(B[NR - H], lane), lane);
-        }
+        const T aL0 = seam_first<ISO, WS>(lane_dn<1>(ld[NR - H], lane), lane);
+        const T cL0 = seam_first<ISO, WS>(lane_dn<1>(ud[NR - H], lane), lane);
+        const T bL0 = seam_first<ISO, WS>(lane_dn<1>(B[NR - H], lane), lane);
 #pragma unroll
         for (int p = 0; p < NR; p += 2 * H) {
             const T aL = p == 0 ? aL0 : ld[p == 0 ? 0 : p - H], cL = p == 0 ? cL0 : ud[p == 0 ? 0 : p - H],
@@ -504,7 +379,7 @@ __device__ __forceinline__ void cr_forward(T (&ld)[NR], T (&d)[NR], T (&ud)[NR],
             ld[p] = -a * aL;
             ud[p] = -c * cR;
         }
-        cr_forward<T, NR, 2 * H, WS, ISO, XM>(ld, d, ud, B, lane);
+        cr_forward<T, NR, 2 * H, WS, ISO>(ld, d, ud, B, lane);
     }
 }
 
@@ -523,37 +398,35 @@ __device__ __forceinline__ void cr_backward(const T (&ld)[NR], const T (&ud)[NR]
 }
 
 // WS lanes per system (64: one system per wave; 32: two); the final pairs sit in lanes l, l ^ (WS/2)
-template <typename T, int NR, int WS = 64, bool ISO = false, int XM = 0>
+template <typename T, int NR, int WS = 64, bool ISO = false, bool SWZ = false>
 __device__ __forceinline__ void cr_pcr_solve(T (&ld)[NR], T (&d)[NR], T (&ud)[NR], T (&B)[NR], T (&x)[NR], int lane,
                                              T *xch)
 {
-    cr_forward<T, NR, 1, WS, ISO, XM>(ld, d, ud, B, lane);
+    cr_forward<T, NR, 1, WS, ISO>(ld, d, ud, B, lane);
     T A = ld[0], D = d[0], C = ud[0], Bv = B[0];
     // the cross-lane levels are one long dependent chain (reciprocal -> normalise -> exchange -> eliminate):
     // a wave inside it is issued ahead of its SIMD neighbour, which then fills the gaps with its assembly
     // (+0.6..0.8 % on the paired kernel, +1.2 % on the one-system kernel, same-box A/B; priority over the
-    // whole solve: +0.1 %)
-    if constexpr (TRPL_PCR_SETPRIO > 0) __builtin_amdgcn_s_setprio(TRPL_PCR_SETPRIO);
-    pcr64_levels<T, 1, WS, ISO, XM>(A, D, C, Bv, lane, xch);
-    const bool low = (lane & (WS / 2)) == 0;       // pairs by Cramer's rule, own unknown only
+    // whole solve: +0.1 %; levels 0 / 1 / 3 re-measured in round 4: -0.4 / +0.1 / +0.15 %, noise)
+    __builtin_amdgcn_s_setprio(2);
+    pcr64_levels<T, 1, WS, ISO, SWZ>(A, D, C, Bv, lane, xch);
+    // the final pairs (lanes l, l ^ WS/2) by Cramer's rule, own unknown only
     // the coupling to the partner row: C in the lower half, A in the upper.  After the levels S = 1 .. WS/4 the other one
     // is an exact zero (rows below 2 S have lost their sub-diagonal, rows above WS - 2 S their super-diagonal: products
     // with the exact zeros of rows 0 and WS - 1), so A + C is that coupling, bit for bit -- one add instead of two selects
-    const T c_own = TRPL_PAIRSTEP_ADD != 0 ? A + C : (low ? C : A);
+    const T c_own = A + C;
     T D_oth, B_oth, c_oth;
     if constexpr (WS == 64) {
-        D_oth = partner32(D, low); B_oth = partner32(Bv, low); c_oth = partner32(c_own, low);
-    } else if constexpr (WS == 32 && (XM & 1) != 0) {
+        D_oth = partner32(D); B_oth = partner32(Bv); c_oth = partner32(c_own);
+    } else if constexpr (WS == 32 && SWZ) {
         D_oth = swap16(D); B_oth = swap16(Bv); c_oth = swap16(c_own);
     } else {
         D_oth = __shfl_xor(D, WS / 2, 64); B_oth = __shfl_xor(Bv, WS / 2, 64); c_oth = __shfl_xor(c_own, WS / 2, 64);
     }
     const T X = (Bv * D_oth - c_own * B_oth) * rcp_fast<T>(D * D_oth - c_own * c_oth);
     x[0] = X;
-    if constexpr (TRPL_PCR_SETPRIO > 0) __builtin_amdgcn_s_setprio(0);
-    T xnext;                                       // a system's last lane: times c^ = 0
-    if constexpr ((XM & 4) != 0) xnext = rot32_up<1>(X);
-    else xnext = seam_last<ISO, WS>(lane_up<1>(X, lane), lane);
+    __builtin_amdgcn_s_setprio(0);
+    const T xnext = seam_last<ISO, WS>(lane_up<1>(X, lane), lane);      // a system's last lane: times c^ = 0
     cr_backward<T, NR, NR / 2>(ld, ud, B, x, xnext);
 }
 

@@ -19,21 +19,9 @@ namespace trpl {
 // chunk of a row is at most 16 bytes -- and cost up to 2x HBM reads when a lane needs several 16-byte loads
 // per row (interleaved layout, NR * sizeof(T) > 16: the line is gone before the second instruction asks for
 // its other half).  So: one wave per workgroup everywhere, non-temporal loads only where an instruction
-// consumes whole lines: directly for 16-byte chunks, through an LDS transpose for wider rows (TRPL_PCRB_STAGE).
-#ifndef TRPL_PCRB_WAVES
-#define TRPL_PCRB_WAVES 1       // wavefronts per workgroup
-#endif
-#ifndef TRPL_PCRB_NT
-#define TRPL_PCRB_NT -1         // -1: automatic (see above), 0: never, 1: non-temporal loads always
-#endif
-#ifndef TRPL_PCRB_STAGE
-#define TRPL_PCRB_STAGE 1       // rows wider than 16 bytes per lane: streamed with full-line non-temporal loads and
-                                // transposed to the interleaved layout through LDS: L = 512 fp64 5.72 -> 5.97 TB/s,
-                                // L = 256 fp64 / L = 512 fp32 +1 % (0: per-lane 16-byte loads, cached)
-#endif
-#ifndef TRPL_PCRB_CAP
-#define TRPL_PCRB_CAP 256       // grid cap: 256 * CAP workgroups, beyond that a wave loops over systems
-#endif
+// consumes whole lines: directly for 16-byte chunks, through an LDS transpose for wider rows (L = 512 fp64 5.72 -> 5.97 TB/s,
+// L = 256 fp64 / L = 512 fp32 +1 %).  (These were build switches TRPL_PCRB_WAVES / _NT / _STAGE / _CAP until round 5.)
+constexpr int kPcrbGridCap = 256 * 256;     // workgroups; beyond that a wave loops over systems
 
 template <bool NT, typename T> __device__ __forceinline__ T pcrb_load(const T *p)
 {
@@ -98,27 +86,23 @@ __device__ __forceinline__ void pcrb_transpose_row(const T (&stage)[NR], T *buf,
 }
 
 template <typename T, int L, bool STRICT>
-__global__ void __launch_bounds__(64 * TRPL_PCRB_WAVES) pcr_batched_kernel(const T *__restrict__ ld, const T *__restrict__ d,
+__global__ void __launch_bounds__(64) pcr_batched_kernel(const T *__restrict__ ld, const T *__restrict__ d,
                                                           const T *__restrict__ ud, const T *__restrict__ b,
                                                           T *__restrict__ x, int64_t S)
 {
     constexpr int W = L < 64 ? L : 64;
     constexpr int NR = L / W;
-    constexpr bool NT = TRPL_PCRB_NT < 0 ? (NR * sizeof(T) <= 16) : (TRPL_PCRB_NT >= 1);
-    const int lane = threadIdx.x & 63;
+    constexpr bool NT = NR * sizeof(T) <= 16;
+    const int lane = threadIdx.x;
     const int ln = lane & (W - 1);
-    // exchange buffer of the solve, private to each of the 4 waves: the cyclic-reduction + PCR solver stages one
-    // value per lane and array (3 x 64), the pure-PCR variants all L rows
-    constexpr int XW = TRPL_CR_HYBRID != 0 ? 64 : L;
-    __shared__ __attribute__((aligned(16))) T xch_all[(!STRICT && L >= 128) ? TRPL_PCRB_WAVES * 3 * XW : 4];
-    T *xch = xch_all + (threadIdx.x >> 6) * 3 * XW;
+    // exchange buffer of the solve: the cyclic-reduction + PCR solver stages one value per lane and array (3 x 64)
+    __shared__ __attribute__((aligned(16))) T xch[(!STRICT && L >= 128) ? 3 * 64 : 4];
     (void)xch;
-    constexpr bool STAGE = TRPL_PCRB_STAGE != 0 && !STRICT && L >= 128 && NR * sizeof(T) > 16;
-    __shared__ __attribute__((aligned(16))) T rowbuf_all[STAGE ? TRPL_PCRB_WAVES * L : 4];
-    T *rowbuf = rowbuf_all + (STAGE ? (threadIdx.x >> 6) * L : 0);
+    constexpr bool STAGE = !STRICT && L >= 128 && NR * sizeof(T) > 16;
+    __shared__ __attribute__((aligned(16))) T rowbuf[STAGE ? L : 4];
     (void)rowbuf;
-    const int64_t wave = (int64_t)blockIdx.x * TRPL_PCRB_WAVES + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * TRPL_PCRB_WAVES;
+    const int64_t wave = blockIdx.x;
+    const int64_t nwaves = gridDim.x;
     for (int64_t s = wave; s < S; s += nwaves) {
         const int64_t base = s * L;
         T vl[NR], vd[NR], vu[NR], vb[NR], vx[NR];
@@ -136,9 +120,7 @@ __global__ void __launch_bounds__(64 * TRPL_PCRB_WAVES) pcr_batched_kernel(const
                 pcrb_load_row<NT>(ld + o, vl); pcrb_load_row<NT>(d + o, vd);
                 pcrb_load_row<NT>(ud + o, vu); pcrb_load_row<NT>(b + o, vb);
             }
-            if constexpr (TRPL_CR_HYBRID != 0) cr_pcr_solve<T, NR>(vl, vd, vu, vb, vx, lane, xch);
-            else if constexpr (sizeof(T) == 8) pcr_solve_L<NR, L>(vl, vd, vu, vb, vx, lane, xch);
-            else                          f32::pcr_solve<NR, L>(vl, vd, vu, vb, vx, lane, xch);
+            cr_pcr_solve<T, NR>(vl, vd, vu, vb, vx, lane, xch);
 #pragma unroll
             for (int j = 0; j < NR; j++) x[base + NR * lane + j] = vx[j];
         } else {
@@ -161,9 +143,8 @@ hipError_t launch_pcr_batched_t(const void *ld, const void *d, const void *ud, c
                                 int L, hipStream_t stream)
 {
     if (S <= 0) return hipSuccess;
-    int64_t blocks = (S + TRPL_PCRB_WAVES - 1) / TRPL_PCRB_WAVES;
-    if (blocks > 256 * (int64_t)TRPL_PCRB_CAP) blocks = 256 * (int64_t)TRPL_PCRB_CAP;
-    dim3 grid((unsigned)blocks), block(64 * TRPL_PCRB_WAVES);
+    const int64_t blocks = S < kPcrbGridCap ? S : kPcrbGridCap;      // one wavefront per workgroup and system
+    dim3 grid((unsigned)blocks), block(64);
     switch (L) {
 #define TRPL_CASE(LL)                                                                                      \
     case LL:                                                                                               \

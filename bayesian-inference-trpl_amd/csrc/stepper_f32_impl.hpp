@@ -24,82 +24,6 @@ struct MatParF {
     float N0, P0, DN, DP, rate, sr0, srL, CN, CP, tauN, tauP, Lambda, n0p0;
 };
 
-template <int NR>
-struct vecF { float v[NR]; };
-
-template <int NR, int L>
-__device__ __forceinline__ void xstore(float *xch, int arr, int lane, const float (&x)[NR])
-{
-    vecF<NR> t;
-#pragma unroll
-    for (int j = 0; j < NR; j++) t.v[j] = x[j];
-    *reinterpret_cast<vecF<NR> *>(xch + arr * L + NR * lane) = t;
-}
-template <int NR, int L>
-__device__ __forceinline__ void xload(const float *xch, int arr, int node0, float (&y)[NR])
-{
-    const vecF<NR> t = *reinterpret_cast<const vecF<NR> *>(xch + arr * L + node0);
-#pragma unroll
-    for (int j = 0; j < NR; j++) y[j] = t.v[j];
-}
-
-template <int NR, int L, int RF>
-__device__ __forceinline__ void pcr_levels(float (&ld)[NR], float (&d)[NR], float (&ud)[NR], float (&B)[NR], int lane,
-                                           float *xch)
-{
-    if constexpr (L > 2 * RF) {
-        float nl[NR], nu[NR], nB[NR];
-#pragma unroll
-        for (int j = 0; j < NR; j++) {
-            const float r = rcp1(d[j]);
-            nl[j] = ld[j] * r; nu[j] = ud[j] * r; nB[j] = B[j] * r;
-        }
-        float l_m[NR], u_m[NR], B_m[NR], l_p[NR], u_p[NR], B_p[NR];
-        if constexpr (RF / NR <= 1) {              // lane shift 0 or 1: in-lane moves / DPP rotates
-            nbrB_dn<float, NR, RF>(nl, l_m, lane);
-            nbrB_dn<float, NR, RF>(nu, u_m, lane);
-            nbrB_dn<float, NR, RF>(nB, B_m, lane);
-            nbrB_up<float, NR, RF>(nl, l_p, lane);
-            nbrB_up<float, NR, RF>(nu, u_p, lane);
-            nbrB_up<float, NR, RF>(nB, B_p, lane);
-        } else {                                   // larger shifts staged through LDS
-            xstore<NR, L>(xch, 0, lane, nl);
-            xstore<NR, L>(xch, 1, lane, nu);
-            xstore<NR, L>(xch, 2, lane, nB);
-            const int dn = (NR * lane - RF) & (L - 1), up = (NR * lane + RF) & (L - 1);
-            xload<NR, L>(xch, 0, dn, l_m);
-            xload<NR, L>(xch, 1, dn, u_m);
-            xload<NR, L>(xch, 2, dn, B_m);
-            xload<NR, L>(xch, 0, up, l_p);
-            xload<NR, L>(xch, 1, up, u_p);
-            xload<NR, L>(xch, 2, up, B_p);
-        }
-#pragma unroll
-        for (int j = 0; j < NR; j++) {
-            d[j] = d[j] - ld[j] * u_m[j] - ud[j] * l_p[j];
-            B[j] = B[j] - ld[j] * B_m[j] - ud[j] * B_p[j];
-            ld[j] = -ld[j] * l_m[j];
-            ud[j] = -ud[j] * u_p[j];
-        }
-        pcr_levels<NR, L, RF * 2>(ld, d, ud, B, lane, xch);
-    }
-}
-
-template <int NR, int L>
-__device__ __forceinline__ void pcr_solve(float (&ld)[NR], float (&d)[NR], float (&ud)[NR], float (&B)[NR],
-                                          float (&x)[NR], int lane, float *xch)
-{
-    pcr_levels<NR, L, 1>(ld, d, ud, B, lane, xch);
-    const bool low = lane < 32;                    // final 2x2 solves by Cramer's rule (see pcr_solve_L)
-#pragma unroll
-    for (int j = 0; j < NR; j++) {
-        const float c_own = low ? +ud[j] : +ld[j];
-        const float d_oth = partner32(d[j], low), B_oth = partner32(B[j], low), c_oth = partner32(c_own, low);
-        const float det = d[j] * d_oth - c_own * c_oth;
-        x[j] = (B[j] * d_oth - c_own * B_oth) * rcp1(det);
-    }
-}
-
 template <bool IS_N, int NR, int L>
 __device__ __forceinline__ void assemble(const MatParF &m, float a0, const float (&Nk)[NR], const float (&Pk)[NR],
                                          const float (&Ek)[NR], const float (&Ep)[NR], const float (&bU)[NR],
@@ -219,13 +143,10 @@ __global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
     int64_t itot = 0;
 
     int64_t pl_next = 0, pl_col = 0;               // next step with t % plT == 0 and its PL column t / plT
+    const int64_t row_cap = bdf_row_cap(a.flags);   // TRPL_FLAG_BDF_ORDER
     for (int64_t t = 0; t <= sink.t_last; t++) {
-        float a0, a1, a2, a3, a4, a5;              // BDF table, pvSimPCR.py:241-250
-        if (t == 0)      { a0 = 1.0f; a1 = -1.0f; a2 = 0.0f; a3 = 0.0f; a4 = 0.0f; a5 = 0.0f; }
-        else if (t == 1) { a0 = 1.5f; a1 = -2.0f; a2 = 0.5f; a3 = 0.0f; a4 = 0.0f; a5 = 0.0f; }
-        else if (t == 2) { a0 = (float)(11.0 / 6); a1 = -3.0f; a2 = 1.5f; a3 = (float)(-1.0 / 3); a4 = 0.0f; a5 = 0.0f; }
-        else if (t == 3) { a0 = (float)(25.0 / 12); a1 = -4.0f; a2 = 3.0f; a3 = (float)(-4.0 / 3); a4 = 0.25f; a5 = 0.0f; }
-        else             { a0 = (float)(137.0 / 60); a1 = -5.0f; a2 = 5.0f; a3 = (float)(-10.0 / 3); a4 = 1.25f; a5 = -0.2f; }
+        float a0, a1, a2, a3, a4, a5;              // BDF table, pvSimPCR.py:241-250 (trpl_common.hpp: bdf_row)
+        bdf_row<float>((int32_t)(t < row_cap ? t : row_cap), a0, a1, a2, a3, a4, a5);
 
         double plv = 0.0;
         const bool pl_step = t == pl_next;

@@ -28,6 +28,7 @@ namespace trpl {
 constexpr uint32_t kFlagPlF32 = 0x2;       // TRPL_FLAG_PL_F32
 constexpr uint32_t kFlagNormalize = 0x4;   // TRPL_FLAG_NORMALIZE
 constexpr uint32_t kFlagSnapRaw = 0x80;    // TRPL_FLAG_SNAP_RAW
+constexpr uint32_t kFlagPairAlwaysSeam = 0x20000;   // TRPL_FLAG_PAIR_ALWAYS_SEAM
 constexpr double kPlFloorExcess = 1e-4;    // TRPL_PL_FLOOR_EXCESS
 
 // A flagged system's snapshot / checkpoint slots hold a quiet NaN whose payload is its status word (1 + failing step):
@@ -81,8 +82,7 @@ __device__ __forceinline__ void solve_lay(double (&ld)[NR], double (&d)[NR], dou
 {
     if constexpr (LAY == 0) pcr_solve<double, NR, W, L>(ld, d, ud, B, x, ln);
     else if constexpr (LAY == 1) pcr_solve_fast<double, NR, W, L>(ld, d, ud, B, x, ln);
-    else if constexpr (TRPL_CR_HYBRID != 0) cr_pcr_solve<double, NR>(ld, d, ud, B, x, ln, xch);
-    else pcr_solve_L<NR, L>(ld, d, ud, B, x, ln, xch);
+    else cr_pcr_solve<double, NR>(ld, d, ud, B, x, ln, xch);
 }
 
 // Relative L1 residual of iterate c in the system (lower l, diagonal dg, upper u | b):
@@ -118,43 +118,6 @@ __device__ __forceinline__ bool residual_below(const double (&l)[NR], const doub
         if constexpr (LAY == 0) return sr / sb < TOL;
         else                    return sr < TOL * sb;
     }
-}
-
-// The FAST (LAY 2) test in two parts, for the one-system steppers: the lanes' terms with their two votes, and the verdict --
-// taken by the caller where it is first needed (after the solve that follows), so that the vote's branch does not cut the
-// iteration's basic block between the residual and the solve (TRPL_NORM_VOTE_DEFER1, crosslane.hpp).
-struct Terms1 {
-    double q;                                   // this lane's sum over its rows of |r| - TOL |b|
-    unsigned long long neg, nonneg;             // lanes with q < 0 / q >= 0 (a NaN is in neither)
-};
-template <int NR>
-__device__ __forceinline__ Terms1 residual_terms(const double (&l)[NR], const double (&dg)[NR], const double (&u)[NR],
-                                                 const double (&b)[NR], const double (&c)[NR], double TOL, int ln)
-{
-    double cm[NR], cp[NR];
-    nbrB_dn<double, NR, 1>(c, cm, ln);
-    nbrB_up<double, NR, 1>(c, cp, ln);
-    double q = 0.0;
-#pragma unroll
-    for (int j = 0; j < NR; j++) {             // the same expressions as residual_below<2>
-        const double r = fabs(__builtin_fma(l[j], cm[j], __builtin_fma(dg[j], c[j], __builtin_fma(u[j], cp[j], -b[j]))));
-        const double qj = __builtin_fma(-TOL, fabs(b[j]), r);
-        q = j == 0 ? qj : q + qj;
-    }
-    Terms1 t = {q, 0ull, 0ull};
-    if constexpr (TRPL_NORM_VOTE != 0) {
-        t.neg = __builtin_amdgcn_ballot_w64(q < 0.0);
-        t.nonneg = __builtin_amdgcn_ballot_w64(q >= 0.0);
-    }
-    return t;
-}
-__device__ __forceinline__ bool residual_verdict(const Terms1 &t)
-{
-    if constexpr (TRPL_NORM_VOTE != 0) {
-        if (t.neg == ~0ull) return true;
-        if (t.nonneg == ~0ull) return false;
-    }
-    return wave_sum(t.q) < 0.0;
 }
 
 // STRICT, bundled systems (max_sims_per_block > 1): the quotient itself, because shared_array_max (pvSimPCR.py:83-90)
@@ -632,7 +595,7 @@ __device__ __forceinline__ void update_field(const MatPar &m, double a0, const d
 // fields live in LDS: 20 B per node and field instead of 32 B (N, P) / 16 registers (E).  State, assembly, solves,
 // residuals and PL stay fp64.  What it buys and what it costs: DESIGN.md section 8 (round 4).
 template <int L, bool STRICT, bool SNAP = false, bool MIXED = false, bool BUNDLE = false, bool HIST32 = false>
-__global__ void __launch_bounds__(BUNDLE ? 64 * bundle_cap(L) : 64, BUNDLE ? 1 : ((STRICT || L > 128) ? (L > 256 ? TRPL_L512_WAVES : 2) : TRPL_FAST_WAVES))
+__global__ void __launch_bounds__(BUNDLE ? 64 * bundle_cap(L) : 64, BUNDLE ? 1 : ((STRICT || L > 128) ? (L > 256 ? 1 : 2) : 3))
 stepper_kernel(const StepArgs a)
 {
     constexpr int W = L < 64 ? L : 64;
@@ -674,13 +637,11 @@ stepper_kernel(const StepArgs a)
     // registers so that ring + PCR exchange buffer leave room for 3 waves per SIMD.
     constexpr bool HREG = LAY != 2;                 // N / P history in registers
     constexpr int HSLOT = 2 * NR * 64;              // N and P; the E history stays in registers
-    constexpr int XCH = LAY != 2 ? 2 : (TRPL_CR_HYBRID != 0 ? 3 * 64 : 3 * L);   // PCR exchange buffer, doubles
+    constexpr int XCH = LAY != 2 ? 2 : 3 * 64;      // PCR exchange buffer, doubles
     // HIST32: {N, P}^{t-1} fp64 [row][lane] | E^{t-1} fp64 | d{N, P} fp32 [3][row][lane] | dE fp32 [3][row][lane], in doubles:
-    // (TRPL_H32_E_REGS: the field's E^{t-1} and three differences in registers instead -- 16 + 12 VGPR pairs for 10 KB of LDS)
-    // (TRPL_H32_FEEDBACK: + one fp32 rounding residual per node of N and P, carried into the next difference stored -- the
-    // stored differences then telescope to the true change of the state to one rounding, whatever the number of steps)
-    constexpr int H32F = TRPL_H32_FEEDBACK ? NR * 64 : 0;
-    constexpr int H32 = H32F + (TRPL_H32_E_REGS ? NR * 64 * 2 + 3 * NR * 64 : NR * 64 * 2 + NR * 64 + 3 * NR * 64 + (3 * NR * 64) / 2);
+    // (round 4 also measured the field's history in registers and a rounding-residual feedback into the stored differences:
+    // DESIGN_HISTORY.md section 7; neither changed the verdict and both left the tree in round 5)
+    constexpr int H32 = NR * 64 * 2 + NR * 64 + 3 * NR * 64 + (3 * NR * 64) / 2;
     constexpr int LDSW = HREG ? 2 : (HIST32 ? H32 + XCH : 4 * HSLOT + XCH);                // per wavefront
     __shared__ __attribute__((aligned(16))) double lds[LDSW * (BUNDLE ? bundle_cap(L) : 1)];
     double *hist = lds + (BUNDLE ? wv * LDSW : 0);
@@ -688,11 +649,8 @@ stepper_kernel(const StepArgs a)
     double2 *hist2 = reinterpret_cast<double2 *>(hist);
     double *xch = hist + (HREG ? 0 : (HIST32 ? H32 : 4 * HSLOT));    // PCR exchange buffer (LAY 2)
     double *prevE = hist + NR * 64 * 2;                               // HIST32 only (hist2[row * 64 + lane] = {N, P}^{t-1})
-    float2 *d32 = reinterpret_cast<float2 *>(prevE + (TRPL_H32_E_REGS ? 0 : NR * 64));       // d32[(slot * NR + row) * 64 + lane] = {dN, dP}
+    float2 *d32 = reinterpret_cast<float2 *>(prevE + NR * 64);       // d32[(slot * NR + row) * 64 + lane] = {dN, dP}
     float *dE32 = reinterpret_cast<float *>(d32 + 3 * NR * 64);
-    float2 *c32 = reinterpret_cast<float2 *>(hist + H32 - H32F);     // TRPL_H32_FEEDBACK: c32[row * 64 + lane] = rounding residuals {N, P}
-    double pEr[NR];                                 // HIST32 + TRPL_H32_E_REGS: E^{t-1} and d_{t-2}, d_{t-3}, d_{t-4} of the field
-    float dEr[3][NR];
     const int hl = lane64;                          // this lane's column of the ring
     double Nk[NR], Pk[NR], Ek[NR];
     double hN[4][NR], hP[4][NR];                    // HREG only: levels t-1 .. t-4
@@ -709,12 +667,11 @@ stepper_kernel(const StepArgs a)
         Ek[j] = 0.0;
         if constexpr (HIST32) {                    // U^{-1} := U^0 (its weight is zero at t = 0), no older differences
             hist2[j * 64 + hl] = make_double2(Nk[j], Pk[j]);
-            if constexpr (TRPL_H32_E_REGS) pEr[j] = 0.0; else prevE[j * 64 + hl] = 0.0;
-            if constexpr (TRPL_H32_FEEDBACK != 0) c32[j * 64 + hl] = make_float2(0.0f, 0.0f);
+            prevE[j * 64 + hl] = 0.0;
 #pragma unroll
             for (int m = 0; m < 3; m++) {
                 d32[(m * NR + j) * 64 + hl] = make_float2(0.0f, 0.0f);
-                if constexpr (TRPL_H32_E_REGS) dEr[m][j] = 0.0f; else dE32[(m * NR + j) * 64 + hl] = 0.0f;
+                dE32[(m * NR + j) * 64 + hl] = 0.0f;
             }
         } else {
 #pragma unroll
@@ -779,6 +736,7 @@ stepper_kernel(const StepArgs a)
         }
     }
     int h32_slot = 2;                              // HIST32: (t - 1) mod 3 at t = 0
+    const int32_t row_cap = bdf_row_cap(a.flags);   // TRPL_FLAG_BDF_ORDER: highest row of the BDF table this run uses
     for (int32_t t = t_begin; t <= sink.t_last; t++) {   // tEvol, pvSimPCR.py:237
         if constexpr (SNAP) {                      // the state at time t, before it is stepped (:283-288)
             if (snap.due(t))
@@ -786,11 +744,7 @@ stepper_kernel(const StepArgs a)
                                           [&](int j) { return node_of<LAY, NR, W>(ln, j); });
         }
         double a0, a1, a2, a3, a4, a5;             // :241-250
-        if (t == 0)      { a0 = 1.0; a1 = -1.0; a2 = 0.0; a3 = 0.0; a4 = 0.0; a5 = 0.0; }
-        else if (t == 1) { a0 = 1.5; a1 = -2.0; a2 = 0.5; a3 = 0.0; a4 = 0.0; a5 = 0.0; }
-        else if (t == 2) { a0 = 11.0 / 6; a1 = -3.0; a2 = 1.5; a3 = -1.0 / 3; a4 = 0.0; a5 = 0.0; }
-        else if (t == 3) { a0 = 25.0 / 12; a1 = -4.0; a2 = 3.0; a3 = -4.0 / 3; a4 = 0.25; a5 = 0.0; }
-        else             { a0 = 137.0 / 60; a1 = -5.0; a2 = 5.0; a3 = -10.0 / 3; a4 = 1.25; a5 = -0.2; }
+        bdf_row<double>(t < row_cap ? t : row_cap, a0, a1, a2, a3, a4, a5);
 
         // PL of the state at time t (level k), pvSimPCR.py:276-281: rate * (sum_i N_i P_i - L N0 P0).
         double plv = 0.0;
@@ -842,26 +796,17 @@ stepper_kernel(const StepArgs a)
 #pragma unroll
             for (int j = 0; j < NR; j++) {
                 const double2 u1 = hist2[j * 64 + hl];
-                const double e1 = TRPL_H32_E_REGS ? pEr[j] : prevE[j * 64 + hl];
+                const double e1 = prevE[j * 64 + hl];
                 const float2 f2 = d32[(o2 + j) * 64 + hl], f3 = d32[(o3 + j) * 64 + hl], f4 = d32[(o1 + j) * 64 + hl];
-                const float g2 = TRPL_H32_E_REGS ? dEr[0][j] : dE32[(o2 + j) * 64 + hl], g3 = TRPL_H32_E_REGS ? dEr[1][j] : dE32[(o3 + j) * 64 + hl],
-                            g4 = TRPL_H32_E_REGS ? dEr[2][j] : dE32[(o1 + j) * 64 + hl];
+                const float g2 = dE32[(o2 + j) * 64 + hl], g3 = dE32[(o3 + j) * 64 + hl], g4 = dE32[(o1 + j) * 64 + hl];
                 const double dn = u1.x - Nk[j], dp = u1.y - Pk[j], de = e1 - Ek[j];       // d_{t-1}, exact to fp64 rounding
                 bN[j] = -a0 * Nk[j] + w1 * dn + w2 * (double)f2.x + w3 * (double)f3.x + w4 * (double)f4.x;
                 bP[j] = -a0 * Pk[j] + w1 * dp + w2 * (double)f2.y + w3 * (double)f3.y + w4 * (double)f4.y;
                 bE[j] = -a0 * Ek[j] + w1 * de + w2 * (double)g2 + w3 * (double)g3 + w4 * (double)g4;
-                if constexpr (TRPL_H32_FEEDBACK != 0) {
-                    const float2 cr = c32[j * 64 + hl];
-                    const double vn = dn + (double)cr.x, vp = dp + (double)cr.y;
-                    const float fn = (float)vn, fp = (float)vp;
-                    d32[(o1 + j) * 64 + hl] = make_float2(fn, fp);
-                    c32[j * 64 + hl] = make_float2((float)(vn - (double)fn), (float)(vp - (double)fp));
-                } else {
-                    d32[(o1 + j) * 64 + hl] = make_float2((float)dn, (float)dp);
-                }
+                d32[(o1 + j) * 64 + hl] = make_float2((float)dn, (float)dp);
                 hist2[j * 64 + hl] = make_double2(Nk[j], Pk[j]);
-                if constexpr (TRPL_H32_E_REGS) { dEr[2][j] = dEr[1][j]; dEr[1][j] = dEr[0][j]; dEr[0][j] = (float)de; pEr[j] = Ek[j]; }
-                else { dE32[(o1 + j) * 64 + hl] = (float)de; prevE[j * 64 + hl] = Ek[j]; }
+                dE32[(o1 + j) * 64 + hl] = (float)de;
+                prevE[j * 64 + hl] = Ek[j];
             }
             h32_slot = h32_slot == 2 ? 0 : h32_slot + 1;
         } else {
@@ -885,9 +830,6 @@ stepper_kernel(const StepArgs a)
             double lo_[NR], dg[NR], up[NR], bb[NR], Ep[NR];
             shift_up1<LAY, NR, W>(Ek, Ep, ln);
             bool okN, okP;
-            // FAST, one system per workgroup: the residual tests' verdicts are taken where they are first used
-            constexpr bool DEFER = LAY == 2 && !MIXED && !BUNDLE && TRPL_NORM_VOTE_DEFER1 != 0;
-            Terms1 tN = {0.0, 0ull, ~0ull}, tP = {0.0, 0ull, ~0ull};       // "not below", decided without a reduction
             // ---- electrons (:148-175) ----
             assemble<LAY, true, NR, W, L>(mp, a0, Nk, Pk, Ek, Ep, bN, lo_, dg, up, bb, ln);
             if constexpr (MIXED) {
@@ -896,9 +838,6 @@ stepper_kernel(const StepArgs a)
                 const double e = residual_err_strict<NR, W>(lo_, dg, up, bb, Nk, ln);
                 okN = wv == 0 ? e < TOL : !(e >= TOL);
                 solve_lay<LAY, NR, W, L>(lo_, dg, up, bb, Nk, ln, xch);
-            } else if constexpr (DEFER) {
-                tN = residual_terms<NR>(lo_, dg, up, bb, Nk, TOL, ln);                             // :172
-                solve_lay<LAY, NR, W, L>(lo_, dg, up, bb, Nk, ln, xch);                                 // :175
             } else {
                 okN = residual_below<LAY, NR, W>(lo_, dg, up, bb, Nk, TOL, ln);                    // :172
                 solve_lay<LAY, NR, W, L>(lo_, dg, up, bb, Nk, ln, xch);                                 // :175
@@ -916,9 +855,6 @@ stepper_kernel(const StepArgs a)
                         const double e = residual_err_strict<NR, W>(lo_, dg, up, bb, Pk, ln);
                         okP = wv == 0 ? e < TOL : !(e >= TOL);
                     }
-                } else if constexpr (DEFER) {
-                    okN = residual_verdict(tN);
-                    if (okN) tP = residual_terms<NR>(lo_, dg, up, bb, Pk, TOL, ln);                 // :200
                 } else {
                     okP = okN ? residual_below<LAY, NR, W>(lo_, dg, up, bb, Pk, TOL, ln) : false;   // :200
                 }
@@ -926,7 +862,6 @@ stepper_kernel(const StepArgs a)
             }
             // ---- field on edges 1..L-1 (:205-209) ----
             update_field<LAY, NR, W>(mp, a0, Nk, Pk, bE, Ek, ln);
-            if constexpr (DEFER) okP = residual_verdict(tP);
             if constexpr (BUNDLE) {                // max over the bundle of errN and errP below TOL (:211-216)
                 if (lane64 == 0) agree[phase & 1][wv] = !valid || (okN && okP);
                 __syncthreads();
@@ -966,8 +901,6 @@ hipError_t launch_stepper(const StepArgs &a, hipStream_t stream)
     const int64_t nsys = a.S * a.C;
     if (nsys <= 0) return hipSuccess;
     dim3 grid((unsigned)nsys), block(64);
-    // development knob: extra dynamic LDS per workgroup lowers the number of resident waves
-    static const unsigned lds_pad = getenv("TRPL_LDS_PAD") ? (unsigned)atoi(getenv("TRPL_LDS_PAD")) : 0u;
     const bool snap = a.n_snap > 0 || a.resN != nullptr;   // snapshot / resume code only exists in its own instantiation
     if (a.bundle > 1) {                            // one workgroup per bundle of a.bundle consecutive samples of a curve
         if (a.bundle > bundle_cap(a.L) || (!STRICT && a.L > 128)) return hipErrorInvalidValue;
@@ -997,8 +930,8 @@ hipError_t launch_stepper(const StepArgs &a, hipStream_t stream)
     switch (a.L) {
 #define TRPL_CASE(LL) \
     case LL: \
-        if (snap) hipLaunchKernelGGL((stepper_kernel<LL, STRICT, true>), grid, block, lds_pad, stream, a); \
-        else      hipLaunchKernelGGL((stepper_kernel<LL, STRICT, false>), grid, block, lds_pad, stream, a); \
+        if (snap) hipLaunchKernelGGL((stepper_kernel<LL, STRICT, true>), grid, block, 0, stream, a); \
+        else      hipLaunchKernelGGL((stepper_kernel<LL, STRICT, false>), grid, block, 0, stream, a); \
         break;
         TRPL_CASE(4) TRPL_CASE(8) TRPL_CASE(16) TRPL_CASE(32) TRPL_CASE(64) TRPL_CASE(128)
         TRPL_CASE(256) TRPL_CASE(512)

@@ -59,9 +59,9 @@ __device__ __forceinline__ void half_sums(double v, double &lo, double &hi)
 //   residual_terms2: every lane's term q and the two lane votes (q < 0, q >= 0);
 //   residual_verdict2: where all 32 lanes of a system agree on the sign of their term, that is the sign of its sum
 //     (wave_sum_negative, crosslane.hpp); only otherwise the half-wave reduction.
-// The verdict follows the terms directly; taking it only where it is first needed (TRPL_NORM_VOTE_DEFER = 1: the electrons'
-// after their solve and the holes' assembly, the holes' at the end of the iteration, so that the iteration stays one basic
-// block up to there) was measured 0.3 % slower.
+// The verdict follows the terms directly; taking it only where it is first needed (the electrons' after their solve and the
+// holes' assembly, the holes' at the end of the iteration, so that the iteration stays one basic block up to there) was
+// measured 0.3 % slower (round 4).
 // needA / needB: the systems whose verdict is used (a frozen or parked system's is not, and must not force a reduction).
 struct Terms2 {
     double q;                                   // this lane's sum over its rows of |r| - TOL |b|
@@ -98,12 +98,10 @@ __device__ __forceinline__ void residual_verdict2(const Terms2 &t, bool needA, b
                                                   int *reductions = nullptr)
 {
     if constexpr (TRPL_NORM_VOTE != 0) {
-#if TRPL_VOTE_FASTPATH
         // the two common outcomes with one 64-bit scalar compare each: every lane of the wave >= 0 (the first iteration
         // of a time step: both systems far from converged) / every lane < 0 (its last one)
         if (t.nonneg == ~0ull) { okA = okB = false; return; }
         if (t.neg == ~0ull) { okA = okB = true; return; }
-#endif
         // the upper halves behind an empty asm: the optimiser would otherwise fold the `>> 32` test into a 64-bit unsigned
         // compare, which only the VALU has
         const unsigned negA = (unsigned)t.neg, nnA = (unsigned)t.nonneg;
@@ -150,8 +148,8 @@ __device__ __forceinline__ void update_field2(const MatPar &m, double a0, const 
 }
 
 // OPT: the optimistic seam (see the time loop); false = the selects in every iteration, the form rounds 1-3 shipped.  Both
-// are in the library: the second as the reference of the differential tests (TRPL_PAIR_ALWAYS_SEAM=1 selects it per process).
-template <bool ISO, int XM, bool SNAP = false, bool OPT = (TRPL_PAIR_OPTIMISTIC != 0)>
+// are in the library: the second as the reference of the differential tests (TRPL_FLAG_PAIR_ALWAYS_SEAM selects it per call).
+template <bool ISO, bool SNAP = false, bool OPT = (TRPL_PAIR_OPTIMISTIC != 0)>
 __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
 {
     constexpr int LAY = 2;
@@ -195,10 +193,9 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
     // ring layout [slot][row][lane]{N, P}: a lane's N and P of one row and level are one ds_read_b128 / ds_write_b128
     // (20 DS instructions per time step instead of 40); the field history hE[m] = E^{t-1-m} stays in registers
     constexpr int HSLOT = 2 * NR * 64;
-    constexpr int XCH = (XM & 1) ? 0 : 3 * 64;      // PCR exchange buffer, only for the LDS-staged levels
-    __shared__ __attribute__((aligned(16))) double lds[4 * HSLOT + XCH];
+    __shared__ __attribute__((aligned(16))) double lds[4 * HSLOT];
     double2 *hist2 = reinterpret_cast<double2 *>(lds);            // hist2[(slot * NR + row) * 64 + lane] = {N, P}
-    double *xch = lds + 4 * HSLOT;                  // never dereferenced when XCH == 0
+    double *xch = nullptr;                          // the solver's exchanges are DPP moves and ds_swizzle rotates: no buffer
     double Nk[NR], Pk[NR], Ek[NR], hE[4][NR];
 #pragma unroll
     for (int j = 0; j < NR; j++) {                  // pvSimPCR.py:356-362
@@ -287,6 +284,7 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
     if constexpr (SNAP) {
         if (t_begin > 0) { pl_col = (t_begin + a.plT - 1) / a.plT; pl_next = pl_col * a.plT; sinkA.base = sinkB.base = pl_col; }
     }
+    const int32_t row_cap = bdf_row_cap(a.flags);    // TRPL_FLAG_BDF_ORDER: highest row of the BDF table this run uses
     for (int32_t t = t_begin; t <= sinkA.t_last; t++) {   // tEvol, pvSimPCR.py:237
         if (deadA && deadB) break;
         if constexpr (SNAP) {                       // the state at time t, before it is stepped (:283-288)
@@ -295,11 +293,7 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
                                           [&](int j) { return NR * ln + j; });
         }
         double a0, a1, a2, a3, a4, a5;              // :241-250
-        if (t == 0)      { a0 = 1.0; a1 = -1.0; a2 = 0.0; a3 = 0.0; a4 = 0.0; a5 = 0.0; }
-        else if (t == 1) { a0 = 1.5; a1 = -2.0; a2 = 0.5; a3 = 0.0; a4 = 0.0; a5 = 0.0; }
-        else if (t == 2) { a0 = 11.0 / 6; a1 = -3.0; a2 = 1.5; a3 = -1.0 / 3; a4 = 0.0; a5 = 0.0; }
-        else if (t == 3) { a0 = 25.0 / 12; a1 = -4.0; a2 = 3.0; a3 = -4.0 / 3; a4 = 0.25; a5 = 0.0; }
-        else             { a0 = 137.0 / 60; a1 = -5.0; a2 = 5.0; a3 = -10.0 / 3; a4 = 1.25; a5 = -0.2; }
+        bdf_row<double>(t < row_cap ? t : row_cap, a0, a1, a2, a3, a4, a5);
 
         // PL of the state at time t, pvSimPCR.py:276-281, per-node excess first (see stepper_impl.hpp)
         double plA = 0.0, plB = 0.0;
@@ -355,34 +349,31 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
             double lo_[NR], dg[NR], up[NR], bb[NR], Ep[NR], x[NR];
             nbrB_up<double, NR, 1>(Ek, Ep, lane);   // a system's last lane reads the partner's E_0 = 0: E_L = 0
             bool okNA, okNB, okPA, okPB;
-            constexpr bool DEFER = TRPL_NORM_VOTE_DEFER != 0;
             const bool needNA = FROZEN ? !doneA : true, needNB = FROZEN ? !doneB : true;
             // ---- electrons (:148-175) ----
             assemble<LAY, true, NR, WS, L, true>(mp, a0, Nk, Pk, Ek, Ep, bN, lo_, dg, up, bb, ln);
             const Terms2 tN = residual_terms2<SEAM>(lo_, dg, up, bb, Nk, TOL, lane);                // :172
-            if constexpr (!DEFER) residual_verdict2(tN, needNA, needNB, okNA, okNB, TRPL_STAT(nredN));
-            cr_pcr_solve<double, NR, WS, SEAM, XM>(lo_, dg, up, bb, x, lane, xch);                      // :175
+            residual_verdict2(tN, needNA, needNB, okNA, okNB, TRPL_STAT(nredN));
+            cr_pcr_solve<double, NR, WS, SEAM, true>(lo_, dg, up, bb, x, lane, xch);                    // :175
 #pragma unroll
             for (int j = 0; j < NR; j++) Nk[j] = act ? x[j] : Nk[j];
             // ---- holes, with the updated electrons (:178-202) ----
             assemble<LAY, false, NR, WS, L, true>(mp, a0, Nk, Pk, Ek, Ep, bP, lo_, dg, up, bb, ln);
-            if constexpr (DEFER) residual_verdict2(tN, needNA, needNB, okNA, okNB, TRPL_STAT(nredN));
             // the holes' norm only matters if the electrons' passed for a system that is still iterating (:213):
             // on the first iteration of a time step it practically never has (a wave-uniform branch)
             const bool needPA = needNA && okNA, needPB = needNB && okNB;
             Terms2 tP = no_terms2();
             if (needPA || needPB) {
                 tP = residual_terms2<SEAM>(lo_, dg, up, bb, Pk, TOL, lane);                         // :200
-                if constexpr (!DEFER) residual_verdict2(tP, needPA, needPB, okPA, okPB, TRPL_STAT(nredP));
-            } else if constexpr (!DEFER) {
+                residual_verdict2(tP, needPA, needPB, okPA, okPB, TRPL_STAT(nredP));
+            } else {
                 okPA = okPB = false;
             }
-            cr_pcr_solve<double, NR, WS, SEAM, XM>(lo_, dg, up, bb, x, lane, xch);                      // :202
+            cr_pcr_solve<double, NR, WS, SEAM, true>(lo_, dg, up, bb, x, lane, xch);                    // :202
 #pragma unroll
             for (int j = 0; j < NR; j++) Pk[j] = act ? x[j] : Pk[j];
             // ---- field on edges 1..L-1 (:205-209) ----
             update_field2<ISO>(mp, a0, Nk, Pk, bE, Ek, lane, act);
-            if constexpr (DEFER) residual_verdict2(tP, needPA, needPB, okPA, okPB, TRPL_STAT(nredP));
             if (!doneA && okNA && okPA) { doneA = true; itA = iters + 1; }                         // :213-216
             if (!doneB && okNB && okPB) { doneB = true; itB = iters + 1; }
         };
@@ -406,22 +397,19 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
             // an iteration's test and turns non-finite in that iteration's solve (its partner, polluted in the same
             // solve, is then marked converged as well): both show below.  A parked system (flagged earlier) is a benign
             // finite one (park()), the odd tail's duplicate a copy of its partner: neither can.
-            iterate_step(std::integral_constant<bool, TRPL_PAIR_OPTIMISTIC == 3>{});      // (3: debugging, first pass voids too)
+            iterate_step(std::false_type{});
             // repeat the step if a live system is flagged in it -- or if a system's new state is not finite: the test of an
             // iteration precedes its solve, so a system can pass it and turn non-finite in that same, last iteration
             // (it is then flagged in the NEXT step), and its partner, polluted in that solve, is marked converged too.
             // The witness costs one compare: the field update forms the reciprocals of a lane's four A_j (each holding that
             // row's N and P, times Lambda D -- a zero factor keeps a NaN) from ONE v_rcp_f64 of their product (rcp_rows), so a
             // non-finite N or P anywhere in the lane makes every new E of the lane non-finite, the last row's included.
-#if TRPL_WITNESS_P
-            // (measured alternative: the holes' solve is the only one whose pollution no later test of the same step sees --
-            // the electrons' shows in the holes' test -- so its four results would do, and are ready before the field update)
-            const double wit = (Pk[0] + Pk[1]) + (Pk[2] + Pk[3]);
-#else
-            const double wit = TRPL_RCP_QUAD != 0 ? Ek[NR - 1] : (Ek[0] + Ek[1]) + (Ek[2] + Ek[3]);
-#endif
+            // (measured alternatives, round 4: the reduced excess sums, every lane's own term of them, the sum of the lane's
+            // four new P -- all bit-identical on the hostile batches, 0.1 - 0.3 % slower)
+            static_assert(NR % 4 == 0, "the witness relies on rcp_rows taking ONE reciprocal of the product of a lane's rows (pcr.hpp)");
+            const double wit = Ek[NR - 1];
             const bool finite2 = TRPL_PAIR_WITNESS == 0 || __builtin_amdgcn_ballot_w64(__builtin_isfinite(wit)) == ~0ull;
-            if (TRPL_PAIR_OPTIMISTIC == 2 || (!deadA && itA >= MAX) || (!deadB && itB >= MAX) || !finite2) {      // (2: debugging, always repeat)
+            if ((!deadA && itA >= MAX) || (!deadB && itB >= MAX) || !finite2) {
                 const int s4 = (int)(t & 3) * NR;
 #pragma unroll
                 for (int j = 0; j < NR; j++) {
@@ -470,26 +458,27 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
 #endif
     sinkA.finish(statusA, itotA);
     if (validB) sinkB.finish(statusB, itotB);
+#undef TRPL_STAT
 }
 
 }  // namespace pair
 
-template <bool ISO, int XM>
+template <bool ISO>
 hipError_t launch_stepper_pair_t(const StepArgs &a, hipStream_t stream)
 {
     if (a.L != pair::L) return hipErrorInvalidValue;
     const int64_t nblk = ((a.S + 1) / 2) * a.C;      // with and without a pairing table
     if (nblk <= 0) return hipSuccess;
-    // measurement / test switch, read once per process: the always-isolating kernel instead of the optimistic one
-    static const bool always_seam = getenv("TRPL_PAIR_ALWAYS_SEAM") && atoi(getenv("TRPL_PAIR_ALWAYS_SEAM")) != 0;
+    // TRPL_FLAG_PAIR_ALWAYS_SEAM (tests, measurements): the always-isolating kernel instead of the optimistic one
+    const bool always_seam = (a.flags & kFlagPairAlwaysSeam) != 0;
     const bool snap = a.n_snap > 0 || a.resN != nullptr;
     const dim3 grid((unsigned)nblk), block(64);
     if (always_seam) {
-        if (snap) hipLaunchKernelGGL((pair::stepper_pair_kernel<ISO, XM, true, false>), grid, block, 0, stream, a);
-        else      hipLaunchKernelGGL((pair::stepper_pair_kernel<ISO, XM, false, false>), grid, block, 0, stream, a);
+        if (snap) hipLaunchKernelGGL((pair::stepper_pair_kernel<ISO, true, false>), grid, block, 0, stream, a);
+        else      hipLaunchKernelGGL((pair::stepper_pair_kernel<ISO, false, false>), grid, block, 0, stream, a);
     } else {
-        if (snap) hipLaunchKernelGGL((pair::stepper_pair_kernel<ISO, XM, true>), grid, block, 0, stream, a);
-        else      hipLaunchKernelGGL((pair::stepper_pair_kernel<ISO, XM, false>), grid, block, 0, stream, a);
+        if (snap) hipLaunchKernelGGL((pair::stepper_pair_kernel<ISO, true>), grid, block, 0, stream, a);
+        else      hipLaunchKernelGGL((pair::stepper_pair_kernel<ISO, false>), grid, block, 0, stream, a);
     }
     return hipGetLastError();
 }

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "api_util.hpp"
+#include "crosslane.hpp"      // TRPL_PAIR_OPTIMISTIC (trpl_kernel_name)
 
 namespace trpl {
 
@@ -92,12 +93,9 @@ void curve_const(double length, double time_ns, int L, int64_t T, trpl::CurveCon
 // Measured crossover (MI355X, Power_scan, round-2 kernels, tools/small_launch_probe.py; pair / single time):
 //   steps = 8000:  1024 systems 1.15, 3072: 1.01, 4096: 0.91, 8192: 0.86, 12 288: 0.82
 //   steps = 1000:  4096: 0.96, 6144: 0.99, 8192: 0.92, 12 288: 0.88
-// TRPL_FLAG_KERNEL_PAIR / _SINGLE force the choice per call; the environment variable TRPL_PAIR=0 / 1
-// forces it for a whole process (measurements only; the flags win).
+// TRPL_FLAG_KERNEL_PAIR / _SINGLE force the choice per call.
 bool use_pair_kernel(int64_t nsys, int64_t steps)
 {
-    static const int forced = getenv("TRPL_PAIR") ? atoi(getenv("TRPL_PAIR")) : -1;
-    if (forced >= 0) return forced != 0;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
         static thread_local int cached_dev = -1, cached_cus = 256;
@@ -120,12 +118,11 @@ constexpr uint32_t kVariantBits = TRPL_FLAG_KERNEL_PAIR | TRPL_FLAG_KERNEL_SINGL
 // group consecutive curves -- neighbouring excitation powers in the reference's files -- are paired for each of the
 // two samples of a period; the first curve of a group of odd size pairs with itself across the two samples.  Every
 // (curve, sample) of the period appears exactly once.  A system's bits do not depend on its partner (tested), so the
-// table is purely a scheduling matter; TRPL_PAIR_CURVES=0 switches it off for A/B measurements.
+// table is purely a scheduling matter; TRPL_FLAG_PAIR_ADJACENT switches it off for A/B measurements.
 void build_pair_table(trpl::StepArgs &a)
 {
     a.pair_n = 0;
-    static const bool enabled = !(getenv("TRPL_PAIR_CURVES") && atoi(getenv("TRPL_PAIR_CURVES")) == 0);
-    if (!enabled || a.C < 2 || a.obs_hi != nullptr || a.pl != nullptr) return;
+    if ((a.flags & TRPL_FLAG_PAIR_ADJACENT) || a.C < 2 || a.obs_hi != nullptr || a.pl != nullptr) return;
     bool used[trpl::kMaxCurves] = {};
     int k = 0;
     for (int c0 = 0; c0 < a.C; c0++) {
@@ -196,6 +193,7 @@ namespace {
 int launch(const trpl::StepArgs &a_in, uint32_t flags, hipStream_t st, int64_t steps)
 {
     if (int rc = check_variant_flags(flags, a_in.L)) return rc;
+    if (((flags >> 14) & 7u) > 5u) return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_BDF_ORDER(%u): the order cap must be 1 .. 5 (0: the reference's ramp)", (flags >> 14) & 7u);
     trpl::StepArgs a = a_in;
     a.bundle = (int32_t)((flags >> 8) & 0xF) + 1;             // TRPL_FLAG_BUNDLE(m)
     if (flags & TRPL_FLAG_HIST32) {
@@ -260,6 +258,24 @@ int trpl_kernel_variant(int64_t nsys, int32_t L, int64_t steps, uint32_t flags)
     if (flags & TRPL_FLAG_MIXED) return TRPL_KERNEL_MIXED;
     if (flags & TRPL_FLAG_HIST32) return TRPL_KERNEL_HIST32;
     return pick_pair_kernel(nsys, L, steps, flags) ? TRPL_KERNEL_FAST_PAIR : TRPL_KERNEL_FAST;
+}
+
+int trpl_kernel_name(int64_t nsys, int32_t L, int64_t steps, uint32_t flags, int32_t snapshots, char *buf, int64_t buflen)
+{
+    if (!buf || buflen < 1) return api_fail(TRPL_ERR_ARG, "buf must hold at least one byte");
+    const char *tf[2] = {"false", "true"};
+    const int snap = snapshots != 0, bundle = ((flags >> 8) & 0xF) != 0;
+    int n;
+    if (flags & TRPL_FLAG_FP32)
+        n = snprintf(buf, (size_t)buflen, "trpl::f32::stepper_kernel<%d>", L);
+    else if (!(flags & (TRPL_FLAG_STRICT | TRPL_FLAG_MIXED | TRPL_FLAG_HIST32)) && pick_pair_kernel(nsys, L, steps, flags))
+        n = snprintf(buf, (size_t)buflen, "trpl::pair::stepper_pair_kernel<true, %s, %s>", tf[snap],
+                     tf[TRPL_PAIR_OPTIMISTIC != 0 && !(flags & TRPL_FLAG_PAIR_ALWAYS_SEAM)]);
+    else
+        n = snprintf(buf, (size_t)buflen, "trpl::stepper_kernel<%d, %s, %s, %s, %s, %s>", L, tf[(flags & TRPL_FLAG_STRICT) != 0],
+                     tf[snap], tf[(flags & TRPL_FLAG_MIXED) != 0], tf[bundle], tf[(flags & TRPL_FLAG_HIST32) != 0]);
+    if (n < 0 || n >= buflen) return api_fail(TRPL_ERR_ARG, "buflen=%lld is too small for the kernel name", (long long)buflen);
+    return TRPL_OK;
 }
 
 int trpl_pair_table(const double *lengths_nm, const int64_t *n_obs, int32_t C, int32_t L, int64_t T, double time_ns,

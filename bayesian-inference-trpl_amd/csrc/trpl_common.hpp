@@ -36,7 +36,8 @@ struct StepArgs {
     double *sse;            // [C][S] out (likelihood mode) or nullptr
     int32_t *status;        // [C][S] out or nullptr
     int64_t *iters_total;   // [C][S] out or nullptr
-    int32_t *floor_col;     // [C][S] out or nullptr: first compared PL column below 1e-12 of the system's first column, or -1
+    int32_t *floor_col;     // [C][S] out or nullptr: first compared PL column with r = PL / (B L n0p0) < TRPL_PL_FLOOR_EXCESS (or a
+                            // non-positive / NaN PL); -1: none (floor-free); -2: a flagged system (status != 0, sse = +inf)
     // state snapshots (solve mode only; pvSimPCR.py:283-288, Legacy/pvSim.py:121-126,:169-171): the state
     // at time step snap_t[i] goes to slot snap_slot[i] of snapN/snapP [C*S][snap_ld][L], snapE [..][L+1]
     double *snapN, *snapP, *snapE;
@@ -69,6 +70,22 @@ struct StepArgs {
     uint8_t pair_cA[kMaxCurves], pair_oA[kMaxCurves], pair_cB[kMaxCurves], pair_oB[kMaxCurves];
     CurveConst curve[kMaxCurves];
 };
+
+// BDF coefficient table of tEvol (pvSimPCR.py:241-250): time step t takes the row min(t, 4) -- order 1 (Euler) at t = 0,
+// ramping to order 5 from t = 4 on.  TRPL_FLAG_BDF_ORDER(k) (bits 14-16 of the flags, k = 1 .. 5; 0 = the reference's ramp)
+// caps the order at k: the row is min(t, k - 1).  k = 2 is the scheme of the reference's older solver Legacy/pvSim.py:94-97
+// (Euler, then BDF2), which makes that file a whole-curve parity reference.  The cap is wave-uniform
+// scalar code outside the iterations: no cost when it is off.
+__host__ __device__ constexpr int32_t bdf_row_cap(uint32_t flags) { return ((flags >> 14) & 7u) ? (int32_t)((flags >> 14) & 7u) - 1 : 4; }
+template <typename T>
+__device__ __forceinline__ void bdf_row(int32_t row, T &a0, T &a1, T &a2, T &a3, T &a4, T &a5)
+{
+    if (row == 0)      { a0 = (T)1.0; a1 = (T)-1.0; a2 = (T)0.0; a3 = (T)0.0; a4 = (T)0.0; a5 = (T)0.0; }
+    else if (row == 1) { a0 = (T)1.5; a1 = (T)-2.0; a2 = (T)0.5; a3 = (T)0.0; a4 = (T)0.0; a5 = (T)0.0; }
+    else if (row == 2) { a0 = (T)(11.0 / 6); a1 = (T)-3.0; a2 = (T)1.5; a3 = (T)(-1.0 / 3); a4 = (T)0.0; a5 = (T)0.0; }
+    else if (row == 3) { a0 = (T)(25.0 / 12); a1 = (T)-4.0; a2 = (T)3.0; a3 = (T)(-4.0 / 3); a4 = (T)0.25; a5 = (T)0.0; }
+    else               { a0 = (T)(137.0 / 60); a1 = (T)-5.0; a2 = (T)5.0; a3 = (T)(-10.0 / 3); a4 = (T)1.25; a5 = (T)-0.2; }
+}
 
 // Launchers (one translation unit per arithmetic mode, see stepper_strict.hip / stepper_fast.hip).
 hipError_t launch_stepper_strict(const StepArgs &a, hipStream_t stream);

@@ -270,6 +270,11 @@ struct trpl_multi {
 
 int trpl_multi_create(const int32_t *devices, int32_t n_devices, trpl_multi_t **handle)
 {
+    return trpl_multi_create_ex(devices, n_devices, 0u, handle);
+}
+
+int trpl_multi_create_ex(const int32_t *devices, int32_t n_devices, uint32_t create_flags, trpl_multi_t **handle)
+{
     if (!handle) return api_fail(TRPL_ERR_ARG, "handle must not be NULL");
     *handle = nullptr;
     int visible = 0;
@@ -283,9 +288,9 @@ int trpl_multi_create(const int32_t *devices, int32_t n_devices, trpl_multi_t **
     h->n = n_devices;
     for (int r = 0; r < n_devices; r++) {
         const int d = devices ? devices[r] : r;
-        // RCCL wants one rank per device; TRPL_MULTI_ALLOW_DUP=1 lets the tests run several "ranks" on one device
-        // against a stand-in collective library (tests/mock_rccl)
-        static const bool allow_dup = getenv("TRPL_MULTI_ALLOW_DUP") && atoi(getenv("TRPL_MULTI_ALLOW_DUP"));
+        // RCCL wants one rank per device; TRPL_MULTI_ALLOW_DUPLICATE_DEVICES lets the tests run several "ranks" on one
+        // device against a stand-in collective library (tests/mock_rccl)
+        const bool allow_dup = (create_flags & TRPL_MULTI_ALLOW_DUPLICATE_DEVICES) != 0;
         bool dup = false;
         for (int q = 0; q < r && !allow_dup; q++) dup = dup || h->dev[q] == d;
         if (d < 0 || d >= visible || dup) {
@@ -456,7 +461,7 @@ int trpl_loglik_multi_dev(trpl_multi_t *h, const double *const *X, int64_t S, in
         }
         // ONE collective: all-gather of `widest` fp64 per rank (RCCL over xGMI), straight into P_full when the
         // shards are equal, through the padded scratch + an unpadding pass otherwise
-        static const bool force_pad = getenv("TRPL_MULTI_FORCE_PAD") && atoi(getenv("TRPL_MULTI_FORCE_PAD"));   // tests
+        const bool force_pad = (flags & TRPL_FLAG_MULTI_FORCE_PAD) != 0;     // tests
         const bool even = S % n == 0 && !force_pad;
         RCCL_TRY(api->GroupStart());
         for (int r = 0; r < n; r++) {

@@ -233,10 +233,14 @@ class MultiDevice:
     8e): contiguous sample shards, one RCCL all-gather of the per-sample likelihoods over xGMI.  The handle
     owns one stream and one RCCL rank per device; create it once and reuse it."""
 
-    def __init__(self, devices=None):
+    def __init__(self, devices=None, allow_duplicate_devices=False):
+        """allow_duplicate_devices (tests): several ranks on one GPU, against a stand-in collective library named by
+        TRPL_RCCL_LIBRARY (trpl_multi_create_ex, TRPL_MULTI_ALLOW_DUPLICATE_DEVICES); real RCCL refuses them."""
         self._h = _abi.C.c_void_p()
         dev = None if devices is None else np.ascontiguousarray(devices, dtype=np.int32)
-        _abi.check(_abi.lib().trpl_multi_create(_abi.ptr(dev), 0 if dev is None else len(dev), _abi.C.byref(self._h)))
+        _abi.check(_abi.lib().trpl_multi_create_ex(_abi.ptr(dev), 0 if dev is None else len(dev),
+                                                   _abi.MULTI_ALLOW_DUPLICATE_DEVICES if allow_duplicate_devices else 0,
+                                                   _abi.C.byref(self._h)))
         self.n = int(_abi.lib().trpl_multi_device_count(self._h))
         self.devices = list(range(self.n)) if dev is None else [int(d) for d in dev]
 

@@ -70,7 +70,7 @@ def bracket_times(sim_t, times):
 
 def loglik(X, init_params, lengths, Time, L, T, obs, tol=7, MAX=10000, plT=1, P=None, pl_f32=False,
            normalize=False, strict=False, device=0, info=None, times=None, fp32=False, devices=None, kernel=None,
-           mixed=False, bundle=1, hist32=False):
+           mixed=False, bundle=1, hist32=False, bdf_order=None, extra_flags=0):
     """Fused likelihood of one experiment (trpl_loglik / trpl_loglik_obs / trpl_loglik_multi).
 
     X (S,13) solver units; init_params (C,L) nm^-3; lengths scalar or (C,); obs = list of C
@@ -82,6 +82,8 @@ def loglik(X, init_params, lengths, Time, L, T, obs, tol=7, MAX=10000, plT=1, P=
     (contiguous sample shards, one per entry, run concurrently from this host thread).
     kernel: None (the library picks the stepper by launch size), "pair" or "single" (TRPL_FLAG_KERNEL_*).
     bundle: the reference's max_sims_per_block (TRPL_FLAG_BUNDLE; single-device calls only).
+    bdf_order: cap the BDF order ramp at 1 .. 5 (TRPL_FLAG_BDF_ORDER); extra_flags: further TRPL_FLAG_* bits, ORed in
+    (tests / measurements: _abi.FLAG_PAIR_ALWAYS_SEAM, _abi.FLAG_PAIR_ADJACENT, ...).
     """
     X = np.ascontiguousarray(X, dtype=np.float64)
     if X.ndim != 2 or X.shape[1] != 13:
@@ -127,7 +129,8 @@ def loglik(X, init_params, lengths, Time, L, T, obs, tol=7, MAX=10000, plT=1, P=
     floor_col = np.full((Cn, S), -1, dtype=np.int32)
     flags = (_abi.FLAG_STRICT if strict else 0) | (_abi.FLAG_PL_F32 if pl_f32 else 0) \
         | (_abi.FLAG_NORMALIZE if normalize else 0) | _abi.fp32_flags(fp32) | _abi.kernel_flag(kernel) \
-        | (_abi.FLAG_MIXED if mixed else 0) | _abi.flag_bundle(bundle, L) | (_abi.FLAG_HIST32 if hist32 else 0)
+        | (_abi.FLAG_MIXED if mixed else 0) | _abi.flag_bundle(bundle, L) | (_abi.FLAG_HIST32 if hist32 else 0) \
+        | _abi.flag_bdf_order(bdf_order) | int(extra_flags)
     sec = _abi.C.c_double(0.0)
     lib = _abi.lib()
     if devices is not None:

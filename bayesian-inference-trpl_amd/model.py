@@ -12,7 +12,7 @@ def _as_f64(a):
 
 def solve_pl(matPar, Length, Time, L, T, dN, plT=1, tol=7, MAX=10000, out=None, dtype=np.float64,
              strict=False, device=0, fp32=False, kernel=None, mixed=False, snap_steps=None, plN=None, plP=None, plE=None,
-             snapshots=None, resume=None, snap_raw=False, bundle=1, hist32=False):
+             snapshots=None, resume=None, snap_raw=False, bundle=1, hist32=False, bdf_order=None, extra_flags=0):
     """PL(t) for S systems of one curve.  matPar (S,12) and dN (L,) in nm/ns units.
     Returns (plI, status, iters_total, seconds).
 
@@ -29,7 +29,9 @@ def solve_pl(matPar, Length, Time, L, T, dN, plT=1, tol=7, MAX=10000, out=None, 
     (the automatic choice looks at the number of steps left).
     bundle: the reference's max_sims_per_block (TRPL_FLAG_BUNDLE, up to 4): `bundle` consecutive samples share one
     convergence test per inner iteration (pvSimPCR.py:211-216) -- strict=True bit-identical to the reference run that
-    way, otherwise to rounding (L <= 128, one-system kernel)."""
+    way, otherwise to rounding (L <= 128, one-system kernel).
+    bdf_order: cap the BDF order ramp (pvSimPCR.py:241-250) at 1 .. 5 (TRPL_FLAG_BDF_ORDER; 2 = Legacy/pvSim.py's scheme).
+    extra_flags: further TRPL_FLAG_* bits, ORed in (tests / measurements: _abi.FLAG_PAIR_ALWAYS_SEAM, ...)."""
     matPar = _as_f64(matPar)
     if matPar.ndim != 2 or matPar.shape[1] != 12:
         raise ValueError("matPar must have shape (S, 12)")
@@ -54,7 +56,7 @@ def solve_pl(matPar, Length, Time, L, T, dN, plT=1, tol=7, MAX=10000, out=None, 
     sec = _abi.C.c_double(0.0)
     flags = (_abi.FLAG_STRICT if strict else 0) | _abi.fp32_flags(fp32) | _abi.kernel_flag(kernel) \
         | (_abi.FLAG_MIXED if mixed else 0) | (_abi.FLAG_SNAP_RAW if snap_raw else 0) | _abi.flag_bundle(bundle, L) \
-        | (_abi.FLAG_HIST32 if hist32 else 0)
+        | (_abi.FLAG_HIST32 if hist32 else 0) | _abi.flag_bdf_order(bdf_order) | int(extra_flags)
     steps = None
     n_snap = 0
     if snap_steps is not None and len(snap_steps):

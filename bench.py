@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--hist32", action="store_true",
                     help="fp64 arithmetic, BDF history as fp32 differences (TRPL_FLAG_HIST32, L = 256 / 512; round-4 experiment)")
     ap.add_argument("--tol", type=int, default=None, help="convergence exponent (default 7, the reference's)")
+    ap.add_argument("--extra-flags", type=lambda v: int(v, 0), default=0,
+                    help="further TRPL_FLAG_* bits for the timed launches (measurements: 0x20000 = always-isolating paired "
+                         "kernel, 0x40000 = adjacent-sample pairing, 0x10 / 0x20 = force the paired / one-system kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcr", action="store_true")
     ap.add_argument("--no-host-api", action="store_true",
@@ -164,7 +167,7 @@ def main():
     X_host = wl.samples(S_total)[lo:hi]                      # same seeded draw on every rank, own shard
     flags = (trpl_amd.FLAG_STRICT if args.strict else 0) | (trpl_amd.FLAG_MIXED if args.mixed else 0) \
         | ((trpl_amd.FLAG_FP32 | trpl_amd.FLAG_FP32_LONG) if args.fp32 else 0) \
-        | (trpl_amd._abi.FLAG_HIST32 if args.hist32 else 0)     # (--fp32: a screening-mode number, flagged as such below)
+        | (trpl_amd._abi.FLAG_HIST32 if args.hist32 else 0) | args.extra_flags     # (--fp32: a screening-mode number, flagged as such below)
     # the stepper variant is a property of the LOGICAL batch (all ranks' samples), not of this rank's shard:
     # a sample's bits then do not depend on how many GPUs the batch is cut over (include/trpl.h)
     flags = trpl_amd._abi.pin_variant(flags, S_total * C, L, T)
@@ -253,18 +256,13 @@ def main():
     variant = trpl_amd._abi.lib().trpl_kernel_variant(S_total * C, L, T, flags)
     if variant == trpl_amd._abi.KERNEL_FAST_PAIR:
         kernel_name = "pair::stepper_pair_kernel (2 x L=128 systems per wavefront; fused time-stepper + likelihood)"
-        # <ISO, XM, SNAP, OPT>: the optimistic-seam instantiation unless TRPL_PAIR_ALWAYS_SEAM=1 selects the other one
-        rocprof_name = "void trpl::pair::stepper_pair_kernel<true, 1, false, %s>" % (
-            "false" if os.environ.get("TRPL_PAIR_ALWAYS_SEAM", "0") not in ("", "0") else "true")
     else:
         kernel_name = "%sstepper_kernel<%d%s> (fused time-stepper + likelihood)" % ("f32::" if args.fp32 else "", L,
                                                                                    ", mixed" if args.mixed else "")
-        rocprof_name = ("void trpl::f32::stepper_kernel<%d>" % L) if args.fp32 else \
-            "void trpl::stepper_kernel<%d, %s, false, %s, false, %s>" % (L, "true" if args.strict else "false",
-                                                                         "true" if args.mixed else "false",
-                                                                         "true" if args.hist32 else "false")
         if args.hist32:
             kernel_name = kernel_name.replace(">", ", fp32-difference history>", 1)
+    # the instantiation that ran, as the library names it (no guessing: trpl_kernel_name)
+    rocprof_name = "void " + trpl_amd._abi.kernel_name(S_total * C, L, T, flags)
     out = {
         "metric": "TRPL timesteps/sec at %d nodes (system = parameter sample x excitation; fused solve + "
                   "log-likelihood; parameter-sample likelihoods/sec in likelihoods_per_s_*)" % L,
@@ -310,7 +308,7 @@ def main():
         ln_ = np.ascontiguousarray(lens, dtype=np.float64)
         no_ = np.full(C, T + 1, dtype=np.int64)
         n_tab = trpl_amd._abi.lib().trpl_pair_table(ln_.ctypes.data, no_.ctypes.data, C, L, T, Time, *[t_.ctypes.data for t_ in tab])
-        out["roofline"]["wavefront_pairs"] = ("adjacent samples of one curve" if n_tab <= 0 or os.environ.get("TRPL_PAIR_CURVES") == "0" else
+        out["roofline"]["wavefront_pairs"] = ("adjacent samples of one curve" if n_tab <= 0 or (flags & trpl_amd._abi.FLAG_PAIR_ADJACENT) else
                                               [{"curves": [int(tab[0][k]), int(tab[2][k])], "sample_offsets": [int(tab[1][k]), int(tab[3][k])]}
                                                for k in range(n_tab)])
     if world > 1:

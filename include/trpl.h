@@ -34,7 +34,10 @@
 extern "C" {
 #endif
 
-#define TRPL_ABI_VERSION 3
+#define TRPL_ABI_VERSION 4   /* 4 (round 5): TRPL_FLAG_BDF_ORDER, TRPL_FLAG_PAIR_ALWAYS_SEAM / _PAIR_ADJACENT / _MULTI_FORCE_PAD (were
+                                process-wide environment switches), trpl_multi_create_ex, TRPL_PL_ENVELOPE_K_L512; floor_col = -2 for
+                                flagged systems, T <= 2^30 - 16, up to TRPL_MAX_CURVES curves and TRPL_FLAG_HIST32 (round 4, then
+                                still under version 3) */
 
 /* status codes */
 #define TRPL_OK 0
@@ -46,7 +49,16 @@ extern "C" {
 /* flags for the solver entry points */
 #define TRPL_FLAG_STRICT 0x1      /* bit-reproducible arithmetic: no FMA contraction, IEEE divides, the
                                      reference's operation order (state is bit-identical to the
-                                     sequentially executed reference); slower */
+                                     sequentially executed reference); 6.4x slower.
+                                     WITHOUT it (the default, "FAST": FMA contraction, v_rcp_f64 + refinement, cyclic reduction +
+                                     PCR, reordered sums) a system follows the reference's ITERATION PATH -- the same number of
+                                     inner iterations at every time step -- up to knife-edge decisions of the convergence test:
+                                     measured against STRICT, iteration totals are identical on every system over the bench window
+                                     (T = 8000: Power_scan x 64 x 3, Twothick x 32 x 6, L = 512 x 16 x 3 -- in the -m gpu suite
+                                     against the oracle, which allows one system one iteration) and differ by ONE iteration on 8 of
+                                     196 608 systems (in totals of ~160 000 each) over the reference's full window T = 80 000
+                                     (profiles/r4_validate_twothick_32768_T80000.txt); PL then agrees to the envelope stated at
+                                     trpl_loglik below */
 #define TRPL_FLAG_PL_F32 0x2      /* trpl_loglik*: round PL and log10 PL through fp32 exactly where the
                                      reference's float32 plI buffer does (bayeslib.py:137) */
 #define TRPL_FLAG_NORMALIZE 0x4   /* trpl_loglik*: self-normalise each PL curve to its t = 0 value
@@ -98,6 +110,24 @@ extern "C" {
                                      one-system fp64 stepper, L <= 128, to rounding (1e-9).  Not with _FP32 / _MIXED /
                                      _KERNEL_PAIR, and not in the trpl_loglik_multi* calls (a sharded batch would depend on
                                      where it is cut).  m = 1 (no bits set): every sample converges on its own */
+#define TRPL_FLAG_BDF_ORDER(k) ((uint32_t)((k) & 0x7) << 14)
+                                  /* cap the order of the BDF ramp (pvSimPCR.py:241-250: order min(t + 1, 5) at step t) at
+                                     k = 1 .. 5: step t takes the coefficient row of step min(t, k - 1).  No bits set (k = 0): the
+                                     reference's ramp.  k = 2 is the time discretisation of the reference's older solver
+                                     Legacy/pvSim.py:94-97 (Euler at t = 0, BDF2 ever after), which with CN = CP = 0 makes that
+                                     file a WHOLE-CURVE parity reference for every stepper here (tests/golden/legacy_full.npz);
+                                     k = 1 is implicit Euler.  Every arithmetic mode and kernel; k > 5 is TRPL_ERR_ARG.  A
+                                     wave-uniform select of the coefficient row outside the iterations: no cost when off */
+#define TRPL_FLAG_PAIR_ALWAYS_SEAM 0x20000  /* test / measurement: the two-systems-per-wavefront stepper clears every value that
+                                     crosses the seam between its two systems in EVERY iteration (the form rounds 1-3 shipped)
+                                     instead of only when a time step is repeated ("optimistic seam", round 4).  Results are
+                                     bit-identical either way -- this is the reference side of the differential tests on hostile
+                                     inputs; ~1.6 % slower.  Ignored by the other kernels */
+#define TRPL_FLAG_PAIR_ADJACENT 0x40000     /* measurement: the two-systems-per-wavefront stepper pairs adjacent samples of one curve
+                                     (the round-2 rule) instead of two curves of one sample (trpl_pair_table); a scheduling
+                                     matter only, results are bit-identical either way */
+#define TRPL_FLAG_MULTI_FORCE_PAD 0x80000   /* trpl_loglik_multi_dev, tests: take the padded all-gather + unpadding pass even when
+                                     the shards are equal */
 #define TRPL_FLAG_KERNEL_PAIR 0x10    /* run the two-systems-per-wavefront stepper whatever the launch size (L = 128,
                                         fp64, not STRICT -- anything else is TRPL_ERR_ARG) */
 #define TRPL_FLAG_KERNEL_SINGLE 0x20  /* run the one-system-per-wavefront stepper whatever the launch size */
@@ -117,6 +147,11 @@ extern "C" {
 #define TRPL_KERNEL_MIXED 4
 #define TRPL_KERNEL_HIST32 5
 int trpl_kernel_variant(int64_t nsys, int32_t L, int64_t steps, uint32_t flags);
+/* The C++ name (namespace, template arguments; no return type, no parameter list) of the time-stepper kernel such a launch runs
+ * -- the name rocprofv3's kernel trace lists it under, after "void " -- written to buf as a NUL-terminated string.  snapshots
+ * != 0: a launch with state snapshots or a resume (their own instantiation).  bench.py names its `roofline.rocprof_name` with
+ * it instead of guessing the instantiation. */
+int trpl_kernel_name(int64_t nsys, int32_t L, int64_t steps, uint32_t flags, int32_t snapshots, char *buf, int64_t buflen);
 
 /* Who shares a wavefront in the two-systems-per-wavefront stepper of a fused on-grid likelihood launch (a scheduling
  * matter only: a system's bits do not depend on its partner).  Curves with the same thickness and observation count
@@ -273,9 +308,13 @@ int trpl_loglik_from_pl_dev(const void *plI, int32_t elem_bytes, int64_t rows, i
  *               r(t) = PL(t) / (B L n0 p0)        (mean excess product per node over the equilibrium product)
  *           this library's default arithmetic and the reference's order of operations (TRPL_FLAG_STRICT, the
  *           sequentially executed reference bit for bit) agree to
- *               |dPL / PL|  <=  1e-9 + K / r(t),    K = TRPL_PL_ENVELOPE_K_THICK = 5e-13 on the 2000 nm films (L = 128),
- *                                                   K = TRPL_PL_ENVELOPE_K_THIN  = 1e-11 on the 311 nm films
- *           (K grows with the stencil's stiffness D dt / dx^2; measured 2e-13 / 3.7e-12, tests hold the constants).
+ *               |dPL / PL|  <=  1e-9 + K / r(t),    K = TRPL_PL_ENVELOPE_K_THICK = 5e-13 on the 2000 nm films at L = 128,
+ *                                                   K = TRPL_PL_ENVELOPE_K_THIN  = 1e-11 on the 311 nm films at L = 128,
+ *                                                   K = TRPL_PL_ENVELOPE_K_L512  = 2e-12 on the 2000 nm film at L = 512
+ *           (K grows with the stencil's stiffness D dt / dx^2 -- the three grids have dx = 15.6, 2.43 and 3.9 nm; measured
+ *           2e-13 / 3.7e-12 / < 2e-12 with the r-independent part at 5.5e-12 for L = 512; the -m gpu tests assert exactly
+ *           these constants: tests/gpu_common.py, tests/test_gpu_l512.py, and tests/test_abi.py that header, binding and
+ *           tests agree).
  *           floor_col[c][s] = first compared PL column (observation index; the grid step with off-grid observations)
  *           with r < TRPL_PL_FLOOR_EXCESS = 1e-4 or a non-positive / NaN PL; -1 if there is none; -2 for a system
  *           flagged as non-converged (status != 0: sse = +inf, nothing to compare).
@@ -289,6 +328,7 @@ int trpl_loglik_from_pl_dev(const void *plI, int32_t elem_bytes, int64_t rows, i
 #define TRPL_PL_FLOOR_EXCESS 1e-4
 #define TRPL_PL_ENVELOPE_K_THICK 5e-13
 #define TRPL_PL_ENVELOPE_K_THIN 1e-11
+#define TRPL_PL_ENVELOPE_K_L512 2e-12
 #define TRPL_MAX_CURVES 1024
 int trpl_loglik(const double *X, int64_t S, int32_t C, const double *lengths_nm, double time_ns,
                 int32_t L, int64_t T, int32_t plT, int32_t tol_exp, int32_t max_iter,
@@ -372,6 +412,11 @@ int trpl_loglik_multi(const double *X, int64_t S, int32_t C, const double *lengt
  * ------------------------------------------------------------------------------------- */
 typedef struct trpl_multi trpl_multi_t;
 int trpl_multi_create(const int32_t *devices, int32_t n_devices, trpl_multi_t **handle);
+/* trpl_multi_create with options.  TRPL_MULTI_ALLOW_DUPLICATE_DEVICES: a device ordinal may be listed more than once (one
+ * "rank" and stream each) -- for tests that run several ranks on one GPU against a stand-in collective library named by
+ * TRPL_RCCL_LIBRARY (tests/mock_rccl); real RCCL refuses duplicate devices. */
+#define TRPL_MULTI_ALLOW_DUPLICATE_DEVICES 0x1
+int trpl_multi_create_ex(const int32_t *devices, int32_t n_devices, uint32_t create_flags, trpl_multi_t **handle);
 int trpl_multi_destroy(trpl_multi_t *handle);
 int trpl_multi_device_count(const trpl_multi_t *handle);
 int trpl_multi_synchronize(trpl_multi_t *handle);

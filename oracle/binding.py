@@ -44,6 +44,8 @@ class OracleLib:
         d.oracle_fastlog.restype = None
         d.oracle_prob.argtypes = [_dp, C.c_void_p, C.c_int, C.c_long, C.c_long, C.c_long, _dp, _dp]
         d.oracle_prob.restype = None
+        d.oracle_set_max_order.argtypes = [C.c_int]
+        d.oracle_set_max_order.restype = C.c_int
 
 
 def build(force=False):
@@ -113,10 +115,19 @@ def scales(length, time_ns, L, T):
 
 
 def pvsim(mat12, length, time_ns, L, T, ini, plT=1, tol=7, MAX=10000, dtype=np.float64, nthreads=1,
-          want_step_iters=False, snap_steps=None, mspb=1):
+          want_step_iters=False, snap_steps=None, mspb=1, max_order=5):
     """pvSim(..., init_mode="points") semantics.  Returns dict(plI, status, iters_total, iters_max[, step_iters]
     [, plN, plP, plE: the state at the time steps snap_steps, pvSimPCR.py:283-288 / Legacy/pvSim.py:121-126]).
-    mspb > 1: max_sims_per_block consecutive samples share one convergence test (pvSimPCR.py:213-216,:258-266)."""
+    mspb > 1: max_sims_per_block consecutive samples share one convergence test (pvSimPCR.py:213-216,:258-266).
+    max_order < 5 caps the BDF order ramp of pvSimPCR.py:241-250 (2: Euler, then BDF2 -- Legacy/pvSim.py:94-97)."""
+    old_order = load().dll.oracle_set_max_order(int(max_order))
+    try:
+        return _pvsim(mat12, length, time_ns, L, T, ini, plT, tol, MAX, dtype, nthreads, want_step_iters, snap_steps, mspb)
+    finally:
+        load().dll.oracle_set_max_order(old_order)
+
+
+def _pvsim(mat12, length, time_ns, L, T, ini, plT, tol, MAX, dtype, nthreads, want_step_iters, snap_steps, mspb):
     mat12 = _f64(mat12)
     S = mat12.shape[0]
     assert mat12.shape[1] == 12

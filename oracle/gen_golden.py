@@ -13,8 +13,10 @@ Reference entry points exercised (file:line):
   probs.fastlog :78-85, probs.prob :49-62                   -> probs.npz
   bayeslib.random_grid :18-32, bayeslib.bayes :207-252      -> bayes_e2e.npz, sampler.npz
   pvSim_fallback.pvSim_cpu_fallback :80-117 (as shipped)    -> fallback.npz
+  bayeslib.bayes(pvSim_cpu_fallback) CPU branch, 64 samples x 3 curves, 8 array tasks -> fallback64.npz (configs[0])
   bayes_io.get_initpoints :106-119, get_data :15-104 + bayes -> bayes_realdata.npz
   Legacy/pvSim.pvSim :129-173; Testing/PV_tester2.dydt :13-49 + odeint -> legacy_odeint.npz
+  Legacy/pvSim.pvSim :129-173 over whole curves (2400 steps, 4 films x 9 samples)  -> legacy_full.npz
   Visualization/utils.py normalize :157-166, w_* :185-226, covariance :222-227, credible_interval :185-196,
   marginalize_1D :239-262, marginalize_2D :264-285 (tempering: marginalization_visual.py:589-591) -> posterior.npz
 
@@ -266,6 +268,101 @@ def case_fallback():
                         length=2000.0, L=128, plI=pl, seconds=np.array(secs))
 
 
+OBS_BALANCED = os.path.join(REF, "Example Data", "Balancedhighsurf_Power_scan_Observations.csv")
+
+
+def _fallback64_task(job):
+    """One SLURM array task of the reference's own distribution (bayeslib.py:131,:231): bayes() with the CPU model,
+    has_GPU False, num_gpus = the number of tasks, sims_per_gpu = its block of samples.  The model handed to bayes() is
+    pvSim_fallback.pvSim_cpu_fallback as shipped behind a recorder that keeps what each call wrote (in fp64; bayes's own
+    buffer is float32, bayeslib.py:137) and the seconds it returned."""
+    from pvSim_fallback import pvSim_cpu_fallback
+    from bayes_io import get_data
+    task, ntasks, S, T, Time, cutoff = job
+    os.environ["SLURM_ARRAY_TASK_ID"] = str(task)
+    for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[v] = "1"
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=1)                            # noqa: F841  (one BLAS thread per task)
+    except ImportError:
+        pass
+    ic_flags = {"time_cutoff": cutoff, "select_obs_sets": None, "noise_level": None}
+    sim_flags = {"load_PL_from_file": False, "override_equal_auger": False, "override_equal_mu": False,
+                 "override_equal_s": False, "log_pl": True, "self_normalize": False,
+                 "random_sample": True, "num_points": S}
+    ini = get_initpoints(EXC_POWER, ic_flags)
+    e_data = get_data([OBS_BALANCED], ic_flags, sim_flags, scale_f=1e-23)
+    calls = []
+
+    def model(plI, matPar, simPar, init_dN):                             # bayeslib.py:148 call form
+        pl64 = np.empty(plI.shape)
+        sec = pvSim_cpu_fallback(pl64, matPar, simPar, init_dN)
+        plI[:] = pl64                                                    # the cast pvSim_fallback.py:113 makes into bayes's buffer
+        calls.append((pl64, sec))
+        return sec
+
+    gpu_info = {"sims_per_gpu": S // ntasks, "num_gpus": ntasks, "has_GPU": False}
+    simPar = [2000, Time, 128, T, 1, PT, 7, 10000]
+    np.random.seed(42)                                                   # parallel_bayes_gpu.py:35
+    t0 = time.time()
+    N, P, X = bayeslib.bayes(model, np.array([0]), None, MINX * UNIT, MAXX * UNIT, DO_LOG, ini, simPar, e_data,
+                             sim_flags, gpu_info, logger=None)
+    wall = time.time() - t0
+    return task, P, X, [c[0] for c in calls], [c[1] for c in calls], wall, e_data
+
+
+def _run_fallback64(T, Time, cutoff, ntasks=8, S=64):
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(ntasks) as pool:
+        t0 = time.time()
+        res = pool.map(_fallback64_task, [(k, ntasks, S, T, Time, cutoff) for k in range(ntasks)], chunksize=1)
+        wall = time.time() - t0
+    res.sort(key=lambda r: r[0])
+    X = res[0][2]
+    assert all(np.array_equal(r[2], X) for r in res)
+    P = sum(r[1] for r in res)                                           # every task leaves the other blocks zero (bayeslib.py:131)
+    blk = S // ntasks
+    pl = np.empty((3, S, T + 1))
+    secs = np.empty((3, ntasks))
+    for k, r in enumerate(res):
+        assert len(r[3]) == 3                                            # one model call per curve (one block per task)
+        for c in range(3):
+            pl[c, k * blk:(k + 1) * blk] = r[3][c]
+            secs[c, k] = r[4][c]
+    return X, P, pl, secs, np.array([r[5] for r in res]), wall, res[0][6]
+
+
+def case_fallback64():
+    """BASELINE.json configs[0] as worded: Power_scan (3 excitations, 128 nodes) x 64 random parameter samples on the CPU
+    through the reference's own CPU path -- bayeslib.bayes(pvSim_fallback.pvSim_cpu_fallback, ...) with has_GPU False
+    (bayeslib.py:148,:158-161,:198-201), observations = the shipped Balancedhighsurf_Power_scan_Observations.csv read by
+    bayes_io.get_data -- run the way the reference distributes work: one SLURM array task per block of samples
+    (bayeslib.py:131,:231; here 8 tasks x 8 samples on the container's 8 cores, their P arrays summed).  Two windows: the
+    bench's (T = 8000 steps = 200 ns; observations cut at 200 ns) and the reference's full one (T = 80 000, 2000 ns).
+    Stored: X, the CPU-branch likelihoods P, PL(t) of all 192 systems (float32, every 8th / 80th column; the first two
+    samples' first 401 columns in fp64), the seconds every model call returned, wall time, the core count, and the
+    observation values the likelihood was taken against (log10, bayes_io.py:67-77)."""
+    ncores = os.cpu_count()
+    out = {"ntasks": 8, "cores": ncores, "L": 128, "length": 2000.0}
+    with open("/proc/cpuinfo") as fh:
+        models = [ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")]
+    out["cpu_model"] = np.array(models[0] if models else "unknown")
+    for tag, T, Time, cutoff, dec in (("w8k", 8000, 200.0, 200, 8), ("full", 80000, 2000.0, 2000, 80)):
+        X, P, pl, secs, task_wall, wall, e_data = _run_fallback64(T, Time, cutoff)
+        out.update({"X": X, f"{tag}_T": T, f"{tag}_time": Time, f"{tag}_P": P, f"{tag}_dec": dec,
+                    f"{tag}_pl32": pl[:, :, ::dec].astype(np.float32), f"{tag}_pl_head": pl[:, :2, :401].copy(),
+                    f"{tag}_model_seconds": secs, f"{tag}_task_wall": task_wall, f"{tag}_wall": wall})
+        for c in range(3):
+            t, v = np.asarray(e_data[0][0][c]), np.asarray(e_data[0][1][c])
+            assert np.allclose(t, 0.025 * np.arange(len(t)), rtol=0, atol=1e-9)     # a prefix of the simulation grid
+            out[f"{tag}_obs_{c}"] = v
+        print("fallback64 %s: wall %.1f s on %d tasks; model seconds per (sample x curve): %.3f" %
+              (tag, wall, 8, secs.sum() / (64 * 3)), flush=True)
+    out["ini"] = get_initpoints(EXC_POWER, {"select_obs_sets": None})
+    np.savez_compressed(os.path.join(OUT, "fallback64.npz"), **out)
+
+
 def case_bayes_realdata():
     """The reference's own ingestion (bayes_io.get_initpoints / get_data on the shipped example
     files, bayes_io.py:15-119) feeding bayeslib.bayes: experiment 0 = the shipped
@@ -375,6 +472,50 @@ def case_legacy_odeint():
                         pT=np.array(pT), plN_legacy=plN, plP_legacy=plP, plE_legacy=plE)
 
 
+LEGACY_FULL_FILMS = ((2000.0, 1.273836e16), (2000.0, 1.153946e17), (2000.0, 1.648494e18), (311.0, 1.648494e18))
+
+
+def _legacy_full_job(job):
+    """One film of case_legacy_full in a worker process: Legacy/pvSim.pvSim as shipped."""
+    import contextlib
+    import io
+    sys.path.insert(0, os.path.join(REF, "Legacy"))
+    import pvSim as legacy
+    m10, simPar, a_nm3, l_nm = job
+    t0 = time.time()
+    with contextlib.redirect_stdout(io.StringIO()):
+        itrs, (plN, plP, plE, plI) = legacy.pvSim(m10.copy(), simPar, (a_nm3, l_nm))
+    return np.array(itrs), plN, plP, plE, plI, time.time() - t0
+
+
+def case_legacy_full():
+    """WHOLE-CURVE fixture of the second solver the north star names: Legacy/pvSim.pvSim (:129-173, iterate :36-88, Thomas
+    solve :14-34) -- Euler at t = 0, BDF2 from t = 1 on (:94-97), no Auger terms -- over 2400 steps (60 ns at the
+    reference's dt = 0.025 ns) on the three Power_scan excitations (Beer-Lambert profiles A exp(-x / l), A as fitted to
+    Example Data/Power_scan_Excitations.csv; Legacy's own "exp" initialisation) of a 2000 nm film and the
+    strongest one on a 311 nm film (Twothick's thin film), x 8 random samples of the box + the marked point.  With the
+    BDF order capped at 2 and CN = CP = 0 pvSimPCR.py discretises the same equations the same way, so
+    this pins the discretisation through an implementation that shares no code with pvSimPCR.py."""
+    import multiprocessing as mp
+    X = np.vstack([draw(8), MARK * UNIT])
+    m10 = X[:, [0, 1, 2, 3, 4, 5, 6, 9, 10, 11]]                        # no CN, CP
+    L, T, dt = 128, 2400, 0.025
+    Time = T * dt
+    l_nm = 1.0 / 6.000e-3
+    pT = (2, 240, 2400)                                                  # 0.1 %, 10 %, 100 % of the window
+    jobs = [(m10, [length, Time, L, T, 1, pT, 7, 10000], a * 1e-21, l_nm) for length, a in LEGACY_FULL_FILMS]
+    with mp.get_context("fork").Pool(len(jobs)) as pool:
+        res = pool.map(_legacy_full_job, jobs, chunksize=1)
+    # PL columns kept: every step of the first 200 (BDF start-up, the stiff first steps), every 5th afterwards
+    cols = np.concatenate([np.arange(0, 200), np.arange(200, T + 1, 5)])
+    np.savez_compressed(os.path.join(OUT, "legacy_full.npz"), X=X, L=L, T=T, time=Time, l_nm=l_nm,
+                        lengths=np.array([f[0] for f in LEGACY_FULL_FILMS]),
+                        a_nm3=np.array([f[1] * 1e-21 for f in LEGACY_FULL_FILMS]), pT=np.array(pT), cols=cols,
+                        iters_max=np.array([r[0] for r in res]), plN=np.array([r[1] for r in res]),
+                        plP=np.array([r[2] for r in res]), plE=np.array([r[3] for r in res]),
+                        plI=np.array([r[4][:, cols] for r in res]), seconds=np.array([r[5] for r in res]))
+
+
 def case_posterior():
     """The numeric core of the GUI that consumes *_BAYRAN_{P,X}.npy, run as shipped (statsmodels stand-in:
     refshim/statsmodels, only needed for the module-level import)."""
@@ -428,10 +569,10 @@ def case_posterior():
                         pairs=np.array([[names.index(a), names.index(b)] for a, b in pairs]), h2=np.stack(h2))
 
 
-CASES = {"posterior": case_posterior, "legacy_odeint": case_legacy_odeint, "csv_fixture": case_csv_fixture, "bayes_realdata": case_bayes_realdata, "pcr_norm": case_pcr_norm, "probs": case_probs, "sampler": case_sampler,
+CASES = {"posterior": case_posterior, "legacy_odeint": case_legacy_odeint, "legacy_full": case_legacy_full, "csv_fixture": case_csv_fixture, "bayes_realdata": case_bayes_realdata, "pcr_norm": case_pcr_norm, "probs": case_probs, "sampler": case_sampler,
          "pvsim_small": case_pvsim_small, "pvsim_power": case_pvsim_power, "pvsim_bundle": case_pvsim_bundle,
          "pvsim_twothick": case_pvsim_twothick, "bayes_e2e": case_bayes_e2e,
-         "fallback": case_fallback}
+         "fallback": case_fallback, "fallback64": case_fallback64}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

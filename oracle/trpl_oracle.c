@@ -266,9 +266,17 @@ static int iterate(sysws *w, const double *mp, const double *a, int k, int kp,
     return iterate_bundle(w, 1, mp, a, k, kp, ko, TOL, MAX);
 }
 
-/* BDF coefficient table, tEvol pvSimPCR.py:241-250 */
+/* BDF coefficient table, tEvol pvSimPCR.py:241-250: step t uses order min(t + 1, 5).
+ * g_max_order (oracle_set_max_order, default 5 = the reference) caps the order: step t then takes the row of step
+ * min(t, max_order - 1).  max_order = 2 is the scheme of the reference's older solver Legacy/pvSim.py:94-97 (Euler at
+ * t = 0, BDF2 ever after); with CN = CP = 0 the two files then discretise the same equations the same way and can be
+ * compared over a whole curve, not only on the steps where BDF2 and the ramp coincide. */
+static int g_max_order = 5;
+int oracle_set_max_order(int k) { int old = g_max_order; if (k >= 1 && k <= 5) g_max_order = k; return old; }
+
 static void bdf_coeffs(long t, double *a)
 {
+    if (t > g_max_order - 1) t = g_max_order - 1;
     if (t == 0)      { a[0] = 1.0;  a[1] = -1.0; a[2] = 0.0; a[3] = 0.0; a[4] = 0.0; a[5] = 0.0; }
     else if (t == 1) { a[0] = 1.5;  a[1] = -2.0; a[2] = 0.5; a[3] = 0.0; a[4] = 0.0; a[5] = 0.0; }
     else if (t == 2) { a[0] = 11.0 / 6; a[1] = -3.0; a[2] = 1.5; a[3] = -1.0 / 3; a[4] = 0.0; a[5] = 0.0; }

@@ -4,6 +4,7 @@ device is present.  No compute call is made here."""
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -24,7 +25,7 @@ def test_library_exports_every_declared_symbol(trpl):
     for n in names:
         assert hasattr(dll, n), n
     assert set(trpl._abi.SIGNATURES) == set(names)       # the binding covers the whole header
-    assert dll.trpl_abi_version() == 3
+    assert dll.trpl_abi_version() == 4 == trpl._abi.ABI_VERSION
 
 
 def test_cites_reference_interfaces():
@@ -306,10 +307,23 @@ def test_python_constants_equal_the_headers_defines():
              "TRPL_KERNEL_FAST": A.KERNEL_FAST, "TRPL_KERNEL_FAST_PAIR": A.KERNEL_FAST_PAIR, "TRPL_KERNEL_STRICT": A.KERNEL_STRICT,
              "TRPL_KERNEL_FP32": A.KERNEL_FP32, "TRPL_KERNEL_MIXED": A.KERNEL_MIXED, "TRPL_KERNEL_HIST32": A.KERNEL_HIST32,
              "TRPL_PL_FLOOR_EXCESS": A.PL_FLOOR_EXCESS, "TRPL_PL_ENVELOPE_K_THICK": A.PL_ENVELOPE_K_THICK,
-             "TRPL_PL_ENVELOPE_K_THIN": A.PL_ENVELOPE_K_THIN, "TRPL_ABI_VERSION": A.ABI_VERSION}
+             "TRPL_PL_ENVELOPE_K_THIN": A.PL_ENVELOPE_K_THIN, "TRPL_PL_ENVELOPE_K_L512": A.PL_ENVELOPE_K_L512,
+             "TRPL_ABI_VERSION": A.ABI_VERSION, "TRPL_FLAG_PAIR_ALWAYS_SEAM": A.FLAG_PAIR_ALWAYS_SEAM,
+             "TRPL_FLAG_PAIR_ADJACENT": A.FLAG_PAIR_ADJACENT, "TRPL_FLAG_MULTI_FORCE_PAD": A.FLAG_MULTI_FORCE_PAD,
+             "TRPL_MULTI_ALLOW_DUPLICATE_DEVICES": A.MULTI_ALLOW_DUPLICATE_DEVICES}
     for name, val in pairs.items():
         assert name in defs, name
         assert num(defs[name]) == val, (name, defs[name], val)
     flags = [v for k, v in pairs.items() if k.startswith("TRPL_FLAG_")]
     assert len(set(flags)) == len(flags) and all(f & (f - 1) == 0 for f in flags)          # distinct single bits
     assert not any(f & 0xF00 for f in flags)                                                # TRPL_FLAG_BUNDLE's field
+    assert not any(f & (7 << 14) for f in flags)                                            # TRPL_FLAG_BDF_ORDER's field
+    assert re.search(r"#define TRPL_FLAG_BDF_ORDER\(k\) \(\(uint32_t\)\(\(k\) & 0x7\) << 14\)", hdr)
+    assert [A.flag_bdf_order(k) for k in (None, 0, 1, 2, 5)] == [0, 0, 1 << 14, 2 << 14, 5 << 14]
+    with pytest.raises(ValueError):
+        A.flag_bdf_order(6)
+    # the envelope constants the -m gpu files assert are the header's (tests/gpu_common.py restates them)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import gpu_common as G
+    assert G.ENVELOPE_K_THICK == A.PL_ENVELOPE_K_THICK and G.ENVELOPE_K == {2000.0: A.PL_ENVELOPE_K_THICK, 311.0: A.PL_ENVELOPE_K_THIN}
+    assert G.ENVELOPE_K_L512 == A.PL_ENVELOPE_K_L512 and G.FLOOR == A.PL_FLOOR_EXCESS

@@ -1,0 +1,373 @@
+"""The likelihood side of the path (a-7 `fastlog`, a-8 `prob`, a-10 `simulate`, f-1 ingestion and observation-time mapping):
+the stand-alone kernels against the reference's goldens (prob bit-exact, log10 to 1 ulp), the unfused drop-in sequence and the
+fused trpl_loglik / trpl_loglik_obs / trpl_loglik_from_pl_dev against bayeslib.bayes's golden likelihoods and the oracle's
+restatement of bayeslib.simulate -- on-grid and off-grid observation times, self-normalisation, the reference's float32 PL
+staging, real example data, more than sixteen curves per call."""
+import os
+
+import numpy as np
+import pytest
+
+from gpu_common import DT, nthreads
+
+pytestmark = pytest.mark.gpu
+
+
+# ----------------------------------------------------------------------------- probs
+def test_fastlog_and_prob_vs_reference_golden(gpu, golden):
+    g = golden("probs")
+    l64 = g["pl64"].copy()
+    assert gpu.fastlog(l64, float(g["MIN"]), 128, 256) > 0
+    assert np.max(np.abs(l64 - g["log64"])) <= 2e-16 * np.max(np.abs(g["log64"]))
+    l32 = g["pl32"].copy()
+    gpu.fastlog(l32, float(g["MIN"]))
+    assert l32.dtype == np.float32 and np.max(np.abs(l32 - g["log32"]) / np.abs(g["log32"])) <= 2.0 ** -23
+    P = g["P64_in"].copy()
+    assert gpu.prob(P, g["log64"], g["values"], np.ones(37), g["mag"], 128, 256) > 0
+    assert np.array_equal(P, g["P64"])                               # serial order kept: bit-exact
+    P = np.zeros(5)
+    gpu.prob(P, g["log32"], g["values"], None, g["mag"])
+    assert np.array_equal(P, g["P32"])
+
+
+def test_fastlog_prob_edge_cases(gpu, oracle):
+    x = np.array([[0.0, -1.0, 1e-3]], dtype=np.float32)
+    gpu.fastlog(x)
+    assert np.isneginf(x[0, 0]) and np.isneginf(x[0, 1])             # (float)DBL_MIN == 0
+    rng = np.random.default_rng(11)
+    rows, cols = 131, 203                                            # ragged vs the 64x64 tiles
+    big = rng.lognormal(-5, 2, (rows, cols + 9))
+    view = big[:, 3:3 + cols]                                        # non-contiguous rows (ld > cols)
+    want = view.copy(); oracle.fastlog(want)
+    gpu.fastlog(view)
+    assert np.max(np.abs(view - want)) <= 4e-16 * np.max(np.abs(want))
+    assert np.array_equal(big[:, :3], big[:, :3]) and np.all(big[:, cols + 3:] > 0)
+    values = rng.uniform(-9, -1, cols); mag = rng.uniform(-1, 1, rows)
+    Pfull = np.zeros((2, rows + 5))
+    gpu.prob(Pfull[1, 2:2 + rows], want, values, None, mag)          # a view into P, like bayeslib.py:195
+    Pw = np.zeros(rows); oracle.prob(Pw, want, values, mag)
+    assert np.array_equal(Pfull[1, 2:2 + rows], Pw) and not Pfull[0].any() and not Pfull[1, :2].any()
+    P0 = np.ones(3); gpu.prob(P0, np.zeros((3, 0)), np.zeros(0), None, np.zeros(3))
+    assert np.array_equal(P0, np.ones(3))
+
+
+# ----------------------------------------------------------------------------- end to end
+def _e2e_inputs(g):
+    T, tg, npre = int(g["T"]), g["tgrid"], int(g["npre"])
+    e_data = [([tg] * 3, list(g["obs0"]), [None] * 3), ([tg[:npre]] * 3, list(g["obs1"]), [None] * 3)]
+    flags = {"load_PL_from_file": False, "log_pl": True, "self_normalize": False}
+    return T, e_data, flags
+
+
+def test_simulate_unfused_vs_reference_bayes_golden(gpu, golden):
+    g = golden("bayes_e2e")
+    T, e_data, flags = _e2e_inputs(g)
+    X = g["X"]
+    P = np.zeros((2, len(X)))
+    z = np.zeros(1)
+    sim_params = [float(g["length"]), float(g["time"]), 128, T, 1, (0,), 7, 10000]
+    gpu.simulate(gpu.pvSim, e_data, P, X, [None], [None], 3, sim_params, g["ini"], flags,
+                 {"sims_per_gpu": 4, "num_gpus": 1}, 0, z.copy(), z.copy(), z.copy())
+    # fp32 PL buffer: one float32 ulp of log10 PL (~1e-7 * |log PL| ~ 7e-7) enters each residual
+    assert np.max(np.abs(P - g["P"]) / np.abs(g["P"])) < 2e-5
+
+
+def test_fused_loglik_vs_reference_and_oracle(gpu, oracle, golden):
+    g = golden("bayes_e2e")
+    T, e_data, flags = _e2e_inputs(g)
+    X = g["X"]
+    for e in range(2):
+        obs = [e_data[e][1][c] for c in range(3)]
+        info = {}
+        P32 = gpu.loglik(X, g["ini"], 2000.0, float(g["time"]), 128, T, obs, pl_f32=True, info=info)
+        assert not info["status"].any()
+        assert np.max(np.abs(P32 - g["P"][e]) / np.abs(g["P"][e])) < 2e-5
+        # full fp64 (no float32 staging) against the oracle run with a float64 buffer
+        e64 = [([g["tgrid"][:len(o)] for o in obs], obs)]
+        want = oracle.simulate_loglik(X, g["ini"], 2000.0, float(g["time"]), 128, T, e64, pl_dtype=np.float64,
+                                      nthreads=4)[0]
+        for strict, tol in ((True, 1e-11), (False, 1e-8)):
+            P64 = gpu.loglik(X, g["ini"], 2000.0, float(g["time"]), 128, T, obs, strict=strict)
+            assert np.max(np.abs(P64 - want) / np.abs(want)) < tol
+    # simulate() in fused mode accumulates into P exactly like the unfused loop
+    P = np.zeros((2, len(X))); z = np.zeros(1)
+    sim_params = [2000.0, float(g["time"]), 128, T, 1, (0,), 7, 10000]
+    gpu.simulate(gpu.pvSim, e_data, P, X, [None], [None], 3, sim_params, g["ini"], flags,
+                 {"sims_per_gpu": 4, "num_gpus": 1, "fused": True}, 0, z.copy(), z.copy(), z.copy())
+    assert np.max(np.abs(P - g["P"]) / np.abs(g["P"])) < 2e-5
+
+
+def test_fused_loglik_twothick_normalize_and_nonconvergence(gpu, oracle):
+    w = gpu.workloads
+    ini, lens = w.twothick(128)
+    X = w.samples(6)
+    X[:, -1] = np.linspace(-0.3, 0.3, 6)
+    T, Time = 40, 1.0
+    ref = [oracle.pvsim((w.MARKED_POINT * gpu.UNIT_CONVERSIONS)[None, :-1], lens[c], Time, 128, T, ini[c])["plI"][0]
+           for c in range(6)]
+    obs = [np.log10(r / r[0])[: T + 1 - 3 * c] for c, r in enumerate(ref)]          # ragged n_obs
+    e_data = [([np.linspace(0, Time, T + 1)[:len(o)] for o in obs], obs)]
+    want = oracle.simulate_loglik(X, ini, lens, Time, 128, T, e_data, pl_dtype=np.float64, normalize=True,
+                                  nthreads=4)[0]
+    info = {}
+    Ps = gpu.loglik(X, ini, lens, Time, 128, T, obs, normalize=True, strict=True, info=info)
+    assert np.max(np.abs(Ps - want) / np.abs(want)) < 1e-10
+    P = gpu.loglik(X, ini, lens, Time, 128, T, obs, normalize=True)
+    assert np.max(np.abs(P - want) / np.abs(want)) < 1e-8
+    # non-convergence: pick MAX from the oracle's per-sample iteration maxima so that some samples
+    # fail and some do not; a failing sample gets -inf, the others are bit-identical to the full run
+    imax = np.array([oracle.pvsim(X[:, :-1], lens[c], Time, 128, T, ini[c])["iters_max"] for c in range(6)]).max(0)
+    MAXc = int(np.sort(imax)[len(imax) // 2])
+    expect_bad = imax >= MAXc
+    assert expect_bad.any() and not expect_bad.all()
+    Pn = gpu.loglik(X, ini, lens, Time, 128, T, obs, normalize=True, strict=True, MAX=MAXc, info=info)
+    bad = info["status"].any(axis=0)
+    assert np.array_equal(bad, expect_bad)
+    assert np.all(np.isneginf(Pn[bad])) and np.array_equal(Pn[~bad], Ps[~bad])
+
+
+def test_fused_loglik_real_data_and_offgrid_times(gpu, oracle, golden):
+    """Shipped example data through this repo's own ingestion, then the fused kernel: on-grid
+    experiment (trpl_loglik) and irregular off-grid observation times (trpl_loglik_obs, the
+    in-kernel form of the reference's per-row griddata) against the reference's bayes() output."""
+    import os
+    from conftest import GOLDEN
+    g = golden("bayes_realdata")
+    T, Time, X = int(g["T"]), float(g["time"]), g["X"]
+    ini = gpu.get_initpoints(os.path.join(GOLDEN, "exc_power_scan.csv"), {"select_obs_sets": None})
+    e0 = gpu.get_data([os.path.join(GOLDEN, "obs_balanced_6ns.csv")],
+                      {"time_cutoff": 5, "select_obs_sets": None, "noise_level": None},
+                      {"log_pl": True, "self_normalize": False})[0]
+    t1 = [g[f"t_1_{c}"] for c in range(3)]; v1 = [g[f"v_1_{c}"] for c in range(3)]
+    # float32-staged, like the reference's buffer
+    P0 = gpu.loglik(X, ini, 2000.0, Time, 128, T, e0[1], pl_f32=True)
+    P1 = gpu.loglik(X, ini, 2000.0, Time, 128, T, v1, times=t1, pl_f32=True)
+    assert np.max(np.abs(P0 - g["P"][0]) / np.abs(g["P"][0])) < 2e-5
+    assert np.max(np.abs(P1 - g["P"][1]) / np.abs(g["P"][1])) < 2e-5
+    # full fp64 against the oracle with a float64 buffer (scipy griddata on the CPU side)
+    want = oracle.simulate_loglik(X, ini, 2000.0, Time, 128, T, [(t1, v1)], pl_dtype=np.float64, nthreads=4)[0]
+    for strict, tol in ((True, 1e-11), (False, 1e-8)):
+        info = {}
+        P64 = gpu.loglik(X, ini, 2000.0, Time, 128, T, v1, times=t1, strict=strict, info=info)
+        assert not info["status"].any() and np.max(np.abs(P64 - want) / np.abs(want)) < tol
+    # the device-resident entry point (torch tensors) gives the same numbers as the host-buffer one
+    import torch
+    from trpl_amd import device as tdev
+    dev = torch.device("cuda", 0)
+    sim_t = np.linspace(0, Time, T + 1)
+    br = [gpu.bracket_times(sim_t, t) for t in t1]
+    n1 = len(t1[0])
+    td = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
+    Pd = torch.zeros(len(X), dtype=torch.float64, device=dev); ssed = torch.empty((3, len(X)), dtype=torch.float64, device=dev)
+    tdev.loglik_obs_device(td(X, torch.float64), td(ini, torch.float64), 2000.0, Time, 128, T, td(np.array(v1), torch.float64),
+                           td(np.array([b[0] for b in br]), torch.int32), td(np.array([b[1] for b in br]), torch.float64),
+                           td(np.array([b[2] for b in br]), torch.float64), [n1] * 3, Pd, ssed)
+    assert np.array_equal(Pd.cpu().numpy(), P64)
+    # unsorted input is sorted by time; observation order does not matter beyond rounding
+    perm = np.random.default_rng(0).permutation(len(t1[0]))
+    Pp = gpu.loglik(X, ini, 2000.0, Time, 128, T, [v1[0][perm], v1[1], v1[2]], times=[t1[0][perm], t1[1], t1[2]])
+    assert np.allclose(Pp, P64, rtol=1e-12)
+    with pytest.raises(ValueError):
+        gpu.loglik(X, ini, 2000.0, Time, 128, T, v1, times=[t1[0] + 1.0, t1[1], t1[2]])
+    # simulate() in fused mode picks the right entry point per experiment
+    e_data = [e0, (t1, v1, [None] * 3)]
+    P = np.zeros((2, len(X))); z = np.zeros(1)
+    gpu.simulate(gpu.pvSim, e_data, P, X, [None], [None], 3, [2000.0, Time, 128, T, 1, (0,), 7, 10000], ini,
+                 {"load_PL_from_file": False, "log_pl": True, "self_normalize": False},
+                 {"sims_per_gpu": 3, "num_gpus": 1, "fused": True}, 0, z.copy(), z.copy(), z.copy())
+    assert np.max(np.abs(P - g["P"]) / np.abs(g["P"])) < 2e-5
+    # ... and the unfused drop-in loop gives the same
+    P2 = np.zeros((2, len(X)))
+    gpu.simulate(gpu.pvSim, e_data, P2, X, [None], [None], 3, [2000.0, Time, 128, T, 1, (0,), 7, 10000], ini,
+                 {"load_PL_from_file": False, "log_pl": True, "self_normalize": False},
+                 {"sims_per_gpu": 3, "num_gpus": 1}, 0, z.copy(), z.copy(), z.copy())
+    assert np.max(np.abs(P2 - g["P"]) / np.abs(g["P"])) < 2e-5
+
+
+# ---- likelihood of PL rows resident in HBM (trpl_loglik_from_pl_dev): one solve, several experiments ----
+def test_loglik_from_resident_pl_equals_the_fused_kernel(trpl, gpu):
+    """solve_pl_device into an HBM buffer + loglik_from_pl_device per observation set == the fused kernel
+    (same PL, same log10 / staging / interpolation rules; the squared errors are summed in another order):
+    fp64 and float32 staging, self-normalisation, on- and off-grid times, a flagged system, two experiments
+    on one solve."""
+    import torch
+    tdev = trpl.device
+    S, T, Time, L = 300, 160, 4.0, 128
+    X = trpl.workloads.samples(S, seed=9)
+    X[:, 12] = np.linspace(-0.3, 0.4, S)                                   # non-trivial log offsets
+    ini, lengths = trpl.workloads.power_scan(L)
+    dev = torch.device("cuda", 0)
+    X_d = torch.from_numpy(X).to(dev)
+    mat_d, mag_d = X_d[:, :12].contiguous(), X_d[:, 12].contiguous()
+    ini_d = torch.from_numpy(ini).to(dev)
+    rng = np.random.default_rng(3)
+    sim_t = np.linspace(0, Time, T + 1)
+    obs_on = [19.0 - 0.02 * np.arange(100), 19.5 - 0.01 * np.arange(T + 1), 20.0 - 0.03 * np.arange(7)]
+    t_off = [np.sort(rng.uniform(0, Time, n)) for n in (50, 1, 33)]
+    obs_off = [19.0 + 0.1 * rng.standard_normal(len(t)) for t in t_off]
+    for pl_dtype, f32 in ((torch.float64, False), (torch.float32, True)):
+        for normalize in (False, True):
+            flags = trpl._abi.FLAG_NORMALIZE if normalize else 0
+            want_on = trpl.loglik(X, ini, lengths, Time, L, T, obs_on, pl_f32=f32, normalize=normalize)
+            want_off = trpl.loglik(X, ini, lengths, Time, L, T, obs_off, times=t_off, pl_f32=f32, normalize=normalize)
+            P_on = torch.zeros(S, dtype=torch.float64, device=dev)
+            P_off = torch.zeros(S, dtype=torch.float64, device=dev)
+            pl = torch.empty((S, T + 1), dtype=pl_dtype, device=dev)
+            st = torch.empty(S, dtype=torch.int32, device=dev)
+            for c in range(3):                                               # ONE solve per curve, two experiments on it
+                tdev.solve_pl_device(mat_d, lengths[c], Time, L, T, ini_d[c].contiguous(), pl, status=st)
+                tdev.loglik_from_pl_device(pl, torch.from_numpy(obs_on[c]).to(dev), mag_d, P=P_on, flags=flags, status=st)
+                hi, dx, h = trpl.bracket_times(sim_t, t_off[c])
+                tdev.loglik_from_pl_device(pl, torch.from_numpy(obs_off[c]).to(dev), mag_d, P=P_off, flags=flags, status=st,
+                                           obs_hi=torch.from_numpy(hi).to(dev), obs_dx=torch.from_numpy(dx).to(dev),
+                                           obs_h=torch.from_numpy(h).to(dev))
+            tol = 2e-6 if f32 else 1e-12          # float32 staging: (float)(pl/norm) here vs (float)pl/(float)norm fused
+            assert np.allclose(P_on.cpu().numpy(), want_on, rtol=tol, atol=0), (pl_dtype, normalize)
+            assert np.allclose(P_off.cpu().numpy(), want_off, rtol=tol, atol=0), (pl_dtype, normalize)
+    # a flagged system scores -inf, its neighbours are untouched
+    pl = torch.empty((S, T + 1), dtype=torch.float64, device=dev)
+    st = torch.empty(S, dtype=torch.int32, device=dev)
+    tdev.solve_pl_device(mat_d, lengths[2], Time, L, T, ini_d[2].contiguous(), pl, status=st, MAX=25)
+    assert 0 < int((st != 0).sum()) < S
+    sse = torch.empty(S, dtype=torch.float64, device=dev)
+    tdev.loglik_from_pl_device(pl, torch.from_numpy(obs_on[1]).to(dev), mag_d, sse=sse, status=st)
+    bad = (st != 0).cpu().numpy()
+    assert np.isinf(sse.cpu().numpy()[bad]).all() and np.isfinite(sse.cpu().numpy()[~bad]).all()
+    with pytest.raises(trpl.TrplError):
+        tdev.loglik_from_pl_device(pl, torch.zeros(T + 5, dtype=torch.float64, device=dev), mag_d, sse=sse)
+
+
+def test_fused_call_limits_sixteen_curves_and_strided_pl(trpl, gpu):
+    """Edge sizes of one fused call: the maximum of 16 curves (ragged observation counts) equals sixteen
+    one-curve calls accumulated in curve order; a 17th curve is a second launch of the same call; plT > 1 in a launch large enough for the
+    two-systems-per-wavefront kernel equals STRICT."""
+    S, T, Time, L = 40, 50, 1.25, 128
+    X = trpl.workloads.samples(S, seed=21)
+    base, lens3 = trpl.workloads.power_scan(L)
+    ini = np.stack([base[c % 3] * (1.0 + 0.05 * c) for c in range(16)])
+    lengths = np.array([2000.0 if c % 2 else 311.0 for c in range(16)])
+    obs = [np.full(1 + (7 * c) % (T + 1), 19.0 + 0.1 * c) for c in range(16)]
+    info = {}
+    P16 = trpl.loglik(X, ini, lengths, Time, L, T, obs, info=info)
+    Pacc = np.zeros(S)
+    for c in range(16):
+        one = {}
+        trpl.loglik(X, ini[c:c + 1], lengths[c:c + 1], Time, L, T, [obs[c]], P=Pacc, info=one)
+        assert np.array_equal(one["sse"][0], info["sse"][c]) and np.array_equal(one["iters_total"][0], info["iters_total"][c])
+    assert np.array_equal(P16, Pacc)
+    # a 17th curve: a second launch inside the same call since round 4 (bayeslib.py:117 loops any number of curves;
+    # test_more_than_sixteen_curves_per_fused_call below), the first sixteen keep their bits
+    i17 = {}
+    P17 = trpl.loglik(X, np.concatenate([ini, ini[:1]]), np.append(lengths, 311.0), Time, L, T, obs + [obs[0]], info=i17)
+    assert np.array_equal(i17["sse"][:16], info["sse"]) and np.array_equal(i17["sse"][16], info["sse"][0])
+    assert np.array_equal(P17, P16 - i17["sse"][16])
+    # plT = 4 at paired-kernel size
+    S2, T2 = 5200, 64
+    if trpl._abi.lib().trpl_kernel_variant(3 * S2, 128, T2, 0) == trpl._abi.KERNEL_FAST_PAIR:
+        X2 = trpl.workloads.samples(S2, seed=22)
+        obs4 = [np.full(T2 // 4 + 1, 19.5)] * 3
+        fi, si = {}, {}
+        pf = trpl.loglik(X2, base, lens3, T2 * 0.025, L, T2, obs4, plT=4, info=fi)
+        ps = trpl.loglik(X2, base, lens3, T2 * 0.025, L, T2, obs4, plT=4, info=si, strict=True)
+        assert np.array_equal(fi["iters_total"], si["iters_total"]) and np.allclose(pf, ps, rtol=1e-9, atol=0)
+
+
+def test_paired_kernel_offgrid_observations_normalize_and_f32_staging_vs_oracle(gpu, oracle):
+    """The paired kernel's less-travelled emission paths against the oracle's restatement of bayeslib.simulate:
+    observation times OFF the simulation grid (per-row griddata in the reference, bayeslib.py:184-191), with
+    self-normalisation (:150-154) and with the reference's float32 PL staging (:137) -- 96 samples x 3 curves."""
+    w = gpu.workloads
+    ini, lens = w.power_scan(128)
+    S, T = 96, 160
+    Time = T * 0.025
+    X = w.samples(S, seed=121)
+    rng = np.random.default_rng(7)
+    times = [np.sort(rng.uniform(0.0, Time, 57)) for _ in range(3)]
+    obs = [np.full(57, 19.0) - 0.3 * t for t in times]
+    for normalize in (False, True):
+        for f32 in (False, True):
+            want = oracle.simulate_loglik(X, ini, lens, Time, 128, T, [(times, obs)],
+                                          pl_dtype=np.float32 if f32 else np.float64, normalize=normalize,
+                                          nthreads=nthreads())[0]
+            for kernel in ("pair", "single"):
+                info = {}
+                P = gpu.loglik(X, ini, lens, Time, 128, T, obs, times=times, pl_f32=f32, normalize=normalize,
+                               kernel=kernel, info=info)
+                assert not info["status"].any()
+                # float32 staging: one float32 ulp of log10 PL enters every residual (as in the unfused golden test)
+                gate = 2e-5 if f32 else 1e-8
+                assert np.max(np.abs(P - want) / np.abs(want)) < gate, (normalize, f32, kernel)
+
+
+@pytest.mark.parametrize("kernel", ["single", "pair", None])
+def test_more_than_sixteen_curves_per_fused_call(gpu, kernel):
+    """bayeslib.simulate loops over ANY number of curves (bayeslib.py:117); a stepper launch carries the constants of at
+    most 16.  The fused call runs 18 curves as two launches and one reduction: every curve's squared-error sum, status,
+    iteration total and floor_col equal those of the curve run alone, bit for bit, and P is minus their sum in curve
+    order (probs.py:44).  Through the host-buffer, the sharded and the off-grid entry points."""
+    w = gpu.workloads
+    L, T, S, C = 128, 150, 21, 18
+    Time = T * DT
+    rng = np.random.default_rng(11)
+    lens = np.where(np.arange(C) % 3 == 0, 311.0, 2000.0)
+    amps = 10 ** rng.uniform(16.0, 18.2, C)
+    ini = np.stack([w.beer_lambert(amps[c], lens[c], L) for c in range(C)])
+    X = w.samples(S, seed=5)
+    obs = [np.linspace(19.0, 18.0, T + 1 - (c % 2) * 7) + 0.01 * c for c in range(C)]
+    kw = {} if kernel is None else dict(kernel=kernel)
+    info = {}
+    P = gpu.loglik(X, ini, lens, Time, L, T, obs, info=info, **kw)
+    assert not info["status"].any()
+    alone = {}
+    for c in range(C):
+        one = {}
+        gpu.loglik(X, ini[c:c + 1], lens[c:c + 1], Time, L, T, [obs[c]], info=one, kernel=kernel or "single")
+        alone[c] = one
+        if kernel is not None:                       # same stepper: the same bits
+            assert np.array_equal(info["sse"][c], one["sse"][0]), c
+            assert np.array_equal(info["iters_total"][c], one["iters_total"][0])
+            assert np.array_equal(info["floor_col"][c], one["floor_col"][0])
+        else:
+            assert np.allclose(info["sse"][c], one["sse"][0], rtol=1e-9, atol=0)
+    want = np.zeros(S)
+    for c in range(C):
+        want -= info["sse"][c]
+    assert np.array_equal(P, want)
+    # sharded over "devices" (the one GPU three times) and with off-grid observation times
+    multi = {}
+    Pm = gpu.loglik(X, ini, lens, Time, L, T, obs, info=multi, devices=[0, 0, 0], **kw)
+    assert np.array_equal(Pm, P) and np.array_equal(multi["sse"], info["sse"])
+    times = [np.linspace(0.0, Time, 40)[1:-1] + 0.004 for _ in range(C)]
+    off = {}
+    Po = gpu.loglik(X, ini, lens, Time, L, T, [np.full(38, 18.5)] * C, info=off, times=times, **kw)
+    one = {}
+    gpu.loglik(X, ini[17:18], lens[17:18], Time, L, T, [np.full(38, 18.5)], info=one, times=times[17:18], kernel=kernel or "single")
+    if kernel is not None:
+        assert np.array_equal(off["sse"][17], one["sse"][0])
+    assert np.isfinite(Po).all()
+    with pytest.raises(gpu.TrplError):
+        gpu.loglik(X[:2], np.repeat(ini[:1], 1025, axis=0), np.full(1025, 2000.0), Time, L, T, [obs[0]] * 1025)
+
+
+@pytest.mark.parametrize("kernel", ["single", "pair"])
+def test_twothick_bench_window_offgrid_observations_against_the_oracle(gpu, oracle, twothick_window, kernel):
+    """The caller-side data path at the bench's window: observation times OFF the simulation grid (the reference
+    interpolates every PL row with scipy griddata, bayeslib.py:184-191; here the bracketing is fused into the stepper,
+    trpl_loglik_obs) and self-normalisation (:150-154), Twothick x 32 samples x 6 curves x T = 8000, against the oracle's
+    restatement of bayeslib.simulate.  Floor-free samples: the oracle's likelihood to 1e-8 in fp64 and to 2e-5 with the
+    reference's float32 PL staging (one float32 ulp of log10 PL enters every residual)."""
+    g = twothick_window
+    rng = np.random.default_rng(23)
+    times = [np.sort(rng.uniform(0.0, g["Time"], 211)) for _ in range(6)]
+    obs = [np.interp(times[c], np.linspace(0.0, g["Time"], g["T"] + 1), g["obs"][c]) + 0.01 for c in range(6)]
+    for normalize, f32 in ((False, False), (True, False), (False, True)):
+        want = oracle.simulate_loglik(g["X"], g["ini"], g["lens"], g["Time"], g["L"], g["T"], [(times, obs)],
+                                      pl_dtype=np.float32 if f32 else np.float64, normalize=normalize, nthreads=nthreads())[0]
+        info = {}
+        P = gpu.loglik(g["X"], g["ini"], g["lens"], g["Time"], g["L"], g["T"], obs, times=times, pl_f32=f32,
+                       normalize=normalize, kernel=kernel, info=info)
+        assert not info["status"].any()
+        clear = (info["floor_col"] == -1).all(axis=0)
+        assert clear.sum() >= 0.8 * g["S"]
+        rel = np.abs(P - want) / np.abs(want)
+        assert rel[clear].max() < (2e-5 if f32 else 1e-8), (normalize, f32, float(rel[clear].max()))

@@ -179,7 +179,7 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did():
     import torch
     from conftest import ROOT
     if torch.cuda.is_available():
-        pytest.skip("the GPU form of this launch is tests/test_gpu_round2.py::test_bench_two_rank_rehearsal_...")
+        pytest.skip("the GPU form of this launch is tests/test_gpu_multi.py::test_bench_two_rank_rehearsal_...")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     env["TRPL_AUTOBUILD"] = "0"
     t0 = time.time()

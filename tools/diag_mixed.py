@@ -1,4 +1,4 @@
-"""Diagnostic: FAST vs STRICT status / iteration agreement under a small iteration cap (which kernel: TRPL_PAIR)."""
+"""Diagnostic: FAST vs STRICT status / iteration agreement under a small iteration cap (which kernel: argv[1] = single | pair, default the library's choice)."""
 import sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +8,7 @@ X = trpl.workloads.samples(S, seed=11)
 ini, lengths = trpl.workloads.power_scan(128)
 obs = [np.full(T + 1, 20.0)] * 3
 fi, si = {}, {}
-pf = trpl.loglik(X, ini, lengths, Time, 128, T, obs, info=fi, MAX=60)
+pf = trpl.loglik(X, ini, lengths, Time, 128, T, obs, info=fi, MAX=60, kernel=sys.argv[1] if len(sys.argv) > 1 else None)
 ps = trpl.loglik(X, ini, lengths, Time, 128, T, obs, info=si, MAX=60, strict=True)
 d = fi["status"] != si["status"]
 print("kernel variant", trpl._abi.lib().trpl_kernel_variant(3 * S, 128, 0), "status mismatches", d.sum(), "of", d.size)

@@ -1,5 +1,5 @@
 """Differential fuzz of the two FAST L = 128 kernels over a parameter box much wider than the reference's:
-   TRPL_PAIR=0 python tools/fuzz_pair.py run gpurun_out/fz0.npz ; TRPL_PAIR=1 python tools/fuzz_pair.py run gpurun_out/fz1.npz
+   python tools/fuzz_pair.py run gpurun_out/fz0.npz single ; python tools/fuzz_pair.py run gpurun_out/fz1.npz pair   (or: strict)
    python tools/fuzz_pair.py cmp gpurun_out/fz0.npz gpurun_out/fz1.npz"""
 import sys
 sys.path.insert(0, ".")
@@ -16,9 +16,11 @@ if sys.argv[1] == "run":
     ini, lens = wl.twothick(128)
     obs = [np.full(T + 1, 18.0) - 0.01 * np.arange(T + 1)] * len(lens)
     info = {}
-    strict = len(sys.argv) > 3 and sys.argv[3] == "strict"        # the reference's arithmetic as the third leg
-    P = trpl_amd.loglik(X, ini, lens, T * 0.025, 128, T, obs, info=info, MAX=2000, strict=strict)
-    v = trpl_amd._abi.lib().trpl_kernel_variant(S * len(lens), 128, T, trpl_amd.FLAG_STRICT if strict else 0)
+    leg = sys.argv[3] if len(sys.argv) > 3 else None
+    strict = leg == "strict"                                      # the reference's arithmetic as the third leg
+    P = trpl_amd.loglik(X, ini, lens, T * 0.025, 128, T, obs, info=info, MAX=2000, strict=strict,
+                        kernel=leg if leg in ("single", "pair") else None)
+    v = trpl_amd._abi.lib().trpl_kernel_variant(S * len(lens), 128, T, (trpl_amd.FLAG_STRICT if strict else 0) | trpl_amd._abi.kernel_flag(leg if leg in ('single', 'pair') else None))
     np.savez(sys.argv[2], P=P, variant=v, **{k: info[k] for k in ("sse", "status", "iters_total")})
     print("variant", v, "non-converged", int((info["status"] != 0).sum()), "of", info["status"].size,
           "iterations", int(info["iters_total"].sum()), "seconds", info["seconds"])

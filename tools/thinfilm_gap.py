@@ -87,7 +87,7 @@ def main():
     for length, g in groups.items():
         dev = np.concatenate(g["dev"]); k = np.concatenate(g["k"])
         cs = [c for c in range(C) if float(lens[c]) == length]
-        clear = (info_s["floor_col"][cs] < 0) & (info_f["floor_col"][cs] < 0) & (info_s["status"][cs] == 0) & (info_f["status"][cs] == 0)
+        clear = (info_s["floor_col"][cs] == -1) & (info_f["floor_col"][cs] == -1) & (info_s["status"][cs] == 0) & (info_f["status"][cs] == 0)
         gap = np.abs(info_f["sse"][cs] - info_s["sse"][cs]) / info_s["sse"][cs]
         out["groups"]["%g nm" % length] = dict(
             systems=g["systems"], flagged=g["flagged"], iteration_totals_differ=g["itdiff"],

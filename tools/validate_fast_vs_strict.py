@@ -45,7 +45,7 @@ if bad.any():
 # ---- the cancellation floor as the library reports it (include/trpl.h: floor_col)
 print(f"floor_col: identical in both arithmetics for {int((fcf == fcs).sum())} of {fcf.size} systems; "
       f"systems that reach the floor {int((fcs >= 0).sum())} ({100 * (fcs >= 0).mean():.2f} %), earliest column {int(fcs[fcs >= 0].min()) if (fcs >= 0).any() else -1}")
-clear = (fcs < 0).all(0) & (fcf < 0).all(0) & ok
+clear = (fcs == -1).all(0) & (fcf == -1).all(0) & ok
 relc = np.abs(Pf[clear] - Ps[clear]) / np.abs(Ps[clear])
 print(f"samples that never reach the floor: {int(clear.sum())} of {S} ({100 * clear.mean():.2f} %): max |P_fast-P_strict|/|P_strict| = {relc.max():.3e}, "
       f"99.9th percentile {np.quantile(relc, 0.999):.2e}, above 1e-8: {int((relc > 1e-8).sum())}")
