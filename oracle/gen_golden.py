@@ -414,6 +414,11 @@ def case_csv_fixture():
         for row in csv.reader(fh):
             if row[0] == "END" or float(row[0]) <= 6.0:
                 w.writerow(row)
+    # the whole observation file (5601 / 8801 / 12801 points, 140 / 220 / 320 ns at 0.025 ns), gzip-compressed: the input of the
+    # production-shape run on the GPU box (tools/e2e_production.py), where the reference checkout does not exist
+    import gzip
+    with open(obs_file, "rb") as fh, gzip.GzipFile(os.path.join(OUT, "obs_balanced_full.csv.gz"), "wb", mtime=0) as out:
+        out.write(fh.read())
 
 
 def case_legacy_odeint():

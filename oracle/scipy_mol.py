@@ -33,9 +33,14 @@ def rhs(t, y, m, dx, Sf, Sb, mu_n, mu_p, n0, p0, CN, CP, tauN, tauP, B, eps):
     Jn[1:-1] = mu_n * ((N[:-1] + N[1:]) / 2) * (Q * E[1:-1]) + (mu_n * KBT) * ((N[1:] - N[:-1]) / dx)   # :50-51
     Jp[1:-1] = mu_p * ((P[:-1] + P[1:]) / 2) * (Q * E[1:-1]) - (mu_p * KBT) * ((P[1:] - P[:-1]) / dx)   # :54-55
     dE = -(Jn + Jp) * (Q_C / (eps * EPS0))                                                              # :58
-    loss = B * excess + excess / (tauN * P + tauP * N) + (CN * N + CP * P) * excess                     # :60-63
-    dN = (1 / Q) * ((Jn[1:] - Jn[:-1]) / dx) - loss                                                     # :65-68
-    dP = (-1 / Q) * ((Jp[1:] - Jp[:-1]) / dx) - loss                                                    # :71-74
+    # the three loss terms are subtracted one after the other, in the reference's order (:60-74): with the same association
+    # every step-size decision of the adaptive integrator is the reference's, and the port reproduces its PL to rounding
+    # instead of to the integrator's accumulated tolerance (a summed `loss` measured up to 4e-4 apart on 3 of 192 curves)
+    rad = B * excess                                                                                    # :60
+    nonrad = excess / ((tauN * P) + (tauP * N))                                                         # :61
+    auger = (CN * N + CP * P) * excess                                                                  # :63
+    dN = (1 / Q) * ((Jn[1:] - Jn[:-1]) / dx) - rad - nonrad - auger                                     # :65-68
+    dP = (-1 / Q) * ((Jp[1:] - Jp[:-1]) / dx) - rad - nonrad - auger                                    # :71-74
     return np.concatenate([dN, dP, dE])
 
 
@@ -64,6 +69,36 @@ def _job(a):
     mp, length, Time, L, T, ini = a
     pl = solve_one(mp, length, Time, L, T, ini)
     return float(np.sum((np.log10(np.abs(pl) + np.finfo(float).tiny)) ** 2))     # bayeslib.py:160-161,200
+
+
+def cpu_branch_loglik(pl, obs, Time, T):
+    """The likelihood bayeslib.simulate's CPU branch forms from one curve's PL rows (bayeslib.py:137,:158-161,:173-191,:198-201):
+    PL staged in float32, log10(|PL| + MIN) in that dtype (MIN = DBL_MIN is 0 in float32), per-row griddata onto the
+    observation times when they are not the whole simulation grid, then -sum (log10 PL - log10 obs)^2 in float64 -- no
+    mag_offset on this branch.  pl (S, T+1); obs (n_obs,) log10 observations on the first n_obs grid points."""
+    from scipy.interpolate import griddata
+    pl32 = np.asarray(pl, dtype=np.float32)
+    with np.errstate(divide="ignore"):
+        lg = np.log10(np.abs(pl32) + np.float32(np.finfo(float).tiny))
+    sim_t = np.linspace(0, Time, T + 1)
+    times = sim_t[:len(obs)]
+    if len(obs) != T + 1:                                                   # bayeslib.almost_equal fails on the shapes (:78-81)
+        lg = np.stack([griddata(sim_t, row, times) for row in lg])
+    return -np.sum((lg - np.asarray(obs)[None, :]) ** 2, axis=1)
+
+
+def _pl_job(a):
+    mp, length, Time, L, T, ini = a
+    return solve_one(mp, length, Time, L, T, ini)
+
+
+def pl_batch(X, ini, lengths, Time, L, T, processes):
+    """PL(t) of len(X) x len(ini) systems on `processes` single-threaded workers: array (C, S, T+1)."""
+    import multiprocessing as mp
+    jobs = [(X[s], lengths[c], Time, L, T, ini[c]) for c in range(len(ini)) for s in range(len(X))]
+    with mp.get_context("fork").Pool(processes, initializer=_one_blas_thread) as pool:
+        out = pool.map(_pl_job, jobs, chunksize=1)
+    return np.array(out).reshape(len(ini), len(X), T + 1)
 
 
 _limiter = None
