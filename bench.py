@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--extra-flags", type=lambda v: int(v, 0), default=0,
                     help="further TRPL_FLAG_* bits for the timed launches (measurements: 0x20000 = always-isolating paired "
                          "kernel, 0x40000 = adjacent-sample pairing, 0x10 / 0x20 = force the paired / one-system kernel)")
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="skip the production-shape end-to-end entry (2^17 samples, real observation file, fused level; ~10 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcr", action="store_true")
     ap.add_argument("--no-host-api", action="store_true",
@@ -324,6 +326,9 @@ def main():
                                               flags, tol, C, args.fp32)
     if rank == 0 and world == 1 and not args.no_host_api and L == 128 and not (args.fp32 or args.mixed or args.strict):
         out["host_api_block"] = host_api_block(trpl_amd, wl, ini, lens, L, T, dt_ns)
+    if rank == 0 and world == 1 and not args.no_e2e and args.workload == "power_scan" and L == 128 \
+            and not (args.fp32 or args.mixed or args.strict):
+        out["e2e_production"] = e2e_production(trpl_amd)
     if rank == 0:
         attach_traffic(out, args.traffic_profile)
     out.update(cpu_legs)
@@ -576,6 +581,51 @@ def host_api_block(trpl_amd, wl, ini, lens, L, T, dt_ns, S=1024):
     return {"samples": S, "curves": len(lens), "T": T, "pl_dtype": "float32", "wall_s": wall, "pvSim_s": t_solve,
             "fastlog_s": t_log, "prob_s": t_prob, "system_timesteps_per_s": S * len(lens) * (T + 1) / wall,
             "finite_likelihoods": int(np.isfinite(P).sum())}
+
+
+def e2e_production(trpl_amd, S=2 ** 17, T=80000, Time=2000.0):
+    """The reference's production shape through the fused integration level (tools/e2e_production.py, level A): the
+    entry script's configuration (parallel_bayes_gpu.py:72-131: S = 2^17 samples of the shipped box, seed 42, L = 128,
+    T = 80 000 steps over 2000 ns, tol 7) with the shipped Balancedhighsurf observation file read by dataio.get_data
+    (tests/golden/obs_balanced_full.csv.gz: 5601 / 8801 / 12801 points -- the fused window ends at the last observation),
+    driver.bayes with one fused launch, export of <name>_BAYRAN_{P,X}.npy.  Wall time from bayes() to the files on disk."""
+    import gzip
+    import shutil
+    import tempfile
+    from trpl_amd import sampler as sm
+    gold = os.path.join(ROOT, "tests", "golden")
+    src = os.path.join(gold, "obs_balanced_full.csv.gz")
+    if not os.path.isfile(src):
+        return {"skipped": "tests/golden/obs_balanced_full.csv.gz not found"}
+    work = tempfile.mkdtemp(prefix="trpl_e2e_")
+    try:
+        obs_csv = os.path.join(work, "Balancedhighsurf_Power_scan_Observations.csv")
+        with gzip.open(src, "rb") as fh, open(obs_csv, "wb") as out:
+            out.write(fh.read())
+        ic_flags = {"time_cutoff": Time, "select_obs_sets": None, "noise_level": None}
+        sim_flags = {"load_PL_from_file": False, "override_equal_auger": False, "override_equal_mu": False,
+                     "override_equal_s": False, "log_pl": True, "self_normalize": False, "random_sample": True, "num_points": S}
+        ini = trpl_amd.get_initpoints(os.path.join(gold, "exc_power_scan.csv"), ic_flags)
+        e_data = trpl_amd.get_data([obs_csv], ic_flags, sim_flags, scale_f=1e-23)
+        n_obs = [len(t) for t in e_data[0][0]]
+        simPar = [2000.0, Time, 128, T, 1, (0, 1, 3, 10, 30, 100), 7, 10000]
+        gpu_info = {"sims_per_gpu": S, "num_gpus": 1, "has_GPU": True, "max_sims_per_block": 1, "fused": True}
+        np.random.seed(42)                                                   # parallel_bayes_gpu.py:35
+        t0 = time.perf_counter()
+        N, P, X = trpl_amd.bayes(trpl_amd.pvSim, None, None, sm.DEFAULT_MINX * sm.UNIT_CONVERSIONS,
+                                 sm.DEFAULT_MAXX * sm.UNIT_CONVERSIONS, sm.DEFAULT_DO_LOG, ini, simPar, e_data, sim_flags, gpu_info)
+        trpl_amd.export(os.path.join(work, "out"), P[0], X / sm.UNIT_CONVERSIONS)     # :194-198
+        wall = time.perf_counter() - t0
+        steps = sum(n - 1 for n in n_obs) + 3
+        return {"integration": "driver.bayes, one fused launch (trpl_loglik_obs); level A of tools/e2e_production.py",
+                "samples": S, "curves": 3, "L": 128, "T": T, "time_ns": Time, "n_obs": n_obs,
+                "observations": "Balancedhighsurf_Power_scan_Observations.csv (shipped example data) via dataio.get_data",
+                "wall_to_npy_s": wall, "likelihoods_per_s": S / wall, "system_timesteps_per_s": S * steps / wall,
+                "finite_likelihoods": int(np.isfinite(P[0]).sum()), "files": sorted(os.listdir(os.path.join(work, "out"))),
+                "other_levels": "profiles/r5_e2e_production.json (the reference's call sequence at sims_per_gpu 1024 / 16384, "
+                                "FAST vs STRICT, oracle subsample)"}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def _profile_key(path):

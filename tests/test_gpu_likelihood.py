@@ -345,6 +345,26 @@ def test_more_than_sixteen_curves_per_fused_call(gpu, kernel):
     if kernel is not None:
         assert np.array_equal(off["sse"][17], one["sse"][0])
     assert np.isfinite(Po).all()
+    # ... and the off-grid call's other outputs for curves of BOTH launch groups: a curve of the first sixteen run alone,
+    # status / iteration totals / floor_col of every group, P = minus the sum of the per-curve sums in curve order, and the
+    # whole thing against the reference's loop -- PL from trpl_solve_pl, log10, the interp1d form of bayeslib.py:189, prob
+    first = {}
+    gpu.loglik(X, ini[3:4], lens[3:4], Time, L, T, [np.full(38, 18.5)], info=first, times=times[3:4], kernel=kernel or "single")
+    if kernel is not None:
+        assert np.array_equal(off["sse"][3], first["sse"][0]) and np.array_equal(off["floor_col"][3], first["floor_col"][0])
+        assert np.array_equal(off["iters_total"][3], first["iters_total"][0]) and np.array_equal(off["iters_total"][17], one["iters_total"][0])
+        assert np.array_equal(off["floor_col"][17], one["floor_col"][0])
+    assert not off["status"].any() and (off["floor_col"] == -1).all()
+    want_o = np.zeros(S)
+    for c in range(C):
+        want_o -= off["sse"][c]
+    assert np.array_equal(Po, want_o)
+    sim_t = np.linspace(0, Time, T + 1)
+    for c in (3, 16, 17):
+        pl, _, _, _ = gpu.solve_pl(X[:, :12], lens[c], Time, L, T, ini[c], kernel=kernel or "single")
+        lg = gpu.interp_rows(sim_t, np.log10(pl), times[c])
+        ref = np.sum((lg + X[:, 12:13] - 18.5) ** 2, axis=1)
+        assert np.max(np.abs(off["sse"][c] / ref - 1)) < 1e-10, c
     with pytest.raises(gpu.TrplError):
         gpu.loglik(X[:2], np.repeat(ini[:1], 1025, axis=0), np.full(1025, 2000.0), Time, L, T, [obs[0]] * 1025)
 

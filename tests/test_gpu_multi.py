@@ -182,7 +182,7 @@ def test_bench_two_rank_rehearsal_gathers_the_single_rank_likelihoods(gpu, tmp_p
     sample shards, pinned kernel variant, all-gather, max-over-ranks timing) must print one contract line
     and gather exactly the likelihood vector a single rank computes for the same 4 096 samples."""
     common = ["--steps", "1", "--warmup", "0", "--T", "200", "--no-cpu-baseline", "--no-pcr", "--no-full-length", "--no-host-api",
-              "--no-other-configs"]
+              "--no-other-configs", "--no-e2e"]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", TRPL_AUTOBUILD="0")
     p1, p2 = str(tmp_path / "p1.npy"), str(tmp_path / "p2.npy")
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--samples-per-gpu", "4096",

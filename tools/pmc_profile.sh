@@ -17,6 +17,6 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
   if [ -n "$PMC_SETS" ] && ! echo " $PMC_SETS " | grep -q " $i "; then continue; fi      # PMC_SETS="1 4": only those passes
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc_${TAG}_$i -- python3 $R/bench.py --steps 1 --warmup 0 --T $PMC_T --no-cpu-baseline --no-pcr --no-full-length --no-host-api --no-other-configs $BENCH_EXTRA > $R/gpurun_out/pmc_${TAG}_$i.log 2>&1 || { echo "pmc set $i failed"; tail -3 $R/gpurun_out/pmc_${TAG}_$i.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc_${TAG}_$i -- python3 $R/bench.py --steps 1 --warmup 0 --T $PMC_T --no-cpu-baseline --no-pcr --no-full-length --no-host-api --no-other-configs --no-e2e $BENCH_EXTRA > $R/gpurun_out/pmc_${TAG}_$i.log 2>&1 || { echo "pmc set $i failed"; tail -3 $R/gpurun_out/pmc_${TAG}_$i.log; exit 1; }
   echo "pmc set $i done"
 done

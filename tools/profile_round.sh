@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err || { echo "bench failed"; tail -5 $OUT/bench.err; exit 1; }
 # the same GPU work as the K timed steps of the bench line above (default T, steps, warmup); the CPU legs and
 # the single full-length pass are skipped so that the kernel's average over these launches is the timed one
-BENCH_ARGS="--no-cpu-baseline --no-full-length --no-host-api --no-other-configs"
+BENCH_ARGS="--no-cpu-baseline --no-full-length --no-host-api --no-other-configs --no-e2e"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py $BENCH_ARGS > $OUT/stats.log 2>&1 || echo "stats pass failed"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $R/bench.py $BENCH_ARGS > $OUT/pmc_$c.log 2>&1 || echo "pmc $c failed"
