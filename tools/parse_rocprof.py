@@ -45,11 +45,22 @@ for cname in ("FETCH_SIZE", "WRITE_SIZE"):
             k = r["Kernel_Name"].split("(")[0]
             d = traffic.setdefault(k, {"FETCH_SIZE": [], "WRITE_SIZE": []})
             d[cname].append(float(r["Counter_Value"]))
+def median(v):
+    v = sorted(v)
+    n = len(v)
+    return 0.0 if n == 0 else (v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2]))
+
+
 out = {}
 for k, d in traffic.items():
-    fetch = sum(d["FETCH_SIZE"]) / max(len(d["FETCH_SIZE"]), 1)
-    write = sum(d["WRITE_SIZE"]) / max(len(d["WRITE_SIZE"]), 1)
+    # per-launch MEDIAN, not mean: the TCC counters are device-wide, and whatever else touches HBM while one dispatch runs is
+    # counted with it (round 4, r4_v7: three stepper launches wrote 14 848 KiB each, the fourth "wrote" 180 510 KiB -- its
+    # mean, 57.6 MB, went into DESIGN.md and the bench line as if it were the kernel's); min / max show such a launch
+    fetch = median(d["FETCH_SIZE"])
+    write = median(d["WRITE_SIZE"])
     out[k] = {"launches_fetch": len(d["FETCH_SIZE"]), "launches_write": len(d["WRITE_SIZE"]),
+              "FETCH_SIZE_KiB_min_max": [min(d["FETCH_SIZE"] or [0.0]), max(d["FETCH_SIZE"] or [0.0])],
+              "WRITE_SIZE_KiB_min_max": [min(d["WRITE_SIZE"] or [0.0]), max(d["WRITE_SIZE"] or [0.0])],
               "FETCH_SIZE_KiB_per_launch_raw": fetch, "WRITE_SIZE_KiB_per_launch": write,
               "hbm_read_bytes_per_launch_corrected": fetch * 1024 * 2,
               "hbm_write_bytes_per_launch": write * 1024,
