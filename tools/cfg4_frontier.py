@@ -2,7 +2,7 @@
 
 For every (arithmetic, tol) pair: system-timesteps/s and inner iterations per step on the config's single-GPU
 share (Power_scan x 32 768 samples x T = 8000, fused likelihood), and the error against the fp64 tol-7 solve
-(which the oracle pins at L = 512, tests/test_gpu_parity.py::test_pvsim_fine_grids_vs_oracle) on a 192-sample
+(which the oracle pins at L = 512, tests/test_gpu_l512.py::test_pvsim_fine_grids_vs_oracle) on a 192-sample
 subset over the same window: max relative PL error over points above the cancellation floor and max relative
 log-likelihood error.
 
