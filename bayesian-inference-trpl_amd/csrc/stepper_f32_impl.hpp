@@ -189,8 +189,7 @@ __global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
         if (it >= MAX) { status = 1 + (int)t; break; }
 
         if (pl_step) {
-            if (sink.interp) sink.emit(pl_col, plv);
-            else sink.push(pl_col, plv);
+            sink.push(pl_col, plv);
             pl_next += a.plT;
             pl_col++;
         }
@@ -202,7 +201,7 @@ __global__ void __launch_bounds__(64, 2) stepper_kernel(const StepArgs a)
         }
     }
 
-    if (!sink.interp) {
+    {
         const int64_t done = status ? (int64_t)(status - 1) : sink.t_last + 1;
         sink.flush_batch((int)((done + a.plT - 1) / a.plT - sink.base));
     }

@@ -277,8 +277,8 @@ struct PlSink {
     // coalesced load of 64 observations, a coalesced PL store -- instead of a wave-uniform fp64 log10,
     // an IEEE divide, a scalar load and a single-lane store on every step.  The squared errors of a
     // batch are added by a wave reduction, so the likelihood sum is associated differently from the
-    // reference's serial loop (~1e-16 relative; STRICT keeps emit()).  Not used for off-grid
-    // observation times, which need consecutive values in order (emit()).
+    // reference's serial loop (~1e-16 relative; STRICT keeps emit()).  Off-grid observation times take the same
+    // route since round 5 (the brackets of a batch's observations are fetched across lanes, see flush_batch).
     __device__ __forceinline__ void push(int32_t col, double plv)
     {
         if (lane_ == col - base) pend = plv;
@@ -300,11 +300,11 @@ struct PlSink {
                 if (a.pl_bytes == 4) ((float *)a.pl)[orow * a.pl_ld + col] = (float)pend / (float)cc.plnorm;
                 else                 ((double *)a.pl)[orow * a.pl_ld + col] = pend / cc.plnorm;
             }
-            if (a.floor_col && base < ncol_ll && first_floor < 0) {
-                const uint64_t below = __builtin_amdgcn_ballot_w64(live && col < ncol_ll && !(pend >= pl_floor));
+            if (a.floor_col && (interp || base < ncol_ll) && first_floor < 0) {
+                const uint64_t below = __builtin_amdgcn_ballot_w64(live && (interp || col < ncol_ll) && !(pend >= pl_floor));
                 if (below) first_floor = (int32_t)(base + __builtin_ctzll(below));
             }
-            if (base < ncol_ll) {                           // bayeslib.py:150-157, probs.py:29-44
+            if (interp || base < ncol_ll) {                 // bayeslib.py:150-157, probs.py:29-44
                 if (a.flags & kFlagNormalize) {
                     if (base == 0) { pl0_d = uniform_d(v); pl0_f = (float)pl0_d; }
                     if (f32) { vf = vf / pl0_f; v = (double)vf; } else { v = v / pl0_d; }
@@ -317,10 +317,42 @@ struct PlSink {
                     if (v < DBL_MIN) v = DBL_MIN;
                     lg = log10(v);
                 }
-                const bool use = live && col < ncol_ll;
-                double err = lg + mag;
-                err -= obs[use ? col : 0];
-                sse += wave_sum(use ? err * err : 0.0);
+                if (!interp) {
+                    const bool use = live && col < ncol_ll;
+                    double err = lg + mag;
+                    err -= obs[use ? col : 0];
+                    sse += wave_sum(use ? err * err : 0.0);
+                } else {
+                    // Off-grid observation times (trpl_loglik_obs; bayeslib.py:184-191): observation i is bracketed by the grid
+                    // columns (hi_i - 1, hi_i).  The observations whose upper column lies in this batch are taken 64 at a
+                    // time, one per lane -- they are sorted by time, so they are the next ones -- each lane fetching the two
+                    // log10 PL values of its bracket from the lanes that hold them (ds_bpermute; column base - 1 is carried from
+                    // the previous batch) and forming scipy interp1d's slope * (x - x_lo) + y_lo.  Round 5: until then this
+                    // path emitted column by column (emit(): a wave-uniform fp64 log10 and an IEEE divide per time step), 21 %
+                    // slower on the production shape than the on-grid path.  Sums are wave reductions, as for on-grid batches.
+                    while (next_obs < ncol_ll) {
+                        const int32_t idx = next_obs + lane;
+                        const bool in = idx < ncol_ll;
+                        const int32_t hi = in ? obs_hi[idx] : 0x7fffffff;
+                        const bool mine = in && hi < base + n;
+                        const uint64_t m = __builtin_amdgcn_ballot_w64(mine);
+                        if (!m) break;
+                        const int k = mine ? hi - base : 0;                     // 0 .. n-1 (earlier brackets were consumed earlier)
+                        const double y_hi = __shfl(lg, k, 64);
+                        const double y_nb = __shfl(lg, k > 0 ? k - 1 : 0, 64);
+                        const double y_lo = k > 0 ? y_nb : lg_prev;
+                        const double dy = f32 ? (double)((float)y_hi - (float)y_lo) : y_hi - y_lo;
+                        const double h = mine ? obs_h[idx] : 1.0, dx = mine ? obs_dx[idx] : 0.0;
+                        double err = ((dy / h) * dx + y_lo) + mag;
+                        err -= obs[mine ? idx : 0];
+                        sse += wave_sum(mine ? err * err : 0.0);
+                        const int cnt = __builtin_popcountll(m);
+                        next_obs += cnt;
+                        if (cnt < 64) break;                                    // the next observation's bracket ends beyond this batch
+                    }
+                    lg_prev = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lg), n - 1),
+                                               __builtin_amdgcn_readlane(__double2loint(lg), n - 1));
+                }
             }
             base += n;
         }
@@ -877,7 +909,7 @@ stepper_kernel(const StepArgs a)
         if (it >= MAX) { status = 1 + (int)t; break; }                                     // :269-274
 
         if (pl_step) {
-            if (STRICT || sink.interp) sink.emit(pl_col, plv);
+            if (STRICT) sink.emit(pl_col, plv);
             else sink.push(pl_col, plv);
             pl_next += a.plT;
             pl_col++;
@@ -885,7 +917,7 @@ stepper_kernel(const StepArgs a)
 
     }
 
-    if (!(STRICT || sink.interp) && valid) {       // columns parked since the last full batch
+    if (!STRICT && valid) {                        // columns parked since the last full batch
         const int64_t done = status ? (int64_t)(status - 1) : sink.t_last + 1;      // steps whose PL was emitted
         sink.flush_batch((int)((done + a.plT - 1) / a.plT - sink.base));
     }

@@ -434,15 +434,15 @@ __global__ void __launch_bounds__(64, 2) stepper_pair_kernel(const StepArgs a)
         }
 
         if (pl_step) {
-            if (!deadA) { if (sinkA.interp) sinkA.emit(pl_col, plA); else sinkA.push(pl_col, plA); }
-            if (!deadB) { if (sinkB.interp) sinkB.emit(pl_col, plB); else sinkB.push(pl_col, plB); }
+            if (!deadA) sinkA.push(pl_col, plA);
+            if (!deadB) sinkB.push(pl_col, plB);
             pl_next += a.plT;
             pl_col++;
         }
 
     }
 
-    if (!sinkA.interp) {                            // columns parked since the last full batch
+    {                                               // columns parked since the last full batch
         const int64_t doneA_ = statusA ? (int64_t)(statusA - 1) : sinkA.t_last + 1;
         const int64_t doneB_ = statusB ? (int64_t)(statusB - 1) : sinkB.t_last + 1;
         sinkA.flush_batch((int)((doneA_ + a.plT - 1) / a.plT - sinkA.base));

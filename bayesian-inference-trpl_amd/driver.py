@@ -195,7 +195,7 @@ def _simulate_resident(e_data, P, X, num_curves, thicknesses, sim_params, init_p
             for c in range(num_curves):
                 t = np.asarray(exp[0][c], dtype=float)
                 o = np.asarray(exp[1][c], dtype=float)
-                if almost_equal(sim_t, t):                                    # bayeslib.py:182-183
+                if is_grid_prefix(t, sim_t):                                  # bayeslib.py:182-183, and prefixes of the grid (below)
                     per_curve.append((torch.from_numpy(np.ascontiguousarray(o)).to(dev), None))
                 else:
                     order = np.argsort(t, kind="stable")
@@ -267,12 +267,19 @@ def simulate(model, e_data, P, X, plI, plI_int, num_curves, sim_params, init_par
                            bundle=_bundle_of(gpu_info, L))
         return
     if fused:
-        # an experiment sampled exactly on the full simulation grid is compared point by point
-        # (the reference's bypass, bayeslib.py:182-183); anything else is interpolated (:184-191)
+        # An experiment sampled exactly on the full simulation grid is compared point by point (the reference's bypass,
+        # bayeslib.py:182-183); anything else is interpolated there (:184-191).  Observation times that are a PREFIX of the
+        # simulation grid -- the shipped example data: 0.025 ns spacing, 140 .. 320 ns of a 2000 ns window; the reference's
+        # shape test sends them to griddata -- are interpolated AT grid nodes, where the interp1d form returns the node's own
+        # value to one rounding: they take the on-grid entry point too (batched emission, curve-pair table: 21 % faster on
+        # the production shape, likelihoods equal to 7e-15, tools/bench_prefix_vs_interp.py); gpu_info["interpolate_prefix"]
+        # = True keeps the literal interpolation.
+        literal = bool(gpu_info.get("interpolate_prefix", False))
         for blk in range(gpu_id * group, len(X), num_gpus * group):
             size = min(group, len(X) - blk)
             for e, exp in enumerate(e_data):
-                on_grid = all(almost_equal(sim_t, np.asarray(exp[0][c], dtype=float)) for c in range(num_curves))
+                on_grid = all((almost_equal(sim_t, np.asarray(exp[0][c], dtype=float)) if literal else
+                               is_grid_prefix(exp[0][c], sim_t)) for c in range(num_curves))
                 info = {}
                 loglik(X[blk:blk + size], init_params, thicknesses, Time, L, T,
                        [exp[1][c] for c in range(num_curves)], tol=sim_params[6], MAX=sim_params[7],

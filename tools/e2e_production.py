@@ -140,26 +140,32 @@ def main():
     # ---- validation ----
     val = {}
     ref_level = "A" if "A" in results else sorted(results)[0]
+    np.random.seed(42)
+    _, _, X = sm.make_grid(1, minX, maxX, sm.DEFAULT_DO_LOG, sim_flags)
+    times = [np.asarray(t) for t in e_data[0][0]]
+    obs = [np.asarray(v) for v in e_data[0][1]]
+    t0 = time.perf_counter()
+    fi, si = {}, {}
+    Pf = trpl_amd.loglik(X, iniPar, Length, Time, L, T, obs, times=times, info=fi)
+    t1 = time.perf_counter()
+    clear_f = (fi["floor_col"] == -1).all(axis=0)                            # floor-free samples (include/trpl.h)
     for level, Pl in results.items():
         if level == ref_level:
             continue
         both = np.isfinite(Pl) & np.isfinite(results[ref_level])
         rel = np.abs(Pl[both] / results[ref_level][both] - 1)
-        val["%s_vs_%s" % (level, ref_level)] = {"max_rel": float(rel.max()), "median_rel": float(np.median(rel)),
-                                                "note": "level B stages PL in float32 (bayeslib.py:137): one float32 ulp of log10 PL per residual"}
-    np.random.seed(42)
-    _, _, X = sm.make_grid(1, minX, maxX, sm.DEFAULT_DO_LOG, sim_flags)
-    times = [np.asarray(t) for t in e_data[0][0]]
-    obs = [np.asarray(v) for v in e_data[0][1]]
+        relc = np.abs(Pl[both & clear_f] / results[ref_level][both & clear_f] - 1)
+        val["%s_vs_%s" % (level, ref_level)] = {
+            "max_rel_floor_free": float(relc.max()), "max_rel_all": float(rel.max()), "median_rel": float(np.median(rel)),
+            "finite_in_one_only": int((np.isfinite(Pl) != np.isfinite(results[ref_level])).sum()),
+            "note": "both levels stage PL in float32 like the reference (bayeslib.py:137); a launch of <= 3072 systems runs the "
+                    "one-system FAST kernel, larger ones the paired kernel: the two agree to rounding except below the "
+                    "cancellation floor (floor_col >= 0), where PL is set by rounding in any evaluation"}
     if not a.no_strict:
-        t0 = time.perf_counter()
-        fi, si = {}, {}
-        Pf = trpl_amd.loglik(X, iniPar, Length, Time, L, T, obs, times=times, info=fi)
-        t1 = time.perf_counter()
         print("FAST pass %.1f s; STRICT pass running ..." % (t1 - t0), flush=True)
         Ps = trpl_amd.loglik(X, iniPar, Length, Time, L, T, obs, times=times, info=si, strict=True)
         t2 = time.perf_counter()
-        clear = (fi["floor_col"] == -1).all(axis=0) & (si["floor_col"] == -1).all(axis=0)
+        clear = clear_f & (si["floor_col"] == -1).all(axis=0)
         gap = np.abs(Pf[clear] / Ps[clear] - 1)
         big = np.abs(Pf / Ps - 1) > 1e-6
         val["fast_vs_strict"] = {"fast_s": t1 - t0, "strict_s": t2 - t1, "floor_col_identical": bool(np.array_equal(fi["floor_col"], si["floor_col"])),
