@@ -327,3 +327,27 @@ def test_python_constants_equal_the_headers_defines():
     import gpu_common as G
     assert G.ENVELOPE_K_THICK == A.PL_ENVELOPE_K_THICK and G.ENVELOPE_K == {2000.0: A.PL_ENVELOPE_K_THICK, 311.0: A.PL_ENVELOPE_K_THIN}
     assert G.ENVELOPE_K_L512 == A.PL_ENVELOPE_K_L512 and G.FLOOR == A.PL_FLOOR_EXCESS
+
+
+def test_kernel_name_and_round5_flags_need_no_device(trpl):
+    """trpl_kernel_name spells the instantiation a launch runs (bench.py's roofline.rocprof_name; rocprofv3 lists it after
+    "void "), the per-call test flags that replaced the environment switches reach it, and the BDF-order field is validated."""
+    A = trpl._abi
+    assert A.kernel_name(196608, 128, 8000) == "trpl::pair::stepper_pair_kernel<true, false, true>"
+    assert A.kernel_name(196608, 128, 8000, A.FLAG_PAIR_ALWAYS_SEAM) == "trpl::pair::stepper_pair_kernel<true, false, false>"
+    assert A.kernel_name(196608, 128, 8000, A.FLAG_KERNEL_PAIR, snapshots=True) == "trpl::pair::stepper_pair_kernel<true, true, true>"
+    assert A.kernel_name(64, 128, 8000) == "trpl::stepper_kernel<128, false, false, false, false, false>"
+    assert A.kernel_name(10 ** 6, 128, 8000, A.FLAG_STRICT) == "trpl::stepper_kernel<128, true, false, false, false, false>"
+    assert A.kernel_name(10 ** 6, 512, 8000, A.FLAG_HIST32) == "trpl::stepper_kernel<512, false, false, false, false, true>"
+    assert A.kernel_name(10 ** 6, 512, 8000, A.FLAG_MIXED) == "trpl::stepper_kernel<512, false, false, true, false, false>"
+    assert A.kernel_name(10 ** 6, 128, 8000, A.flag_bundle(3, 128)) == "trpl::stepper_kernel<128, false, false, false, true, false>"
+    assert A.kernel_name(10 ** 6, 512, 100, A.FLAG_FP32) == "trpl::f32::stepper_kernel<512>"
+    lib = A.lib()
+    import ctypes as C
+    small = C.create_string_buffer(8)
+    assert lib.trpl_kernel_name(10, 128, 10, 0, 0, C.addressof(small), 8) == A.ERR_ARG and b"buflen" in lib.trpl_last_error()
+    assert lib.trpl_kernel_name(10, 128, 10, 0, 0, None, 0) == A.ERR_ARG
+    # the library reads no process-wide switch but TRPL_RCCL_LIBRARY (SURVEY 8b: no hidden globals)
+    import glob
+    src = "".join(open(f).read() for f in glob.glob(os.path.join(ROOT, "bayesian-inference-trpl_amd", "csrc", "*.h*")))
+    assert re.findall(r'getenv\("([A-Z_]+)"\)', src) == ["TRPL_RCCL_LIBRARY"]
