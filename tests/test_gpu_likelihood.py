@@ -428,3 +428,42 @@ def test_configs0_fused_likelihood_against_the_reference_cpu_path(gpu, golden):
     # bayes_io.get_data elsewhere (test_csv_ingestion_matches_reference); here the ingested values are the fixture's
     record("configs0_vs_reference_cpu_path", {"max_dex": worst_dex, "max_rel_loglik": float(rel.max()), "median_rel_loglik": float(np.median(rel)),
                                               "reference_wall_s_8_tasks": float(g["w8k_wall"]), "reference_cpu": str(g["cpu_model"])})
+
+
+@pytest.mark.parametrize("kernel", ["single", "pair"])
+def test_offgrid_observations_dense_sparse_and_on_the_window_edges(gpu, kernel):
+    """The off-grid emission is batched 64 grid columns at a time, the observations of a batch taken 64 per pass across the
+    lanes (PlSink::flush_batch): many observations per grid interval (several passes per batch, a chunk boundary inside an
+    interval), repeated times, none at all for hundreds of steps, observations exactly at t = 0, on grid nodes and at
+    t = Time, a ragged count per curve, with and without the reference's float32 staging and self-normalisation -- against
+    STRICT (the serial column-by-column emission, emit()) and against the reference's own order of operations on the stored
+    PL matrix (trpl_solve_pl, log10, the interp1d form of bayeslib.py:189, probs.prob)."""
+    w = gpu.workloads
+    ini, lens = w.power_scan(128)
+    S, T = 37, 333                                              # an odd batch, a last batch of 14 columns
+    Time = T * DT
+    X = w.samples(S, seed=23)
+    X[:, 12] = np.linspace(-0.2, 0.2, S)
+    rng = np.random.default_rng(17)
+    sim_t = np.linspace(0, Time, T + 1)
+    dense = np.sort(rng.uniform(0.0, 70 * DT, 4000))            # ~57 observations per interval over the first 70 steps
+    times = [np.concatenate([[0.0, 0.0], dense, np.repeat(sim_t[[90, 91, 128]], 3), [Time - 1e-9, Time, Time]]),   # a gap of 200 steps
+             np.sort(rng.uniform(0.0, Time, 129)),              # sparse: less than one per batch of 64 columns on average
+             np.concatenate([sim_t[::7], [Time]])]              # on grid nodes only
+    obs = [np.full(len(t), 18.0) - 0.2 * t for t in times]
+    for pl_f32, normalize in ((False, False), (True, False), (False, True)):
+        info, ref = {}, {}
+        P = gpu.loglik(X, ini, lens, Time, 128, T, obs, times=times, kernel=kernel, pl_f32=pl_f32, normalize=normalize, info=info)
+        Ps = gpu.loglik(X, ini, lens, Time, 128, T, obs, times=times, strict=True, pl_f32=pl_f32, normalize=normalize, info=ref)
+        assert not info["status"].any() and np.array_equal(info["iters_total"], ref["iters_total"])
+        assert (info["floor_col"] == -1).all() and (ref["floor_col"] == -1).all()
+        gate = 2e-6 if pl_f32 else 1e-9                          # float32 staging: an ulp of log10 PL can flip with the state's last bits
+        assert np.max(np.abs(info["sse"] / ref["sse"] - 1)) < gate, (pl_f32, normalize)
+        assert np.max(np.abs(P / Ps - 1)) < gate
+        if pl_f32 or normalize:
+            continue
+        for c in range(3):                                      # the reference's loop on the stored PL
+            pl, _, _, _ = gpu.solve_pl(X[:, :12], lens[c], Time, 128, T, ini[c], kernel=kernel)
+            lg = gpu.interp_rows(sim_t, np.log10(pl), np.sort(times[c]))
+            want = np.sum((lg + X[:, 12:13] - obs[c][np.argsort(times[c], kind="stable")][None, :]) ** 2, axis=1)
+            assert np.max(np.abs(info["sse"][c] / want - 1)) < 1e-11, c
