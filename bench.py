@@ -137,6 +137,9 @@ def main():
         ini_c, lens_c = wl.power_scan(args.L) if args.workload == "power_scan" else wl.twothick(args.L)
         cpu_legs["cpu_baseline"] = cpu_baseline(wl, trpl_amd, ini_c, lens_c, args.T * 0.025, args.L, args.T, args.cpu_seconds)
         cpu_legs["cpu_baseline_scipy"] = cpu_baseline_scipy(wl, ini_c, lens_c, args.T * 0.025, args.L, args.T)
+        rec = cpu_reference_recorded()
+        if rec is not None:
+            cpu_legs["cpu_reference_recorded"] = rec
 
     import torch
     import torch.distributed as dist
@@ -781,6 +784,25 @@ def cpu_baseline_scipy(wl, ini, lens, Time, L, T):
             "sample": "%d seeded samples x %d curves, scipy solve_ivp(BDF, rtol 1e-5) sampled on T=%d output steps "
                       "(%.1f s on %d processes)" % (n, len(lens), T, sec, cores),
             "likelihoods_per_s_at_T": n / sec}
+
+
+def cpu_reference_recorded():
+    """What the REFERENCE'S OWN CPU path measured for BASELINE.json configs[0] (Power_scan x 64 samples through
+    bayeslib.bayes(pvSim_fallback.pvSim_cpu_fallback), has_GPU False, 8 SLURM-style array tasks) where the reference can run --
+    the development container -- as recorded in tests/golden/fallback64.npz by oracle/gen_golden.py case_fallback64.  A recorded
+    figure of another machine, NOT timed in this run (the reference never travels to the GPU box); `cpu_baseline_scipy` is its
+    pinned port timed here."""
+    path = os.path.join(ROOT, "tests", "golden", "fallback64.npz")
+    if not os.path.isfile(path):
+        return None
+    g = np.load(path)
+    out = {"kind": "reference", "measured": "development container, recorded in tests/golden/fallback64.npz", "cores": int(g["ntasks"]),
+           "cpu_model": str(g["cpu_model"]), "samples": 64, "curves": 3, "unit": "system-timesteps/s"}
+    for tag, name in (("w8k", "bench_window"), ("full", "full_window")):
+        T, wall = int(g[tag + "_T"]), float(g[tag + "_wall"])
+        out[name] = {"T": T, "wall_s": wall, "value": 64 * 3 * (T + 1) / wall, "likelihoods_per_s": 64 / wall,
+                     "model_seconds_per_system": float(g[tag + "_model_seconds"].sum()) / 192}
+    return out
 
 
 if __name__ == "__main__":
