@@ -293,46 +293,67 @@ def simulate(model, e_data, P, X, plI, plI_int, num_curves, sim_params, init_par
     # P[e, j] receives its curves in the same order either way, so the loops can be swapped: blocks outside,
     # and -- when the model is this package's own (re-entrant: every call runs on a private stream) -- the
     # block's curves solved concurrently from a few host threads, which is what fills the chip when the
-    # blocks are as small as the reference's default 1024 samples.
+    # blocks are as small as the reference's default 1024 samples.  Since round 5 a worker also does its curve's
+    # normalisation, fastlog and time interpolation (the calls release the GIL), and the next block's curves are
+    # submitted while this thread accumulates the current block's squared errors with prob() in curve order: the
+    # same calls on the same data in the same order per P[e, j], overlapped (production shape, sims_per_gpu 1024:
+    # 147 s -> see DESIGN.md section 5).
     overlap = model is pvSim and bool(gpu_info.get("overlap_curves", True)) and num_curves > 1
     ncol = T // sim_params[4] + 1
+    obs_times = [[np.asarray(exp[0][c], dtype=float) for c in range(num_curves)] for exp in e_data]
+    on_grid = [[almost_equal(sim_t, t) for t in per_curve] for per_curve in obs_times]        # :173,:182-183
 
-    def solve_curve(ic_num, blk, size):
+    def process_curve(ic_num, blk, size):
         par = list(sim_params)
         par[0] = thicknesses[ic_num]                                      # :119
         buf = np.empty((size, ncol), dtype=pl_dtype)                      # :137
         sec = model(buf, None, None, None, X[blk:blk + size, :-1], par, init_params[ic_num], None, None,
                     int(gpu_info.get("max_sims_per_block", 1)), init_mode="points")      # :93,:146
-        return buf, sec
+        misc = 0.0
+        if NORMALIZE:                                                     # :150-154
+            buf /= buf[:, :1].copy()
+        if LOG_PL:                                                        # :155-157
+            misc += fastlog(buf, sys.float_info.min, device=device)
+        ints = []
+        for e in range(len(e_data)):                                      # :168
+            if on_grid[e][ic_num]:
+                ints.append(buf)
+            else:                                                         # :184-191
+                clock0 = time.perf_counter()
+                ints.append(interp_rows(sim_t, buf, obs_times[e][ic_num]))
+                misc += time.perf_counter() - clock0
+        return buf, ints, sec, misc
 
+    blocks = list(range(gpu_id * group, len(X), num_gpus * group))        # :131
     pool = None
     if overlap:
         from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(max_workers=min(num_curves, 8))
+
+    def submit(blk):
+        size = min(group, len(X) - blk)
+        return [pool.submit(process_curve, c, blk, size) for c in range(num_curves)]
+
     try:
-        for blk in range(gpu_id * group, len(X), num_gpus * group):       # :131
+        ahead = submit(blocks[0]) if overlap and blocks else None
+        for bi, blk in enumerate(blocks):
             size = min(group, len(X) - blk)
             if logger is not None:
                 logger.info("Calculating {} of {}".format(blk, len(X)))
-            pending = [pool.submit(solve_curve, c, blk, size) for c in range(num_curves)] if overlap else None
+            pending = ahead
+            if overlap:
+                ahead = submit(blocks[bi + 1]) if bi + 1 < len(blocks) else None
+            mag = np.ascontiguousarray(X[blk:blk + size, -1])
             for ic_num in range(num_curves):                              # :117
                 sim_params[0] = thicknesses[ic_num]                       # :119 (the caller's list is mutated, as there)
-                plI[gpu_id], sec = pending[ic_num].result() if overlap else solve_curve(ic_num, blk, size)
+                plI[gpu_id], ints, sec, misc = pending[ic_num].result() if overlap else process_curve(ic_num, blk, size)
                 solver_time[gpu_id] += sec
-                if NORMALIZE:                                             # :150-154
-                    plI[gpu_id] /= plI[gpu_id][:, :1].copy()
-                if LOG_PL:                                                # :155-157
-                    misc_time[gpu_id] += fastlog(plI[gpu_id], sys.float_info.min, device=device)
-                for e, exp in enumerate(e_data):                          # :168
-                    times, values = np.asarray(exp[0][ic_num], dtype=float), exp[1][ic_num]
-                    if almost_equal(sim_t, times):                        # :173,:182-183
-                        plI_int[gpu_id] = plI[gpu_id]
-                    else:                                                 # :184-191
-                        clock0 = time.perf_counter()
-                        plI_int[gpu_id] = interp_rows(sim_t, plI[gpu_id], times)
-                        misc_time[gpu_id] += time.perf_counter() - clock0
-                    err_sq_time[gpu_id] += prob(P[e, blk:blk + size], plI_int[gpu_id], values, None,
-                                                np.ascontiguousarray(X[blk:blk + size, -1]), device=device)
+                misc_time[gpu_id] += misc
+                for e, exp in enumerate(e_data):
+                    plI_int[gpu_id] = ints[e]
+                    err_sq_time[gpu_id] += prob(P[e, blk:blk + size], ints[e], exp[1][ic_num], None, mag, device=device)
+                if overlap:
+                    pending[ic_num] = None                                # let the block's buffers go as soon as they are used
     finally:
         if pool is not None:
             pool.shutdown(wait=True)
