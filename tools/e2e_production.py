@@ -22,7 +22,6 @@ level A, and FAST against STRICT (floor_col of every system, likelihood gap of t
     python tools/e2e_production.py [--S 131072] [--levels A,B1024,B16384] [--out gpurun_out/r5/e2e_production.json]
 """
 import argparse
-import csv
 import gzip
 import json
 import logging
