@@ -467,3 +467,38 @@ def test_offgrid_observations_dense_sparse_and_on_the_window_edges(gpu, kernel):
             lg = gpu.interp_rows(sim_t, np.log10(pl), np.sort(times[c]))
             want = np.sum((lg + X[:, 12:13] - obs[c][np.argsort(times[c], kind="stable")][None, :]) ** 2, axis=1)
             assert np.max(np.abs(info["sse"][c] / want - 1)) < 1e-11, c
+
+
+def test_driver_levels_agree_on_grid_prefix_observations_across_blocks(gpu, oracle):
+    """The production shape in small (tools/e2e_production.py): observation times that are a PREFIX of the simulation grid, of
+    different lengths per curve, S not a multiple of sims_per_gpu.  driver.bayes through (A) the fused level -- which routes grid
+    prefixes to the on-grid entry -- , (A') the fused level with gpu_info["interpolate_prefix"] (the literal in-kernel
+    interpolation, trpl_loglik_obs) and (B) the reference's call sequence pvSim -> fastlog -> interpolation -> prob with the
+    curves of a block and the next block overlapped by host threads (5 blocks, the last one short): the same likelihoods --
+    A against A' to 1e-13 (interpolating at a node returns the node's value to one rounding), B against A to the float32
+    staging both emulate -- and the oracle's restatement of bayeslib.simulate within 2e-5 (float32 staging, as in the goldens)."""
+    w = gpu.workloads
+    sm = gpu.sampler
+    ini, lens = w.power_scan(128)
+    T, Time, S = 240, 6.0, 37
+    sim_t = np.linspace(0, Time, T + 1)
+    n_obs = (101, 161, 241)
+    mark = (w.MARKED_POINT * gpu.UNIT_CONVERSIONS)[None, :-1]
+    vals = [np.log10(oracle.pvsim(mark, lens[c], Time, 128, T, ini[c])["plI"][0][:n]) + 0.05 for c, n in enumerate(n_obs)]
+    e_data = [([sim_t[:n] for n in n_obs], vals, [np.ones(n) for n in n_obs])]
+    sim_flags = {"load_PL_from_file": False, "override_equal_auger": False, "override_equal_mu": False, "override_equal_s": False,
+                 "log_pl": True, "self_normalize": False, "random_sample": True, "num_points": S}
+    simPar = [2000.0, Time, 128, T, 1, (0, 100), 7, 10000]
+    box = (sm.DEFAULT_MINX * sm.UNIT_CONVERSIONS, sm.DEFAULT_MAXX * sm.UNIT_CONVERSIONS, sm.DEFAULT_DO_LOG)
+    res = {}
+    for name, info in (("A", {"sims_per_gpu": 16, "fused": True}), ("A_literal", {"sims_per_gpu": 16, "fused": True, "interpolate_prefix": True}),
+                       ("B", {"sims_per_gpu": 8}), ("B_serial", {"sims_per_gpu": 8, "overlap_curves": False})):
+        gpu_info = dict(num_gpus=1, has_GPU=True, max_sims_per_block=1, **info)
+        _, P, X = gpu.bayes(gpu.pvSim, None, None, *box, ini, list(simPar), e_data, sim_flags, gpu_info, rng=np.random.RandomState(42))
+        res[name] = P[0].copy()
+    assert np.isfinite(res["A"]).all()
+    assert np.max(np.abs(res["A_literal"] / res["A"] - 1)) < 1e-13
+    assert np.array_equal(res["B"], res["B_serial"])                       # overlapping changes no bit
+    assert np.max(np.abs(res["B"] / res["A"] - 1)) < 1e-7                  # (blocks of 8 run the one-system kernel, the fused 16 x 3 too)
+    want = oracle.simulate_loglik(X, ini, lens, Time, 128, T, [(e_data[0][0], e_data[0][1])], sims_per_gpu=8, nthreads=nthreads())[0]
+    assert np.max(np.abs(res["B"] / want - 1)) < 2e-5 and np.max(np.abs(res["A"] / want - 1)) < 2e-5
