@@ -58,7 +58,7 @@ def flag_bundle(m, L=None):
     return ((int(m) - 1) & 0xF) << 8
 
 KERNEL_FAST, KERNEL_FAST_PAIR, KERNEL_STRICT, KERNEL_FP32, KERNEL_MIXED, KERNEL_HIST32 = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_SNAPS = 16
 
 
@@ -75,6 +75,7 @@ _pd = C.POINTER(C.c_double)
 SIGNATURES = {
     "trpl_abi_version": [],
     "trpl_last_error": [],
+    "trpl_has_experimental": [],
     "trpl_device_count": [],
     "trpl_pair_table": [_vp, _vp, _i32, _i32, _i64, _f64, _vp, _vp, _vp, _vp],
     "trpl_solve_pl": [_vp, _i64, _f64, _f64, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _i64, _vp, _vp, _u32,
@@ -261,6 +262,11 @@ def lib():
 def check(rc):
     if rc != OK:
         raise TrplError(rc, lib().trpl_last_error().decode("utf-8", "replace"))
+
+
+def has_experimental():
+    """True when the loaded library was built with `make EXPERIMENTAL=1` (TRPL_FLAG_MIXED / TRPL_FLAG_HIST32 steppers)."""
+    return hasattr(lib(), "trpl_has_experimental") and bool(lib().trpl_has_experimental())
 
 
 def kernel_flag(kernel):

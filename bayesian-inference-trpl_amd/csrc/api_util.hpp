@@ -112,6 +112,25 @@ struct HostMap {
     }
 };
 
+// Optional profiler ranges (ROCTx) around the host-buffer entry points, so that a marker trace of an UNMODIFIED caller
+// (`rocprofv3 --marker-trace --kernel-trace -- python parallel_bayes_gpu.py`) shows the reference's three timed phases
+// by name -- pvSim (pvSimPCR.py:378-381), fastlog (probs.py:79-84), prob (probs.py:51-61) -- instead of anonymous kernels
+// and copies.  No link dependency (like RCCL): the two symbols are taken from whatever the process already exports
+// (rocprofv3 --marker-trace preloads librocprofiler-sdk-roctx.so), else from libroctx64.so if dlopen finds it; absent
+// => every range is a no-op (one predictable branch per call).  trpl_api.hip holds the binding.
+struct RoctxApi {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+};
+const RoctxApi &roctx();
+struct ProfRange {
+    bool on;
+    explicit ProfRange(const char *name) : on(roctx().push != nullptr) { if (on) (void)roctx().push(name); }
+    ~ProfRange() { if (on) (void)roctx().pop(); }
+    ProfRange(const ProfRange &) = delete;
+    ProfRange &operator=(const ProfRange &) = delete;
+};
+
 int select_device(int32_t device);          // hipSetDevice with range check (trpl_api.hip)
 int check_grid(int32_t L, int64_t T, int32_t plT, int32_t max_iter, double time_ns);
 // the observation brackets of trpl_loglik_obs are host data in the host-buffer calls: sorted, in [1, T]
@@ -120,6 +139,8 @@ int check_brackets(const int32_t *obs_hi, const double *obs_dx, const double *ob
 // which FAST kernel a logical batch of nsys systems runs (flags may force it); see trpl_kernel_variant
 bool pick_pair_kernel(int64_t nsys, int32_t L, int64_t steps, uint32_t flags);
 int check_variant_flags(uint32_t flags, int32_t L);
+// every flag / shape combination a stepper launch refuses (trpl_api.hip); launch() and trpl_kernel_name share it
+int check_launch(uint32_t flags, int32_t L, int64_t steps, bool snap, bool resume);
 // flags with the kernel variant of the logical batch pinned (TRPL_FLAG_KERNEL_PAIR / _SINGLE set)
 uint32_t pin_variant(uint32_t flags, int64_t nsys, int32_t L, int64_t steps);
 // time steps a likelihood launch takes: up to the last observation (on-grid), T off-grid

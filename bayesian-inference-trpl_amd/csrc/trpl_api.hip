@@ -2,6 +2,7 @@
 // argument checks, the per-curve constants of pvSim (pvSimPCR.py:314-331), staging for the
 // host-buffer calls, launches.  Nothing here throws across the ABI.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -26,6 +27,27 @@ int api_fail(int code, const char *fmt, ...)
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
     return code;
+}
+
+const RoctxApi &roctx()
+{
+    static const RoctxApi api = [] {
+        RoctxApi a;
+        void *push = dlsym(RTLD_DEFAULT, "roctxRangePushA"), *pop = dlsym(RTLD_DEFAULT, "roctxRangePop");
+        if (!push || !pop) {
+            void *dl = nullptr;
+            for (const char *n : {"libroctx64.so.4", "libroctx64.so"})
+                if ((dl = dlopen(n, RTLD_NOW | RTLD_LOCAL)) != nullptr) break;
+            push = dl ? dlsym(dl, "roctxRangePushA") : nullptr;
+            pop = dl ? dlsym(dl, "roctxRangePop") : nullptr;
+        }
+        if (push && pop) {
+            a.push = (int (*)(const char *))push;
+            a.pop = (int (*)())pop;
+        }
+        return a;
+    }();
+    return api;
 }
 
 int check_grid(int32_t L, int64_t T, int32_t plT, int32_t max_iter, double time_ns)
@@ -174,6 +196,50 @@ uint32_t pin_variant(uint32_t flags, int64_t nsys, int32_t L, int64_t steps)
     return flags | (pick_pair_kernel(nsys, L, steps, flags) ? TRPL_FLAG_KERNEL_PAIR : TRPL_FLAG_KERNEL_SINGLE);
 }
 
+// Everything a stepper launch refuses because of its flags and shape, in ONE place: launch() and trpl_kernel_name run the
+// same checks, so a kernel name is only ever returned for an instantiation that exists and that the launch would run.
+// snap: state snapshots requested; resume: the launch continues from a checkpoint.
+int check_launch(uint32_t flags, int32_t L, int64_t steps, bool snap, bool resume)
+{
+    if (!pow2(L) || L < 4 || L > 512) return api_fail(TRPL_ERR_ARG, "L=%d must be a power of two in [4, 512]", L);
+    if (int rc = check_variant_flags(flags, L)) return rc;
+    if (((flags >> 14) & 7u) > 5u) return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_BDF_ORDER(%u): the order cap must be 1 .. 5 (0: the reference's ramp)", (flags >> 14) & 7u);
+    const int32_t bundle = (int32_t)((flags >> 8) & 0xF) + 1;             // TRPL_FLAG_BUNDLE(m)
+#ifndef TRPL_EXPERIMENTAL
+    if (flags & (TRPL_FLAG_MIXED | TRPL_FLAG_HIST32))
+        return api_fail(TRPL_ERR_UNSUPPORTED, "%s: this library was built without the experimental steppers (measured and rejected, "
+                        "DESIGN.md section 7); rebuild with `make EXPERIMENTAL=1` to run them",
+                        (flags & TRPL_FLAG_MIXED) ? "TRPL_FLAG_MIXED" : "TRPL_FLAG_HIST32");
+#endif
+    if (flags & TRPL_FLAG_HIST32) {
+        if (flags & (TRPL_FLAG_STRICT | TRPL_FLAG_FP32 | TRPL_FLAG_MIXED | TRPL_FLAG_KERNEL_PAIR))
+            return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_HIST32 excludes TRPL_FLAG_STRICT, TRPL_FLAG_FP32, TRPL_FLAG_MIXED and TRPL_FLAG_KERNEL_PAIR");
+        if (L != 256 && L != 512) return api_fail(TRPL_ERR_UNSUPPORTED, "TRPL_FLAG_HIST32: the fp32-difference history is built for L = 256 and 512 (got %d)", L);
+        if (snap || resume || bundle > 1)
+            return api_fail(TRPL_ERR_UNSUPPORTED, "snapshots, resume and bundles are not available with TRPL_FLAG_HIST32");
+    }
+    if (bundle > 1 && (flags & (TRPL_FLAG_FP32 | TRPL_FLAG_MIXED | TRPL_FLAG_KERNEL_PAIR)))
+        return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_BUNDLE goes with TRPL_FLAG_STRICT or the plain fp64 one-system stepper only");
+    if (bundle > 1 && !(flags & TRPL_FLAG_STRICT) && L > 128)
+        return api_fail(TRPL_ERR_UNSUPPORTED, "TRPL_FLAG_BUNDLE without TRPL_FLAG_STRICT is built for L <= 128 (got %d)", L);
+    if (bundle > trpl::bundle_cap(L))
+        return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_BUNDLE(%d): at most %d systems per bundle at L = %d", bundle, trpl::bundle_cap(L), L);
+    if (flags & TRPL_FLAG_FP32) {
+        if (flags & (TRPL_FLAG_STRICT | TRPL_FLAG_MIXED)) return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_FP32 excludes TRPL_FLAG_STRICT and TRPL_FLAG_MIXED");
+        if (L < 128) return api_fail(TRPL_ERR_UNSUPPORTED, "the fp32 stepper is built for L >= 128 (got %d)", L);
+        if (snap) return api_fail(TRPL_ERR_UNSUPPORTED, "state snapshots are not available with TRPL_FLAG_FP32");
+        if (steps > TRPL_FP32_MAX_STEPS && !(flags & TRPL_FLAG_FP32_LONG))
+            return api_fail(TRPL_ERR_UNSUPPORTED, "TRPL_FLAG_FP32 over %lld time steps: an fp32 state loses the decay beyond ~%d steps "
+                            "(PL errors of percents, then tens of percents: include/trpl.h); use the fp64 path, or add "
+                            "TRPL_FLAG_FP32_LONG (Python wrappers: fp32=\"long\") for a screening pass", (long long)steps, TRPL_FP32_MAX_STEPS);
+    }
+    if (flags & TRPL_FLAG_MIXED) {
+        if (flags & TRPL_FLAG_STRICT) return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_MIXED and TRPL_FLAG_STRICT exclude each other");
+        if (L < 128) return api_fail(TRPL_ERR_UNSUPPORTED, "the mixed-precision stepper is built for L >= 128 (got %d)", L);
+    }
+    return TRPL_OK;
+}
+
 int select_device(int32_t device)
 {
     int n = 0;
@@ -192,38 +258,16 @@ namespace {
 // steps: how many time steps the launch will take (T, or up to the last observation in likelihood mode)
 int launch(const trpl::StepArgs &a_in, uint32_t flags, hipStream_t st, int64_t steps)
 {
-    if (int rc = check_variant_flags(flags, a_in.L)) return rc;
-    if (((flags >> 14) & 7u) > 5u) return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_BDF_ORDER(%u): the order cap must be 1 .. 5 (0: the reference's ramp)", (flags >> 14) & 7u);
+    if (int rc = check_launch(flags, a_in.L, steps, a_in.n_snap > 0, a_in.resN != nullptr)) return rc;
     trpl::StepArgs a = a_in;
     a.bundle = (int32_t)((flags >> 8) & 0xF) + 1;             // TRPL_FLAG_BUNDLE(m)
-    if (flags & TRPL_FLAG_HIST32) {
-        if (flags & (TRPL_FLAG_STRICT | TRPL_FLAG_FP32 | TRPL_FLAG_MIXED | TRPL_FLAG_KERNEL_PAIR))
-            return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_HIST32 excludes TRPL_FLAG_STRICT, TRPL_FLAG_FP32, TRPL_FLAG_MIXED and TRPL_FLAG_KERNEL_PAIR");
-        if (a.L != 256 && a.L != 512) return api_fail(TRPL_ERR_UNSUPPORTED, "TRPL_FLAG_HIST32: the fp32-difference history is built for L = 256 and 512 (got %d)", a.L);
-        if (a.n_snap > 0 || a.resN != nullptr || a.bundle > 1)
-            return api_fail(TRPL_ERR_UNSUPPORTED, "snapshots, resume and bundles are not available with TRPL_FLAG_HIST32");
-    }
-    if (a.bundle > 1 && (flags & (TRPL_FLAG_FP32 | TRPL_FLAG_MIXED | TRPL_FLAG_KERNEL_PAIR)))
-        return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_BUNDLE goes with TRPL_FLAG_STRICT or the plain fp64 one-system stepper only");
-    if (a.bundle > 1 && !(flags & TRPL_FLAG_STRICT) && a.L > 128)
-        return api_fail(TRPL_ERR_UNSUPPORTED, "TRPL_FLAG_BUNDLE without TRPL_FLAG_STRICT is built for L <= 128 (got %d)", a.L);
-    if (a.bundle > trpl::bundle_cap(a.L))
-        return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_BUNDLE(%d): at most %d systems per bundle at L = %d", a.bundle, trpl::bundle_cap(a.L), a.L);
     if (flags & TRPL_FLAG_FP32) {
-        if (flags & (TRPL_FLAG_STRICT | TRPL_FLAG_MIXED)) return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_FP32 excludes TRPL_FLAG_STRICT and TRPL_FLAG_MIXED");
-        if (a.L < 128) return api_fail(TRPL_ERR_UNSUPPORTED, "the fp32 stepper is built for L >= 128 (got %d)", a.L);
-        if (a.n_snap > 0) return api_fail(TRPL_ERR_UNSUPPORTED, "state snapshots are not available with TRPL_FLAG_FP32");
-        if (steps > TRPL_FP32_MAX_STEPS && !(flags & TRPL_FLAG_FP32_LONG))
-            return api_fail(TRPL_ERR_UNSUPPORTED, "TRPL_FLAG_FP32 over %lld time steps: an fp32 state loses the decay beyond ~%d steps "
-                            "(PL errors of percents, then tens of percents: include/trpl.h); use the fp64 / TRPL_FLAG_MIXED "
-                            "path, or add TRPL_FLAG_FP32_LONG (Python wrappers: fp32=\"long\") for a screening pass", (long long)steps, TRPL_FP32_MAX_STEPS);
         hipError_t e32 = trpl::launch_stepper_f32(a, st);
         if (e32 != hipSuccess) return api_fail(TRPL_ERR_HIP, "fp32 stepper launch: %s", hipGetErrorString(e32));
         return TRPL_OK;
     }
+#ifdef TRPL_EXPERIMENTAL
     if (flags & TRPL_FLAG_MIXED) {
-        if (flags & TRPL_FLAG_STRICT) return api_fail(TRPL_ERR_ARG, "TRPL_FLAG_MIXED and TRPL_FLAG_STRICT exclude each other");
-        if (a.L < 128) return api_fail(TRPL_ERR_UNSUPPORTED, "the mixed-precision stepper is built for L >= 128 (got %d)", a.L);
         hipError_t em = trpl::launch_stepper_mixed(a, st);
         if (em != hipSuccess) return api_fail(TRPL_ERR_HIP, "mixed stepper launch: %s", hipGetErrorString(em));
         return TRPL_OK;
@@ -233,6 +277,7 @@ int launch(const trpl::StepArgs &a_in, uint32_t flags, hipStream_t st, int64_t s
         if (eh != hipSuccess) return api_fail(TRPL_ERR_HIP, "hist32 stepper launch: %s", hipGetErrorString(eh));
         return TRPL_OK;
     }
+#endif
     if (pick_pair_kernel(a.S * a.C, a.L, steps, flags)) {
         build_pair_table(a);
         hipError_t ep = trpl::launch_stepper_pair(a, st);
@@ -249,6 +294,14 @@ int launch(const trpl::StepArgs &a_in, uint32_t flags, hipStream_t st, int64_t s
 extern "C" {
 
 int trpl_abi_version(void) { return TRPL_ABI_VERSION; }
+int trpl_has_experimental(void)
+{
+#ifdef TRPL_EXPERIMENTAL
+    return 1;
+#else
+    return 0;
+#endif
+}
 const char *trpl_last_error(void) { return g_err; }
 
 int trpl_kernel_variant(int64_t nsys, int32_t L, int64_t steps, uint32_t flags)
@@ -263,6 +316,10 @@ int trpl_kernel_variant(int64_t nsys, int32_t L, int64_t steps, uint32_t flags)
 int trpl_kernel_name(int64_t nsys, int32_t L, int64_t steps, uint32_t flags, int32_t snapshots, char *buf, int64_t buflen)
 {
     if (!buf || buflen < 1) return api_fail(TRPL_ERR_ARG, "buf must hold at least one byte");
+    buf[0] = 0;
+    // the checks of a launch: no name for a combination launch() refuses or for an instantiation that does not exist
+    // (`snapshots` covers snapshots AND resume; the fp32 stepper has one instantiation and accepts a resume)
+    if (int rc = check_launch(flags, L, steps, snapshots != 0 && !(flags & TRPL_FLAG_FP32), false)) return rc;
     const char *tf[2] = {"false", "true"};
     const int snap = snapshots != 0, bundle = ((flags >> 8) & 0xF) != 0;
     int n;
@@ -463,6 +520,7 @@ int trpl_solve_pl_snap(const double *matpar, int64_t S, double length_nm, double
                        const int64_t *snap_steps, int32_t n_snap, double *plN, double *plP, double *plE,
                        uint32_t flags, int32_t device, double *seconds)
 {
+    ProfRange range("trpl_solve_pl (pvSim)");
     return solve_pl_host_impl(matpar, S, length_nm, time_ns, L, T, plT, tol_exp, max_iter, dN, 0, nullptr, nullptr, nullptr,
                               plI, pl_elem_bytes, pl_ld, status, iters_total, snap_steps, n_snap, plN, plP, plE, flags,
                               device, seconds);
@@ -476,6 +534,7 @@ int trpl_solve_pl_resume(const double *matpar, int64_t S, double length_nm, doub
 {
     if (!resN || !resP || !resE) return api_fail(TRPL_ERR_ARG, "resN, resP and resE must not be NULL");
     if (t0 < 4 || t0 > T) return api_fail(TRPL_ERR_ARG, "t0=%lld must be in [4, T]: a resume needs five BDF levels", (long long)t0);
+    ProfRange range("trpl_solve_pl_resume (pvSim, init_mode continue)");
     return solve_pl_host_impl(matpar, S, length_nm, time_ns, L, T, plT, tol_exp, max_iter, nullptr, t0, resN, resP, resE, plI,
                               pl_elem_bytes, pl_ld, status, iters_total, snap_steps, n_snap, plN, plP, plE, flags, device,
                               seconds);
@@ -513,6 +572,7 @@ int trpl_log10_clamp(void *x, int32_t elem_bytes, int64_t rows, int64_t cols, in
     if (rows == 0 || cols == 0) return TRPL_OK;
     if (!x) return api_fail(TRPL_ERR_ARG, "x must not be NULL");
     if (int rc = select_device(device)) return rc;
+    ProfRange range("trpl_log10_clamp (fastlog)");
     HostPin pin;
     CallScope cs;
     HIP_TRY(cs.open());
@@ -552,6 +612,7 @@ int trpl_sse_accumulate(double *P, const void *plI, int32_t elem_bytes, int64_t 
     if (rows == 0) return TRPL_OK;
     if (!P || !mag || (n_obs && (!plI || !values))) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");
     if (int rc = select_device(device)) return rc;
+    ProfRange range("trpl_sse_accumulate (prob)");
     HostPin pin;
     CallScope cs;
     HIP_TRY(cs.open());
@@ -736,6 +797,7 @@ int trpl_loglik(const double *X, int64_t S, int32_t C, const double *lengths_nm,
                 int64_t obs_ld, const int64_t *n_obs, double *P, double *sse, int32_t *status,
                 int64_t *iters_total, int32_t *floor_col, uint32_t flags, int32_t device, double *seconds)
 {
+    ProfRange range("trpl_loglik (pvSim + fastlog + prob, fused)");
     return loglik_host_impl(X, S, C, lengths_nm, time_ns, L, T, plT, tol_exp, max_iter, dN, obs, nullptr, nullptr,
                             nullptr, obs_ld, n_obs, P, sse, status, iters_total, floor_col, flags, device, seconds);
 }
@@ -747,6 +809,7 @@ int trpl_loglik_obs(const double *X, int64_t S, int32_t C, const double *lengths
                     int32_t *floor_col, uint32_t flags, int32_t device, double *seconds)
 {
     if (!obs_hi || !obs_dx || !obs_h) return api_fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h must not be NULL");
+    ProfRange range("trpl_loglik_obs (pvSim + fastlog + griddata + prob, fused)");
     return loglik_host_impl(X, S, C, lengths_nm, time_ns, L, T, 1, tol_exp, max_iter, dN, obs, obs_hi, obs_dx, obs_h,
                             obs_ld, n_obs, P, sse, status, iters_total, floor_col, flags, device, seconds);
 }

@@ -81,6 +81,7 @@ int trpl_loglik_multi(const double *X, int64_t S, int32_t C, const double *lengt
                       const int64_t *n_obs, double *P, double *sse, int32_t *status, int64_t *iters_total,
                       int32_t *floor_col, uint32_t flags, const int32_t *devices, int32_t n_devices, double *seconds)
 {
+    ProfRange range("trpl_loglik_multi (sample shards over the visible devices)");
     if (int rc = check_grid(L, T, plT, max_iter, time_ns)) return rc;
     if (S < 0) return api_fail(TRPL_ERR_ARG, "S must be >= 0");
     if (C < 1 || C > TRPL_MAX_CURVES) return api_fail(TRPL_ERR_ARG, "C=%d must be in [1, %d]", C, TRPL_MAX_CURVES);

@@ -40,6 +40,24 @@ def is_grid_prefix(times, sim_t, threshold=1e-10):
     return bool(np.all(np.abs(times - ref) <= threshold * scale))
 
 
+def observations_on_grid(times, sim_t, literal=False):
+    """How the fused level routes one curve's observation times.  True: compared point by point with the first
+    len(times) simulation columns (entry points trpl_loglik / the on-grid form of trpl_loglik_from_pl_dev); False:
+    interpolated in the kernel (trpl_loglik_obs / the bracket form).  Default rule: a PREFIX of the simulation grid is on
+    the grid.  literal (gpu_info["interpolate_prefix"]): the reference's own test -- only the FULL grid bypasses the
+    interpolation (bayeslib.py:173,:182-183), a prefix goes through it like any other set of times (:184-191)."""
+    if literal:
+        return almost_equal(sim_t, np.asarray(times, dtype=float))
+    return is_grid_prefix(times, sim_t)
+
+
+def fused_entry_point(exp_times, sim_t, num_curves, literal=False):
+    """Name of the C entry point driver.simulate's fused level calls for one experiment (single-experiment branch): every
+    curve on the grid -> "trpl_loglik", else "trpl_loglik_obs".  bench.py labels its e2e record with it."""
+    on = all(observations_on_grid(exp_times[c], sim_t, literal) for c in range(num_curves))
+    return "trpl_loglik" if on else "trpl_loglik_obs"
+
+
 def interp_rows(sim_t, pl, times):
     """Vectorised 1-D linear interpolation of every row of `pl` from sim_t onto `times`; the
     arithmetic of scipy's interp1d/griddata, which the reference applies row by row
@@ -66,6 +84,19 @@ def bracket_times(sim_t, times):
     hi = np.clip(np.searchsorted(sim_t, times), 1, len(sim_t) - 1)
     lo = hi - 1
     return hi.astype(np.int32), times - sim_t[lo], sim_t[hi] - sim_t[lo]
+
+
+DEFAULT_MAX_HOST_BYTES = 16 << 30      # gpu_info["max_host_bytes"]: PL results the unfused overlapped path may hold at once
+
+
+def unfused_curve_bytes(size, ncol, pl_dtype, n_interp, num_curves):
+    """Host bytes ONE (block, curve) result of the unfused path holds: the block's PL matrix (size x ncol in the caller's
+    PL dtype, bayeslib.py:137) + a float64 interpolated copy (size x n_obs) per experiment whose times are off the grid
+    (:184-191).  n_interp: the n_obs of every (experiment, curve) that is interpolated, 0 for the others, experiment-major;
+    the largest curve counts."""
+    n_interp = np.asarray(n_interp, dtype=np.int64).reshape(-1, max(int(num_curves), 1))
+    worst = int(n_interp.sum(axis=0).max()) if n_interp.size else 0
+    return int(size) * (int(ncol) * np.dtype(pl_dtype).itemsize + 8 * worst)
 
 
 def loglik(X, init_params, lengths, Time, L, T, obs, tol=7, MAX=10000, plT=1, P=None, pl_f32=False,
@@ -172,11 +203,12 @@ def _bundle_of(gpu_info, L):
 
 
 def _simulate_resident(e_data, P, X, num_curves, thicknesses, sim_params, init_params, normalize, pl_dtype, group,
-                       num_gpus, gpu_id, device, solver_time, err_sq_time, sim_t, bundle=1):
+                       num_gpus, gpu_id, device, solver_time, err_sq_time, sim_t, bundle=1, literal=False):
     """Several experiments, fused option on: the reference's own loop order -- curves -> sample blocks ->
     experiments (bayeslib.py:117-171) -- with the block's PL matrix kept in HBM: one solve per (curve, block)
     (trpl_solve_pl_dev), then one pass over it per experiment (trpl_loglik_from_pl_dev: normalise, clamp,
-    log10, time interpolation, squared error).  Only X goes in and P comes out."""
+    log10, time interpolation, squared error).  Only X goes in and P comes out.  literal: observations_on_grid's switch
+    (gpu_info["interpolate_prefix"])."""
     import time
 
     import torch
@@ -195,7 +227,7 @@ def _simulate_resident(e_data, P, X, num_curves, thicknesses, sim_params, init_p
             for c in range(num_curves):
                 t = np.asarray(exp[0][c], dtype=float)
                 o = np.asarray(exp[1][c], dtype=float)
-                if is_grid_prefix(t, sim_t):                                  # bayeslib.py:182-183, and prefixes of the grid (below)
+                if observations_on_grid(t, sim_t, literal):                   # bayeslib.py:182-183, and prefixes of the grid (below)
                     per_curve.append((torch.from_numpy(np.ascontiguousarray(o)).to(dev), None))
                 else:
                     order = np.argsort(t, kind="stable")
@@ -264,7 +296,7 @@ def simulate(model, e_data, P, X, plI, plI_int, num_curves, sim_params, init_par
     if fused and len(e_data) > 1 and gpu_info.get("devices") is None:
         _simulate_resident(e_data, P, X, num_curves, thicknesses, sim_params, init_params, NORMALIZE, pl_dtype,
                            group, num_gpus, gpu_id, device, solver_time, err_sq_time, sim_t,
-                           bundle=_bundle_of(gpu_info, L))
+                           bundle=_bundle_of(gpu_info, L), literal=bool(gpu_info.get("interpolate_prefix", False)))
         return
     if fused:
         # An experiment sampled exactly on the full simulation grid is compared point by point (the reference's bypass,
@@ -273,13 +305,12 @@ def simulate(model, e_data, P, X, plI, plI_int, num_curves, sim_params, init_par
         # shape test sends them to griddata -- are interpolated AT grid nodes, where the interp1d form returns the node's own
         # value to one rounding: they take the on-grid entry point too (batched emission, curve-pair table: 21 % faster on
         # the production shape, likelihoods equal to 7e-15, tools/bench_prefix_vs_interp.py); gpu_info["interpolate_prefix"]
-        # = True keeps the literal interpolation.
+        # = True keeps the literal interpolation (both fused branches: this one and _simulate_resident).
         literal = bool(gpu_info.get("interpolate_prefix", False))
         for blk in range(gpu_id * group, len(X), num_gpus * group):
             size = min(group, len(X) - blk)
             for e, exp in enumerate(e_data):
-                on_grid = all((almost_equal(sim_t, np.asarray(exp[0][c], dtype=float)) if literal else
-                               is_grid_prefix(exp[0][c], sim_t)) for c in range(num_curves))
+                on_grid = fused_entry_point(exp[0], sim_t, num_curves, literal) == "trpl_loglik"
                 info = {}
                 loglik(X[blk:blk + size], init_params, thicknesses, Time, L, T,
                        [exp[1][c] for c in range(num_curves)], tol=sim_params[6], MAX=sim_params[7],
@@ -298,7 +329,8 @@ def simulate(model, e_data, P, X, plI, plI_int, num_curves, sim_params, init_par
     # submitted while this thread accumulates the current block's squared errors with prob() in curve order: the
     # same calls on the same data in the same order per P[e, j], overlapped (production shape, sims_per_gpu 1024:
     # 147 s -> see DESIGN.md section 5).
-    overlap = model is pvSim and bool(gpu_info.get("overlap_curves", True)) and num_curves > 1
+    overlap = (model is pvSim or getattr(model, "reentrant", False)) and bool(gpu_info.get("overlap_curves", True)) \
+        and num_curves > 1
     ncol = T // sim_params[4] + 1
     obs_times = [[np.asarray(exp[0][c], dtype=float) for c in range(num_curves)] for exp in e_data]
     on_grid = [[almost_equal(sim_t, t) for t in per_curve] for per_curve in obs_times]        # :173,:182-183
@@ -325,35 +357,55 @@ def simulate(model, e_data, P, X, plI, plI_int, num_curves, sim_params, init_par
         return buf, ints, sec, misc
 
     blocks = list(range(gpu_id * group, len(X), num_gpus * group))        # :131
+    tasks = [(blk, min(group, len(X) - blk), c) for blk in blocks for c in range(num_curves)]   # the order P receives them in
+    # Host memory of the overlapped path is bounded by BYTES, not by a block count: at most `window` (block, curve) results
+    # exist at once -- being solved, waiting for their turn at prob(), or still referenced by plI[gpu_id] -- and the window is
+    # what gpu_info["max_host_bytes"] (default 16 GiB) holds of unfused_curve_bytes(), capped at two blocks' curves (the
+    # round-5 schedule: this block's curves + the next block prefetched).  Below two results the path runs inline, one result
+    # at a time -- what the reference holds (bayeslib.py:137).
+    per_curve = unfused_curve_bytes(min(group, len(X)) if len(X) else 0, ncol, pl_dtype,
+                                    [0 if on_grid[e][c] else len(obs_times[e][c]) for e in range(len(e_data))
+                                     for c in range(num_curves)], num_curves)
+    budget = int(gpu_info.get("max_host_bytes", DEFAULT_MAX_HOST_BYTES))
+    window = min(2 * num_curves, budget // max(per_curve, 1))
+    if window < 2:
+        overlap = False
     pool = None
     if overlap:
+        from collections import deque
         from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(max_workers=min(num_curves, 8))
-
-    def submit(blk):
-        size = min(group, len(X) - blk)
-        return [pool.submit(process_curve, c, blk, size) for c in range(num_curves)]
-
+        pool = ThreadPoolExecutor(max_workers=min(num_curves, 8, window - 1))
     try:
-        ahead = submit(blocks[0]) if overlap and blocks else None
-        for bi, blk in enumerate(blocks):
-            size = min(group, len(X) - blk)
-            if logger is not None:
-                logger.info("Calculating {} of {}".format(blk, len(X)))
-            pending = ahead
+        nxt, queue = 0, None
+        if overlap:
+            queue = deque()
+            while nxt < len(tasks) and len(queue) < window - 1:          # + the result plI[gpu_id] keeps = window
+                blk, size, c = tasks[nxt]
+                queue.append(pool.submit(process_curve, c, blk, size))
+                nxt += 1
+        for blk, size, ic_num in tasks:
+            if ic_num == 0:
+                if logger is not None:
+                    logger.info("Calculating {} of {}".format(blk, len(X)))
+                mag = np.ascontiguousarray(X[blk:blk + size, -1])
+            sim_params[0] = thicknesses[ic_num]                           # :119 (the caller's list is mutated, as there)
             if overlap:
-                ahead = submit(blocks[bi + 1]) if bi + 1 < len(blocks) else None
-            mag = np.ascontiguousarray(X[blk:blk + size, -1])
-            for ic_num in range(num_curves):                              # :117
-                sim_params[0] = thicknesses[ic_num]                       # :119 (the caller's list is mutated, as there)
-                plI[gpu_id], ints, sec, misc = pending[ic_num].result() if overlap else process_curve(ic_num, blk, size)
-                solver_time[gpu_id] += sec
-                misc_time[gpu_id] += misc
-                for e, exp in enumerate(e_data):
-                    plI_int[gpu_id] = ints[e]
-                    err_sq_time[gpu_id] += prob(P[e, blk:blk + size], ints[e], exp[1][ic_num], None, mag, device=device)
-                if overlap:
-                    pending[ic_num] = None                                # let the block's buffers go as soon as they are used
+                res = queue.popleft().result()
+            else:
+                plI[gpu_id] = plI_int[gpu_id] = None                      # one result at a time
+                res = process_curve(ic_num, blk, size)
+            plI[gpu_id], ints, sec, misc = res
+            del res
+            solver_time[gpu_id] += sec
+            misc_time[gpu_id] += misc
+            for e, exp in enumerate(e_data):
+                plI_int[gpu_id] = ints[e]
+                err_sq_time[gpu_id] += prob(P[e, blk:blk + size], ints[e], exp[1][ic_num], None, mag, device=device)
+            del ints                                                      # plI[gpu_id] / plI_int[gpu_id] keep the last matrices, as there
+            if overlap and nxt < len(tasks):                              # the previous result is gone: the window has room
+                b2, s2, c2 = tasks[nxt]
+                queue.append(pool.submit(process_curve, c2, b2, s2))
+                nxt += 1
     finally:
         if pool is not None:
             pool.shutdown(wait=True)

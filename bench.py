@@ -84,6 +84,13 @@ def main():
     ap.add_argument("--T", type=int, default=8000,
                     help="time steps per pass (reference production: 80000; 8000 is the survey's sweep length)")
     ap.add_argument("--samples-per-gpu", type=int, default=65536)
+    ap.add_argument("--samples-total", type=int, default=None,
+                    help="rehearsals: the logical batch, cut into --gpus contiguous shards by trpl_shard_bounds -- need not be "
+                         "divisible by --gpus (default: --samples-per-gpu x --gpus, weak scaling)")
+    ap.add_argument("--rehearse-on-device0", action="store_true",
+                    help="--single-process only: all --gpus 'ranks' are device 0 (TRPL_MULTI_ALLOW_DUPLICATE_DEVICES) -- the "
+                         "N-rank logic on a one-GPU box; RCCL refuses duplicate devices, so TRPL_RCCL_LIBRARY must name a stand-in "
+                         "(tests/mock_rccl).  Not a measurement")
     ap.add_argument("--workload", default="power_scan", choices=["power_scan", "twothick"])
     ap.add_argument("--strict", action="store_true", help="bit-reproducible arithmetic mode")
     ap.add_argument("--L", type=int, default=128, help="spatial nodes (configs[4]: 512)")
@@ -166,7 +173,7 @@ def main():
     Time = T * dt_ns
     ini, lens = wl.power_scan(L) if args.workload == "power_scan" else wl.twothick(L)
     C = len(lens)
-    S_total = args.samples_per_gpu * world
+    S_total = args.samples_total if args.samples_total is not None else args.samples_per_gpu * world
     lo, hi = trpl_amd.dist.shard_bounds(S_total, world, rank)
     S = hi - lo
     X_host = wl.samples(S_total)[lo:hi]                      # same seeded draw on every rank, own shard
@@ -284,7 +291,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%s x %d samples/GPU (%d total), %d curves, L=%d nodes, T=%d steps of dt=0.025 ns, "
                                "tol=1e-%d, MAX=10000, %s, arithmetic=%s"
-                               % (args.workload, args.samples_per_gpu, S_total, C, L, T, tol,
+                               % (args.workload, -(-S_total // world), S_total, C, L, T, tol,
                                   "fp32 state" if args.fp32 else ("fp64 state + fp32 solves" if args.mixed else ("fp64, fp32-difference history" if args.hist32 else "fp64")),
                                   "strict" if args.strict else "fast"),
                    "arithmetic": "strict" if args.strict else "fast", "precision": "fp32 state" if args.fp32 else
@@ -333,6 +340,7 @@ def main():
             and not (args.fp32 or args.mixed or args.strict):
         out["e2e_production"] = e2e_production(trpl_amd)
     if rank == 0:
+        out["library"] = library_record(trpl_amd)
         attach_traffic(out, args.traffic_profile)
     out.update(cpu_legs)
     if world > 1:
@@ -352,21 +360,26 @@ def main_single_process(args):
     from trpl_amd import device as tdev
     from trpl_amd import workloads as wl
     n = args.gpus
-    if torch.cuda.device_count() < n:
+    rehearse = bool(args.rehearse_on_device0)
+    if not rehearse and torch.cuda.device_count() < n:
         raise SystemExit("bench.py --single-process --gpus %d: only %d devices visible" % (n, torch.cuda.device_count()))
+    if rehearse and not os.environ.get("TRPL_RCCL_LIBRARY"):
+        raise SystemExit("bench.py --rehearse-on-device0: RCCL refuses duplicate devices; name a stand-in collective "
+                         "library in TRPL_RCCL_LIBRARY (tests/mock_rccl)")
+    ordinals = [0] * n if rehearse else list(range(n))
     L, T, dt_ns = args.L, args.T, 0.025
     tol = args.tol if args.tol is not None else 7
     Time = T * dt_ns
     ini, lens = wl.power_scan(L) if args.workload == "power_scan" else wl.twothick(L)
     C = len(lens)
-    S_total = args.samples_per_gpu * n
+    S_total = args.samples_total if args.samples_total is not None else args.samples_per_gpu * n
     X_host = wl.samples(S_total)
     flags = (trpl_amd.FLAG_STRICT if args.strict else 0) | (trpl_amd.FLAG_MIXED if args.mixed else 0)
-    md = tdev.MultiDevice(list(range(n)))
+    md = tdev.MultiDevice(ordinals, allow_duplicate_devices=rehearse)
     bounds = md.shard_bounds(S_total)
     Xs, inis, obss, Ps, sses, sts, its = [], [], [], [], [], [], []
     for r, (lo, hi) in enumerate(bounds):
-        dev = torch.device("cuda", r)
+        dev = torch.device("cuda", ordinals[r])
         with torch.cuda.device(dev):
             ini_d = torch.from_numpy(ini).to(dev)
             mark = torch.from_numpy((wl.MARKED_POINT * trpl_amd.UNIT_CONVERSIONS)[None, :-1].copy()).to(dev)
@@ -404,13 +417,28 @@ def main_single_process(args):
     sys_steps = S_total * C * (T + 1)
     value = sys_steps * args.steps / elapsed
     tf = it_all * FLOP_PER_ITER_PER_NODE * L / (elapsed / args.steps) / 1e12
+    # what proves the ranks of this form: the communicator's size, each rank's device and PCI bus id, the all-gather payload
+    devs = []
+    for r, o in enumerate(ordinals):
+        props = torch.cuda.get_device_properties(o)
+        devs.append({"rank": r, "device": o, "name": props.name, "pci_bus_id": getattr(props, "pci_bus_id", None),
+                     "samples": bounds[r][1] - bounds[r][0]})
+    widest = max(hi - lo for lo, hi in bounds)
+    rccl = {"world": int(md.n), "backend": "rccl (ncclCommInitAll)" if not rehearse else
+            "stand-in collective library %s" % os.path.basename(os.environ["TRPL_RCCL_LIBRARY"]),
+            "devices": devs, "distinct_devices": len({(d["device"], d["pci_bus_id"]) for d in devs}),
+            "allgather_bytes": widest * 8 * n, "allgather_bytes_per_rank": widest * 8,
+            "padded_exchange": len({hi - lo for lo, hi in bounds}) > 1,
+            "note": "one ncclAllGather of ceil(S/N) fp64 per rank per step (+ the unpadding pass when shards are unequal); "
+                    "its time is inside ms_per_step (single host thread: not separated here)"}
     out = {"metric": "TRPL timesteps/sec at %d nodes (system = parameter sample x excitation; fused solve + "
                      "log-likelihood), one process driving all devices" % L,
            "value": value, "unit": "system-timesteps/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+           "value_n1_equiv": value / n, "rccl": rccl, "rehearsal_on_one_device": rehearse,
            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": "%s x %d samples/GPU (%d total), %d curves, L=%d nodes, T=%d steps of dt=0.025 ns, "
-                                  "tol=1e-%d, MAX=10000, fp64" % (args.workload, args.samples_per_gpu, S_total, C, L, T, tol),
+                                  "tol=1e-%d, MAX=10000, fp64" % (args.workload, -(-S_total // n), S_total, C, L, T, tol),
                       "samples_total": S_total, "curves": C, "L": L, "T": T,
                       "parallelism": "single process, sample-shard x%d (trpl_loglik_multi_dev)" % n,
                       "collective": "RCCL ncclAllGather (ncclCommInitAll), P resident on every device"},
@@ -493,14 +521,48 @@ def one_pass(torch, tdev, trpl_amd, wl, dev, workload, S, L, T, dt_ns, tol, flag
     it = int(iters.sum().item())
     tf = it * FLOP_PER_ITER_PER_NODE * L / (ms * 1e-3) / 1e12
     variant = trpl_amd._abi.lib().trpl_kernel_variant(S * C, L, T, flags)
-    return {"workload": "%s x %d samples, %d curves, L=%d nodes, T=%d steps of dt=0.025 ns, tol=1e-%d, fp64, arithmetic=fast"
-                        % (workload, S, C, L, T, tol),
+    fp32 = bool(flags & trpl_amd.FLAG_FP32)
+    peak = FP64_VECTOR_PEAK_TFLOPS * (2 if fp32 else 1)
+    return {"workload": "%s x %d samples, %d curves, L=%d nodes, T=%d steps of dt=0.025 ns, tol=1e-%d, %s, arithmetic=fast"
+                        % (workload, S, C, L, T, tol, "fp32 state" if fp32 else "fp64"),
             "samples": S, "curves": C, "L": L, "T": T, "tol_exp": tol, "passes": 1, "ms": ms,
             "system_timesteps_per_s": S * C * (T + 1) / (ms * 1e-3), "likelihoods_per_s_at_T": S / (ms * 1e-3),
             "inner_iterations": it, "mean_inner_iterations_per_step": it / (S * C * (T + 1)),
-            "roofline_achieved_tflops": tf, "roofline_frac": tf / FP64_VECTOR_PEAK_TFLOPS,
-            "kernel": "pair::stepper_pair_kernel" if variant == trpl_amd._abi.KERNEL_FAST_PAIR else "stepper_kernel<%d>" % L,
+            "roofline_achieved_tflops": tf, "roofline_peak_tflops": peak, "roofline_frac": tf / peak,
+            "kernel": ("pair::stepper_pair_kernel" if variant == trpl_amd._abi.KERNEL_FAST_PAIR else
+                       "%sstepper_kernel<%d>" % ("f32::" if fp32 else "", L)),
+            "rocprof_name": "void " + trpl_amd._abi.kernel_name(S * C, L, T, flags),
             "nonconverged": int((status != 0).sum().item()), "finite_likelihoods": int(torch.isfinite(P).sum().item())}
+
+
+def fp32_pl_error(torch, tdev, trpl_amd, wl, dev, L, T, dt_ns, n_sub=256, tol32=3):
+    """What the fp32-STATE stepper (configs[4] as worded: TRPL_FLAG_FP32 | _FP32_LONG, tol 1e-3) does to PL(t): its PL on an
+    n_sub-sample subsample of the same seeded batch against the fp64 tol-7 stepper's, relative, over every stored column of
+    the window -- the reason the driver's record answers configs[4] in fp64 (pvSimPCR.py:10-11 is fp64 only)."""
+    Time = T * dt_ns
+    ini, lens = wl.power_scan(L)
+    X = torch.from_numpy(np.ascontiguousarray(wl.samples(n_sub)[:, :12])).to(dev)
+    ini_d = torch.from_numpy(ini).to(dev)
+    worst = []
+    f32 = trpl_amd.FLAG_FP32 | trpl_amd.FLAG_FP32_LONG
+    for c in range(len(lens)):
+        pl64 = torch.empty((n_sub, T + 1), dtype=torch.float64, device=dev)
+        pl32 = torch.empty((n_sub, T + 1), dtype=torch.float64, device=dev)
+        st64 = torch.empty(n_sub, dtype=torch.int32, device=dev)
+        st32 = torch.empty(n_sub, dtype=torch.int32, device=dev)
+        tdev.solve_pl_device(X, lens[c], Time, L, T, ini_d[c].contiguous(), pl64, status=st64, tol=7)
+        tdev.solve_pl_device(X, lens[c], Time, L, T, ini_d[c].contiguous(), pl32, status=st32, tol=tol32, flags=f32)
+        torch.cuda.synchronize()
+        ok = ((st64 == 0) & (st32 == 0))[:, None] & (pl64 > 0) & torch.isfinite(pl32)
+        rel = torch.where(ok, (pl32 / pl64 - 1).abs(), torch.zeros_like(pl64))
+        worst.append({"curve": c, "max": float(rel.max().item()), "median": float(rel[ok].median().item()),
+                      "median_last_column": float(rel[:, -1][ok[:, -1]].median().item()),
+                      "max_at_column": int(rel.max(dim=0).values.argmax().item()),
+                      "flagged_fp32": int((st32 != 0).sum().item()), "flagged_fp64": int((st64 != 0).sum().item())})
+    return {"against": "fp64 stepper, tol 1e-7, the same %d samples (seeded batch's first rows) x %d curves, every PL column of the "
+                       "T = %d window" % (n_sub, len(lens), T),
+            "max": max(w["max"] for w in worst), "median": float(np.median([w["median"] for w in worst])),
+            "per_curve": worst}
 
 
 def other_configs(torch, tdev, trpl_amd, wl, dev, S, T, dt_ns):
@@ -516,6 +578,15 @@ def other_configs(torch, tdev, trpl_amd, wl, dev, S, T, dt_ns):
         torch.cuda.empty_cache()
         out.append(dict(config="configs[4], one GPU's share of 8", share_of=262144, n_gpus_of_config=8,
                         **one_pass(torch, tdev, trpl_amd, wl, dev, "power_scan", 32768, 512, T, dt_ns, tol)))
+    # configs[4] AS WORDED (fp32): the fp32-state stepper over the same window -- a SCREENING mode (include/trpl.h,
+    # TRPL_FLAG_FP32): refused beyond TRPL_FP32_MAX_STEPS steps without _FP32_LONG.  Recorded with its PL error so that the
+    # record itself says why the entries above are fp64.
+    torch.cuda.empty_cache()
+    f32 = trpl_amd.FLAG_FP32 | trpl_amd.FLAG_FP32_LONG
+    out.append(dict(config="configs[4] as worded (fp32 state), one GPU's share of 8", share_of=262144, n_gpus_of_config=8,
+                    screening=True, dtype="f32 state, f64 reductions",
+                    pl_rel_err_vs_fp64=fp32_pl_error(torch, tdev, trpl_amd, wl, dev, 512, T, dt_ns),
+                    **one_pass(torch, tdev, trpl_amd, wl, dev, "power_scan", 32768, 512, T, dt_ns, 3, flags=f32)))
     return out
 
 
@@ -620,7 +691,12 @@ def e2e_production(trpl_amd, S=2 ** 17, T=80000, Time=2000.0):
         trpl_amd.export(os.path.join(work, "out"), P[0], X / sm.UNIT_CONVERSIONS)     # :194-198
         wall = time.perf_counter() - t0
         steps = sum(n - 1 for n in n_obs) + 3
-        return {"integration": "driver.bayes, one fused launch (trpl_loglik_obs); level A of tools/e2e_production.py",
+        # the entry point the fused level routed this experiment to (observation times that are a prefix of the
+        # simulation grid take the on-grid entry: driver.fused_entry_point)
+        entry = trpl_amd.driver.fused_entry_point(e_data[0][0], np.linspace(0, Time, T + 1), 3,
+                                                  bool(gpu_info.get("interpolate_prefix", False)))
+        return {"integration": "driver.bayes, one fused launch (%s); level A of tools/e2e_production.py" % entry,
+                "entry_point": entry,
                 "samples": S, "curves": 3, "L": 128, "T": T, "time_ns": Time, "n_obs": n_obs,
                 "observations": "Balancedhighsurf_Power_scan_Observations.csv (shipped example data) via dataio.get_data",
                 "wall_to_npy_s": wall, "likelihoods_per_s": S / wall, "system_timesteps_per_s": S * steps / wall,
@@ -629,6 +705,19 @@ def e2e_production(trpl_amd, S=2 ** 17, T=80000, Time=2000.0):
                                 "FAST vs STRICT, oracle subsample)"}
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+def library_record(trpl_amd):
+    """Which libtrpl_hip.so this line was measured with: the hash of the sources it was linked from (the Makefile's
+    libtrpl_hip.so.srchash; parse_rocprof.py copies it into profiles/<tag>_hbm_traffic.json, attach_traffic compares)."""
+    A = trpl_amd._abi
+    try:
+        with open(A.LIB_PATH + ".srchash") as fh:
+            h = fh.read().strip()
+    except OSError:
+        h = None
+    return {"path": os.path.relpath(A.LIB_PATH, ROOT), "srchash": h, "sources_current": bool(h) and h == A.source_hash(),
+            "abi_version": int(A.lib().trpl_abi_version()), "experimental_steppers": bool(A.has_experimental())}
 
 
 def _profile_key(path):
@@ -645,7 +734,10 @@ def attach_traffic(out, tag=None):
     is that of ANOTHER run of the same kernels -- the profile named in `traffic_source` (chosen by tag:
     --traffic-profile, else the highest round/version number; never by file time) -- not of the run being
     timed; null if none is committed.  The stepper's traffic scales with the profile's T (the observation
-    stream, ~8 B per system-step through L2); the PCR's is size-matched (65 536 x 128)."""
+    stream, ~8 B per system-step through L2); the PCR's is size-matched (65 536 x 128).
+    `traffic_source_stale`: the profile records the source hash of the library it ran (`_meta.srchash`); true when that
+    differs from the hash of the library loaded HERE (or the profile predates the field) -- the quoted figure then
+    belongs to other kernels than the ones being timed and the profile should be re-taken (tools/profile_round.sh)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), key=_profile_key)
     if tag is not None:
@@ -655,6 +747,8 @@ def attach_traffic(out, tag=None):
     t = json.load(open(files[-1]))
     src = os.path.basename(files[-1])
     meta = t.get("_meta", {})
+    here = (out.get("library") or {}).get("srchash")
+    stale = not (here and meta.get("srchash") == here)
     # kernel names gained a template argument in round 2: accept the profile's spelling of the same kernel
     def find(name):
         base = name.split("<")[0]
@@ -668,6 +762,8 @@ def attach_traffic(out, tag=None):
             out[obj]["traffic_source"] = "from profile %s (profiles/%s%s): a separate rocprofv3 --pmc run of the same " \
                                          "kernels, not this timed run" % (src[:-len("_hbm_traffic.json")], src,
                                                                           ", T=%s" % meta["T"] if "T" in meta else "")
+            out[obj]["traffic_source_stale"] = stale
+            out[obj]["traffic_source_srchash"] = meta.get("srchash")
 
 
 def bench_pcr(torch, tdev, dev, flags, S=65536, L=128, reps=48, dtype=None, nsets=4):

@@ -34,7 +34,10 @@
 extern "C" {
 #endif
 
-#define TRPL_ABI_VERSION 4   /* 4 (round 5): TRPL_FLAG_BDF_ORDER, TRPL_FLAG_PAIR_ALWAYS_SEAM / _PAIR_ADJACENT / _MULTI_FORCE_PAD (were
+#define TRPL_ABI_VERSION 5   /* 5 (round 6): trpl_has_experimental(); TRPL_FLAG_MIXED / TRPL_FLAG_HIST32 exist only in a library built with
+                                `make EXPERIMENTAL=1` (the default library answers TRPL_ERR_UNSUPPORTED); trpl_kernel_name validates like a
+                                launch; roctx ranges around the host-buffer calls when libroctx64.so is loadable.
+                                4 (round 5): TRPL_FLAG_BDF_ORDER, TRPL_FLAG_PAIR_ALWAYS_SEAM / _PAIR_ADJACENT / _MULTI_FORCE_PAD (were
                                 process-wide environment switches), trpl_multi_create_ex, TRPL_PL_ENVELOPE_K_L512; floor_col = -2 for
                                 flagged systems, T <= 2^30 - 16, up to TRPL_MAX_CURVES curves and TRPL_FLAG_HIST32 (round 4, then
                                 still under version 3) */
@@ -69,15 +72,19 @@ extern "C" {
                                      state cannot hold the BDF history differences, and over thousands of time
                                      steps the PL error grows to percents and, on the decayed tail, tens of
                                      percent (measured at L = 512, T = 8000: DESIGN.md section 7); use the
-                                     default fp64 path (or TRPL_FLAG_MIXED) at tol_exp 6 for results.  No
+                                     default fp64 path at tol_exp 6 for results.  No
                                      reference exists for this mode (the reference is fp64 only).  A launch that
                                      takes more than TRPL_FP32_MAX_STEPS time steps is refused (TRPL_ERR_UNSUPPORTED)
                                      unless TRPL_FLAG_FP32_LONG is set too */
-#define TRPL_FP32_MAX_STEPS 256   /* measured at L = 512 (tests/test_gpu_round3.py): PL error
+#define TRPL_FP32_MAX_STEPS 256   /* measured at L = 512 (tests/test_gpu_l512.py): PL error
                                      ~1e-3 after 60 steps, percents after 1000, 0.4 after 8000 */
 #define TRPL_FLAG_FP32_LONG 0x1000 /* with TRPL_FLAG_FP32: run a window longer than TRPL_FP32_MAX_STEPS anyway -- the
                                      caller has read the paragraph above and wants the screening pass */
 
+/* The next two flags name EXPERIMENTAL steppers -- measured, not faster, never selected by default.  They
+ * are compiled only into a library built with `make EXPERIMENTAL=1` (libtrpl_hip_exp.so; trpl_has_experimental() == 1); the
+ * default library refuses them with TRPL_ERR_UNSUPPORTED and a message that says so.  The bits and TRPL_KERNEL_MIXED / _HIST32
+ * keep their values in both builds. */
 #define TRPL_FLAG_MIXED 0x40      /* fp64 state, history, assembly, residuals, PL and likelihood; each inner iteration
                                      solves its tridiagonal CORRECTION equation A delta = b - A c in fp32 (L >= 128, not
                                      combinable with STRICT / FP32).  Same convergence test as fp64 (the fp64 residual of
@@ -150,7 +157,10 @@ int trpl_kernel_variant(int64_t nsys, int32_t L, int64_t steps, uint32_t flags);
 /* The C++ name (namespace, template arguments; no return type, no parameter list) of the time-stepper kernel such a launch runs
  * -- the name rocprofv3's kernel trace lists it under, after "void " -- written to buf as a NUL-terminated string.  snapshots
  * != 0: a launch with state snapshots or a resume (their own instantiation).  bench.py names its `roofline.rocprof_name` with
- * it instead of guessing the instantiation. */
+ * it instead of guessing the instantiation.  Runs the flag / shape checks of a launch first: a combination a launch would
+ * refuse (TRPL_FLAG_KERNEL_PAIR with _STRICT, _HIST32 at L = 128 or with snapshots, _FP32 over more than TRPL_FP32_MAX_STEPS
+ * steps without _FP32_LONG, a bundle the grid cannot hold, a flag of the experimental build in the default library ...) returns
+ * the launch's error code and message and an empty string -- never the name of an instantiation that does not exist. */
 int trpl_kernel_name(int64_t nsys, int32_t L, int64_t steps, uint32_t flags, int32_t snapshots, char *buf, int64_t buflen);
 
 /* Who shares a wavefront in the two-systems-per-wavefront stepper of a fused on-grid likelihood launch (a scheduling
@@ -165,6 +175,8 @@ int trpl_pair_table(const double *lengths_nm, const int64_t *n_obs, int32_t C, i
                     int32_t *cA, int32_t *oA, int32_t *cB, int32_t *oB);
 
 int trpl_abi_version(void);
+/* 1 when this library contains the experimental steppers (TRPL_FLAG_MIXED, TRPL_FLAG_HIST32: `make EXPERIMENTAL=1`), else 0 */
+int trpl_has_experimental(void);
 const char *trpl_last_error(void);
 /* number of visible HIP devices (0 with none); never fails */
 int trpl_device_count(void);

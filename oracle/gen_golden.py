@@ -17,6 +17,7 @@ Reference entry points exercised (file:line):
   bayes_io.get_initpoints :106-119, get_data :15-104 + bayes -> bayes_realdata.npz
   Legacy/pvSim.pvSim :129-173; Testing/PV_tester2.dydt :13-49 + odeint -> legacy_odeint.npz
   Legacy/pvSim.pvSim :129-173 over whole curves (2400 steps, 4 films x 9 samples)  -> legacy_full.npz
+  Testing/PV_tester2.dydt :13-49 + odeint (:91-93) at rtol 1e-10, 800 steps, 4 films x 9 samples -> tester_refine.npz
   Visualization/utils.py normalize :157-166, w_* :185-226, covariance :222-227, credible_interval :185-196,
   marginalize_1D :239-262, marginalize_2D :264-285 (tempering: marginalization_visual.py:589-591) -> posterior.npz
 
@@ -521,6 +522,65 @@ def case_legacy_full():
                         plI=np.array([r[4][:, cols] for r in res]), seconds=np.array([r[5] for r in res]))
 
 
+def _tester_refine_job(job):
+    """One (film, sample) of case_tester_refine in a worker process: Testing/PV_tester2.dydt under scipy odeint."""
+    sys.path.insert(0, os.path.join(REF, "Testing"))
+    import PV_tester2 as tester
+    from scipy.integrate import odeint
+    mp_row, dN, L, T = job
+    y0 = np.concatenate([mp_row[0] + dN, mp_row[1] + dN, np.zeros(L + 1)])      # PV_tester2.py:85-89
+    tSteps = np.linspace(0, T, T + 1)                                            # :91
+    t0 = time.time()
+    sols = []
+    from threadpoolctl import threadpool_limits
+    for rtol, atol in ((1e-8, 1e-12), (1e-10, 1e-14)):
+        with threadpool_limits(1):       # LSODA factorises a 385 x 385 Jacobian: 8 workers x 8 BLAS threads would spin
+            data, info = odeint(tester.dydt, y0, tSteps, args=(L, *mp_row), tfirst=True, rtol=rtol, atol=atol, hmax=0.5,
+                                mxstep=200000, full_output=True)
+        assert info["message"] == "Integration successful."
+        sols.append(mp_row[4] * np.sum(data[:, :L] * data[:, L:2 * L] - mp_row[0] * mp_row[1], axis=1))   # :120
+    neg = bool((data[:, :2 * L] < 0).any())                                      # the tester's own acceptance test, :101
+    return sols[1], float(np.max(np.abs(sols[1] / sols[0] - 1))), neg, time.time() - t0
+
+
+def case_tester_refine():
+    """The THIRD solver the north star names, as the target of a time-step refinement study: Testing/PV_tester2.dydt
+    (:13-49: the semi-discrete equations of the same spatial scheme, no Auger) integrated by scipy odeint the way its
+    __main__ does (:91-93, non-dimensional variables of :55-76), at rtol 1e-10 / atol 1e-14 -- the TIME-CONVERGED solution
+    of the scheme pvSimPCR.py steps with BDF at fixed dt (each curve is checked against a second odeint run at rtol 1e-8:
+    the two agree far below the refinement errors the tests measure, stored as `ode_conv`).  8 random samples of the box +
+    the marked point x the three Power_scan excitations on a 2000 nm film + the strongest on a 311 nm film (the films of
+    case_legacy_full), 800 steps of the reference's dt = 0.025 ns (20 ns), PL stored at every step in pvSim's units.
+    tests/: the oracle / the GPU at T * k steps with plT = k, k = 1 .. 16, must approach these curves at second order
+    (the Euler start of pvSimPCR.py:241-242 dominates the error of the early columns)."""
+    import multiprocessing as mp
+    X = np.vstack([draw(8), MARK * UNIT])
+    m10 = X[:, [0, 1, 2, 3, 4, 5, 6, 9, 10, 11]]                        # no CN, CP
+    L, T, dt = 128, 800, 0.025
+    Time = T * dt
+    l_nm = 1.0 / 6.000e-3
+    jobs, unit = [], []
+    for length, a in LEGACY_FULL_FILMS:
+        dx = length / L
+        dx3 = dx ** 3; dtdx = dt / dx; dtdx2 = dtdx / dx
+        scales = np.array([dx3, dx3, dtdx2, dtdx2, dtdx2 / dx, dtdx, dtdx, 1 / dt, 1 / dt, 1 / dx])   # PV_tester2.py:62-65
+        dN = (a * 1e-21 * dx3) * np.exp(-(np.arange(L) + 0.5) / (l_nm / dx))                              # :67-73
+        jobs += [(row, dN, L, T) for row in m10 * scales]
+        unit.append(dx ** 2 * dt)                                        # pvSimPCR.py:393 (the tester's own `dx**4/dt` is
+        #                                                                  another unit; the curves are compared as ratios)
+    with mp.get_context("fork").Pool(8) as pool:
+        res = pool.map(_tester_refine_job, jobs, chunksize=1)
+    F, S = len(LEGACY_FULL_FILMS), len(X)
+    pl = np.array([r[0] for r in res]).reshape(F, S, T + 1) / np.array(unit)[:, None, None]
+    conv = np.array([r[1] for r in res]).reshape(F, S)
+    assert conv.max() < 1e-7, conv
+    np.savez_compressed(os.path.join(OUT, "tester_refine.npz"), X=X, L=L, T=T, time=Time, l_nm=l_nm,
+                        lengths=np.array([f[0] for f in LEGACY_FULL_FILMS]),
+                        a_nm3=np.array([f[1] * 1e-21 for f in LEGACY_FULL_FILMS]), plI_odeint=pl, ode_conv=conv,
+                        negative=np.array([r[2] for r in res]).reshape(F, S),
+                        seconds=np.array([r[3] for r in res]).reshape(F, S))
+
+
 def case_posterior():
     """The numeric core of the GUI that consumes *_BAYRAN_{P,X}.npy, run as shipped (statsmodels stand-in:
     refshim/statsmodels, only needed for the module-level import)."""
@@ -574,7 +634,7 @@ def case_posterior():
                         pairs=np.array([[names.index(a), names.index(b)] for a, b in pairs]), h2=np.stack(h2))
 
 
-CASES = {"posterior": case_posterior, "legacy_odeint": case_legacy_odeint, "legacy_full": case_legacy_full, "csv_fixture": case_csv_fixture, "bayes_realdata": case_bayes_realdata, "pcr_norm": case_pcr_norm, "probs": case_probs, "sampler": case_sampler,
+CASES = {"posterior": case_posterior, "legacy_odeint": case_legacy_odeint, "tester_refine": case_tester_refine, "legacy_full": case_legacy_full, "csv_fixture": case_csv_fixture, "bayes_realdata": case_bayes_realdata, "pcr_norm": case_pcr_norm, "probs": case_probs, "sampler": case_sampler,
          "pvsim_small": case_pvsim_small, "pvsim_power": case_pvsim_power, "pvsim_bundle": case_pvsim_bundle,
          "pvsim_twothick": case_pvsim_twothick, "bayes_e2e": case_bayes_e2e,
          "fallback": case_fallback, "fallback64": case_fallback64}

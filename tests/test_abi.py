@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(trpl):
     for n in names:
         assert hasattr(dll, n), n
     assert set(trpl._abi.SIGNATURES) == set(names)       # the binding covers the whole header
-    assert dll.trpl_abi_version() == 4 == trpl._abi.ABI_VERSION
+    assert dll.trpl_abi_version() == 5 == trpl._abi.ABI_VERSION
 
 
 def test_cites_reference_interfaces():
@@ -338,8 +338,14 @@ def test_kernel_name_and_round5_flags_need_no_device(trpl):
     assert A.kernel_name(196608, 128, 8000, A.FLAG_KERNEL_PAIR, snapshots=True) == "trpl::pair::stepper_pair_kernel<true, true, true>"
     assert A.kernel_name(64, 128, 8000) == "trpl::stepper_kernel<128, false, false, false, false, false>"
     assert A.kernel_name(10 ** 6, 128, 8000, A.FLAG_STRICT) == "trpl::stepper_kernel<128, true, false, false, false, false>"
-    assert A.kernel_name(10 ** 6, 512, 8000, A.FLAG_HIST32) == "trpl::stepper_kernel<512, false, false, false, false, true>"
-    assert A.kernel_name(10 ** 6, 512, 8000, A.FLAG_MIXED) == "trpl::stepper_kernel<512, false, false, true, false, false>"
+    if A.has_experimental():                        # `make EXPERIMENTAL=1` (libtrpl_hip_exp.so under TRPL_LIBRARY)
+        assert A.kernel_name(10 ** 6, 512, 8000, A.FLAG_HIST32) == "trpl::stepper_kernel<512, false, false, false, false, true>"
+        assert A.kernel_name(10 ** 6, 512, 8000, A.FLAG_MIXED) == "trpl::stepper_kernel<512, false, false, true, false, false>"
+    else:                                           # the default library has no such instantiation and says so
+        for fl, word in ((A.FLAG_HIST32, "TRPL_FLAG_HIST32"), (A.FLAG_MIXED, "TRPL_FLAG_MIXED")):
+            with pytest.raises(A.TrplError) as e:
+                A.kernel_name(10 ** 6, 512, 8000, fl)
+            assert e.value.code == A.ERR_UNSUPPORTED and word in str(e.value) and "EXPERIMENTAL=1" in str(e.value)
     assert A.kernel_name(10 ** 6, 128, 8000, A.flag_bundle(3, 128)) == "trpl::stepper_kernel<128, false, false, false, true, false>"
     assert A.kernel_name(10 ** 6, 512, 100, A.FLAG_FP32) == "trpl::f32::stepper_kernel<512>"
     lib = A.lib()
@@ -351,3 +357,46 @@ def test_kernel_name_and_round5_flags_need_no_device(trpl):
     import glob
     src = "".join(open(f).read() for f in glob.glob(os.path.join(ROOT, "bayesian-inference-trpl_amd", "csrc", "*.h*")))
     assert re.findall(r'getenv\("([A-Z_]+)"\)', src) == ["TRPL_RCCL_LIBRARY"]
+
+
+def test_kernel_name_refuses_what_a_launch_refuses(trpl):
+    """trpl_kernel_name runs the flag / shape checks of a launch (csrc/trpl_api.hip check_launch): it returns a name exactly
+    for the combinations a launch accepts, and every name it returns is an instantiation the library contains (the mangled
+    kernel symbols of the shared object are the instantiation list).  bench.py attaches rocprof statistics by that name, so a
+    name without a kernel would silently attach nothing."""
+    import itertools
+    import subprocess
+    A = trpl._abi
+    nm = subprocess.run(["nm", "-D", "--defined-only", A.LIB_PATH], capture_output=True, text=True).stdout
+    filt = subprocess.run(["c++filt"], input=nm, capture_output=True, text=True).stdout
+    have = set(re.findall(r"(trpl::(?:pair::|f32::)?stepper(?:_pair)?_kernel<[^>]*>)", filt))
+    assert len(have) >= 40, len(have)
+    exp = A.has_experimental()
+    named = refused = 0
+    arith = [0, A.FLAG_STRICT, A.FLAG_FP32, A.FLAG_FP32 | A.FLAG_FP32_LONG, A.FLAG_MIXED, A.FLAG_HIST32, A.FLAG_STRICT | A.FLAG_FP32,
+             A.FLAG_MIXED | A.FLAG_HIST32]
+    for L, ar, kern, bundle, snap, steps in itertools.product(
+            (2, 4, 64, 128, 256, 512, 1024, 96), arith, (0, A.FLAG_KERNEL_PAIR, A.FLAG_KERNEL_SINGLE, A.FLAG_KERNEL_PAIR | A.FLAG_KERNEL_SINGLE),
+            (1, 2, 4, 5, 16), (False, True), (100, 8000)):
+        flags = ar | kern | (((bundle - 1) & 0xF) << 8)
+        # what a launch accepts, restated from include/trpl.h's flag paragraphs
+        ok = L in (4, 8, 16, 32, 64, 128, 256, 512) and kern != (A.FLAG_KERNEL_PAIR | A.FLAG_KERNEL_SINGLE)
+        fp32, strict, mixed, hist = bool(ar & A.FLAG_FP32), bool(ar & A.FLAG_STRICT), bool(ar & A.FLAG_MIXED), bool(ar & A.FLAG_HIST32)
+        if kern == A.FLAG_KERNEL_PAIR:
+            ok &= L == 128 and not (strict or fp32 or mixed or hist)
+        ok &= not ((mixed or hist) and not exp)
+        ok &= not (hist and (strict or fp32 or mixed or L not in (256, 512) or snap or bundle > 1))
+        ok &= not (mixed and (strict or fp32 or L < 128))
+        ok &= not (fp32 and (strict or L < 128 or (steps > A.FP32_MAX_STEPS and not ar & A.FLAG_FP32_LONG)))
+        ok &= not (bundle > 1 and (fp32 or mixed or kern == A.FLAG_KERNEL_PAIR or bundle > A.bundle_cap(L) or (not strict and L > 128)))
+        try:
+            name = A.kernel_name(10 ** 6, L, steps, flags, snapshots=snap)
+        except A.TrplError as e:
+            assert not ok, (L, hex(flags), snap, steps, str(e))
+            assert e.code in (A.ERR_ARG, A.ERR_UNSUPPORTED)
+            refused += 1
+            continue
+        assert ok, (L, hex(flags), snap, steps, name)
+        assert name in have, (name, L, hex(flags), snap, steps)
+        named += 1
+    assert named > 100 and refused > 1000, (named, refused)

@@ -25,7 +25,7 @@ def _worker(rank, world, port, S, out_dir):
     import oracle
     import trpl_amd
     g = np.load(os.path.join(GOLDEN, "bayes_e2e.npz"))
-    X = np.concatenate([g["X"]] * 2)[:S]
+    X = np.concatenate([g["X"]] * (1 + S // len(g["X"])))[:S]
     T, tg = 12, g["tgrid"]
     e_data = [([tg[:T + 1]] * 3, [o[:T + 1] for o in g["obs0"]]), ([tg[:5]] * 3, [o[:5] for o in g["obs1"]])]
 
@@ -69,6 +69,27 @@ def _worker_small(rank, world, port, S):
 def test_gather_with_fewer_samples_than_ranks():
     mp.spawn(_worker_small, args=(2, _free_port(), 1), nprocs=2, join=True)
     mp.spawn(_worker_small, args=(2, _free_port(), 5), nprocs=2, join=True)
+
+
+def test_eight_ranks_shard_and_gather_like_the_node(tmp_path):
+    """configs[3]'s rank count on the CPU: world size 8 over gloo, the oracle standing in for the device call.  S = 19 (not
+    divisible by 8: three ranks hold 3 samples, five hold 2 -- trpl_shard_bounds) gathers the single-process likelihoods bit
+    for bit on every rank; S = 5 leaves three ranks with an empty shard.  (Eight ranks sharing one GPU is not run anywhere:
+    the GPU pool admits six GPU processes per box, launcher and test runner included; tests/test_gpu_multi.py rehearses
+    three ranks on the GPU and eight "ranks" inside one process.)"""
+    world = 8
+    mp.spawn(_worker, args=(world, _free_port(), 19, str(tmp_path)), nprocs=world, join=True)
+    single = np.load(tmp_path / "P_single.npy")
+    assert single.shape == (2, 19) and np.isfinite(single).all()
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / ("P_rank%d.npy" % r)), single), r
+    import sys
+    sys.path.insert(0, ROOT)
+    import trpl_amd
+    sizes = [np.subtract(*trpl_amd.dist.shard_bounds(19, world, r)[::-1]) for r in range(world)]
+    assert sizes == [3, 3, 3, 2, 2, 2, 2, 2]
+    mp.spawn(_worker_small, args=(world, _free_port(), 5), nprocs=world, join=True)
+    mp.spawn(_worker_small, args=(world, _free_port(), 524288 // 4096), nprocs=world, join=True)
 
 
 # ---- posterior core over shards (dist.posterior_*_sharded); the CPU oracle stands in for the device calls ----

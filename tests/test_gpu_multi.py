@@ -227,6 +227,76 @@ def test_bench_two_rank_rehearsal_gathers_the_single_rank_likelihoods(gpu, tmp_p
     assert np.array_equal(np.load(p3), a)
 
 
+def _bench(args, env, timeout=900):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2500:])
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]                               # ONE contract line
+    return json.loads(lines[0])
+
+
+REHEARSAL = ["--steps", "1", "--warmup", "1", "--T", "200", "--no-cpu-baseline", "--no-pcr", "--no-full-length", "--no-host-api",
+             "--no-other-configs", "--no-e2e"]
+
+
+@pytest.mark.parametrize("S_total", [4098, 4099])
+def test_bench_three_rank_rehearsal_with_even_and_uneven_shards(gpu, tmp_path, S_total):
+    """The driver's N > 1 form of bench.py with more than two ranks on this box's one GPU: `bench.py --gpus 3 --backend gloo`
+    starts its ranks itself (fresh children, before the parent touches the GPU; never a re-exec).  The pool admits SIX
+    processes with the GPU open per box and counts this pytest process and the launcher too (a five-rank rehearsal was
+    killed by that guard at 7), so eight ranks on one card cannot run here: world size 8 is covered on the CPU
+    (tests/test_dist_gloo.py) and inside one process (next test).  S_total = 4098 (three equal shards) and 4099 (1367 + 1366
+    + 1366: trpl_shard_bounds) gather the single launch's likelihoods BIT FOR BIT; the line carries the rccl record (world,
+    every rank's pid / device / PCI bus id, all-gather bytes and time) and value_n1_equiv."""
+    env = {k: v for k, v in dict(os.environ, MASTER_ADDR="127.0.0.1", TRPL_AUTOBUILD="0").items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    W = 3
+    p1, pw = str(tmp_path / "p1.npy"), str(tmp_path / "pw.npy")
+    one = _bench(["--gpus", "1", "--samples-total", str(S_total), "--dump-p", p1] + REHEARSAL, env)
+    many = _bench(["--gpus", str(W), "--backend", "gloo", "--samples-total", str(S_total), "--dump-p", pw] + REHEARSAL, env)
+    assert many["n_gpus"] == W and many["scaling"] == "weak" and many["config"]["samples_total"] == S_total
+    assert many["config"]["collective"].startswith("gloo") and many["nonconverged_systems"] == one["nonconverged_systems"] == 0
+    rc = many["rccl"]
+    assert rc["world"] == W and [d["rank"] for d in rc["devices"]] == list(range(W)) and len({d["pid"] for d in rc["devices"]}) == W
+    assert all(d["pci_bus_id"] is not None or d["name"] for d in rc["devices"])
+    assert rc["allgather_bytes_per_rank"] == -(-S_total // W) * 8 and rc["allgather_bytes"] == W * rc["allgather_bytes_per_rank"]
+    assert rc["allgather_us"] > 0 and abs(many["value_n1_equiv"] * W - many["value"]) < 1e-6 * many["value"]
+    assert many["library"]["srchash"] == one["library"]["srchash"] and one["library"]["sources_current"]
+    a, b = np.load(p1), np.load(pw)
+    assert a.shape == b.shape == (1, S_total) and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("S_total", [4096, 4099])
+def test_single_process_bench_with_eight_ranks_on_one_device(gpu, tmp_path, S_total):
+    """configs[3]'s rank count through the one-process form: `bench.py --single-process --gpus 8 --rehearse-on-device0` --
+    trpl_multi_create_ex with eight ranks on device 0, the six RCCL entry points bound to tests/mock_rccl (RCCL refuses
+    duplicate devices) -- ONE process on the GPU.  4096 samples: equal shards, direct exchange; 4099: 513 x 3 + 512 x 5,
+    padded exchange + unpadding.  The gathered vector (identical on all eight "devices": bench.py asserts it) equals the
+    single launch bit for bit, and the line carries the same rccl / value_n1_equiv fields as the per-rank form."""
+    so = str(tmp_path / "libmock_rccl.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O1", "-o", so,
+                           os.path.join(ROOT, "tests", "mock_rccl", "mock_rccl.cpp")])
+    env = dict(os.environ, TRPL_AUTOBUILD="0")
+    p1, p8 = str(tmp_path / "p1.npy"), str(tmp_path / "p8.npy")
+    one = _bench(["--gpus", "1", "--samples-total", str(S_total), "--dump-p", p1] + REHEARSAL, env)
+    eight = _bench(["--single-process", "--gpus", "8", "--rehearse-on-device0", "--samples-total", str(S_total), "--steps", "1",
+                    "--warmup", "1", "--T", "200", "--dump-p", p8], dict(env, TRPL_RCCL_LIBRARY=so))
+    assert eight["n_gpus"] == 8 and eight["rehearsal_on_one_device"] and eight["config"]["samples_total"] == S_total
+    rc = eight["rccl"]
+    assert rc["world"] == 8 and [d["rank"] for d in rc["devices"]] == list(range(8)) and rc["distinct_devices"] == 1
+    assert sum(d["samples"] for d in rc["devices"]) == S_total and rc["padded_exchange"] == (S_total % 8 != 0)
+    assert rc["allgather_bytes_per_rank"] == -(-S_total // 8) * 8
+    assert abs(eight["value_n1_equiv"] * 8 - eight["value"]) < 1e-6 * eight["value"]
+    assert eight["nonconverged_systems"] == one["nonconverged_systems"] == 0
+    assert np.array_equal(np.load(p8), np.load(p1))
+    # without a stand-in library the rehearsal switch refuses to run (RCCL would reject the duplicate devices)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--single-process", "--gpus", "8", "--rehearse-on-device0",
+                        "--T", "50"], env={k: v for k, v in env.items() if k != "TRPL_RCCL_LIBRARY"}, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "TRPL_RCCL_LIBRARY" in r.stderr
+
+
 def test_rank_driver_gathers_over_rccl_on_a_one_rank_group(gpu, tmp_path):
     """The one-process-per-GPU driver with the REAL collective backend: a child process joins a 1-rank
     torch.distributed group on the `nccl` backend (= RCCL on ROCm), computes its shard with the fused call and

@@ -5,6 +5,8 @@ mode; and the STRICT continuation is the ORACLE's uninterrupted run bit for bit.
 import numpy as np
 import pytest
 
+from gpu_common import needs_experimental
+
 pytestmark = pytest.mark.gpu
 
 MODES = [dict(strict=True), dict(kernel="single"), dict(kernel="pair"), dict(mixed=True)]
@@ -45,6 +47,8 @@ def _split_run(gpu, X, length, Time, L, T, ini, t0, plT=1, late=(), **mode):
 @pytest.mark.parametrize("mode", MODES, ids=lambda m: "-".join("%s=%s" % kv for kv in m.items()))
 @pytest.mark.parametrize("t0", [4, 57, 96])
 def test_continued_run_is_the_uninterrupted_run_bit_for_bit(gpu, mode, t0):
+    if mode.get("mixed"):
+        needs_experimental(gpu, dict(mixed=True))
     X, length, ini = _case(gpu, 9, seed=5)
     T = 160
     Time = T * DT
@@ -73,6 +77,8 @@ def test_strict_continuation_is_the_oracles_uninterrupted_run(gpu, oracle):
 def test_continue_with_decimated_pl_and_an_odd_batch(gpu, mode):
     """plT = 8 with t0 off the PL grid: the first column written by the continuation is the next multiple of plT;
     columns before it keep the caller's values.  An odd batch leaves the paired kernel a half-empty wavefront."""
+    if mode.get("mixed"):
+        needs_experimental(gpu, dict(mixed=True))
     X, length, ini = _case(gpu, 11, seed=9)
     T, Time, t0, plT = 256, 256 * DT, 99, 8
     (pl, st, it, _), (pl2, _, st_b, it2, _) = _split_run(gpu, X, length, Time, 128, T, ini, t0, plT=plT, **mode)
@@ -274,6 +280,8 @@ def test_device_resident_continue_of_a_single_system(gpu, flag):
     """trpl_solve_pl_resume_dev takes no excitation (the state comes from the checkpoint) and must not read one: with
     S = 1 the only other array of the call, matpar, holds 12 doubles -- a kernel that still loaded L excitation values
     through an alias of it read ~1 KB past the caller's tensor (round-2 advisor finding)."""
+    if flag == "mixed":
+        needs_experimental(gpu, dict(mixed=True))
     import torch
     dv = gpu.device
     X, length, ini = _case(gpu, 1, seed=31)
@@ -306,6 +314,8 @@ def test_a_system_flagged_before_the_checkpoint_keeps_its_status_through_the_res
     instead of max_iter on NaNs at every step) and its PL / later snapshots are NaN exactly where the uninterrupted
     run's are -- status, PL and snapshots of every system bit for bit, iteration totals once the step at t0 is
     counted once."""
+    if mode.get("mixed"):
+        needs_experimental(gpu, dict(mixed=True))
     X, length, ini = _case(gpu, 12, seed=5)
     L, T, t0 = 128, 96, 40
     Time = T * DT

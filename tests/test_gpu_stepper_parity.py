@@ -9,7 +9,7 @@ include/trpl.h states, |dPL / PL| <= 1e-9 + K / r (r = PL / (B L n0p0), K per fi
 import numpy as np
 import pytest
 
-from gpu_common import (ENVELOPE_K, FLOOR, IDS, KERNELS, RTOL_FAST, RTOL_STRICT, SSE_GATE, _check_pl_against, deviation_bound,
+from gpu_common import (ENVELOPE_K, FLOOR, IDS, KERNELS, RTOL_FAST, RTOL_STRICT, SSE_GATE, _check_pl_against, deviation_bound, follows_iteration_path,
                         excess_scale, first_below, nthreads, record, relerr)
 
 pytestmark = pytest.mark.gpu
@@ -31,7 +31,8 @@ def test_pvsim_power_scan_vs_reference_golden(gpu, golden):
         assert not st.any() and np.array_equal(it, want_it)
         assert relerr(pl, want) <= RTOL_STRICT
         pl, st, it = _run(gpu, X[:, :-1], 2000.0, float(g["time"]), 128, T, g["ini"][c])
-        assert not st.any() and np.all(np.abs(it - want_it) <= 0.01 * want_it + 1)
+        assert not st.any()
+        follows_iteration_path(it, want_it, "curve %d" % c)
         assert relerr(pl, want) < RTOL_FAST
 
 
@@ -44,14 +45,15 @@ def test_pvsim_twothick_vs_reference_golden(gpu, golden):
         assert not st.any() and np.array_equal(it, want_it)
         assert relerr(pl, want) <= RTOL_STRICT
         pl, st, it = _run(gpu, X[:, :-1], float(length), float(g["time"]), 128, T, g["ini"][c])
-        assert not st.any() and np.all(np.abs(it - want_it) <= 0.01 * want_it + 1)
+        assert not st.any()
+        follows_iteration_path(it, want_it, "curve %d" % c)
         assert relerr(pl, want) < RTOL_FAST
 
 
 def test_pvsim_64_random_samples_vs_oracle(gpu, oracle):
     """BASELINE configs[0] shape: Power_scan (3 excitations, 128 nodes) x 64 random parameter samples,
-    here against the pinned CPU oracle: STRICT iteration counts identical and PL to 1e-13, FAST PL to
-    1e-9 and iteration totals within 1 %."""
+    here against the pinned CPU oracle: STRICT iteration counts identical and PL bit for bit, FAST PL to
+    1e-9 and the oracle's iteration totals (gpu_common.follows_iteration_path)."""
     w = gpu.workloads
     ini, lens = w.power_scan(128)
     X = w.samples(64)
@@ -63,7 +65,7 @@ def test_pvsim_64_random_samples_vs_oracle(gpu, oracle):
         assert np.array_equal(it, r["iters_total"]) and relerr(pl, r["plI"]) <= RTOL_STRICT
         pl, st, it, _ = gpu.solve_pl(X[:, :-1], lens[c], Time, 128, T, ini[c])
         assert not st.any() and relerr(pl, r["plI"]) < RTOL_FAST
-        assert np.all(np.abs(it - r["iters_total"]) <= 0.01 * r["iters_total"] + 1)
+        follows_iteration_path(it, r["iters_total"], "curve %d" % c)
 
 
 def test_against_legacy_pvsim_and_odeint(gpu, golden):
@@ -82,6 +84,49 @@ def test_against_legacy_pvsim_and_odeint(gpu, golden):
         assert np.max(np.abs(plI / g["plI_legacy"] - 1)) < 1e-3
         assert np.max(np.abs(plI / g["plI_odeint"] - 1)) < 2e-2
         assert np.max(np.abs(plI[:, -1] / g["plI_odeint"][:, -1] - 1)) < 5e-4
+
+
+def test_time_step_refinement_converges_to_pv_tester2_odeint(gpu, oracle, golden):
+    """The third reference north_star names, pinned by time-step refinement.  Testing/PV_tester2.dydt (:13-49) under scipy
+    odeint (:91-93, rtol 1e-10) is the time-converged solution of the spatial scheme that pvSimPCR.py:241-250 steps at fixed
+    dt; tests/golden/tester_refine.npz holds it for 9 samples x (the three Power_scan excitations on a 2000 nm film + the
+    strongest on a 311 nm film) over 20 ns, every 0.025 ns (oracle/gen_golden.py case_tester_refine, the reference's own
+    code).  With T * k steps of dt / k and plT = k, k = 1, 2, 4, 8, 16 (the same 801 stored columns):
+      * STRICT is the CPU oracle BIT FOR BIT at every k (PL bit patterns, iteration totals);
+      * both FAST kernels hold the oracle's iteration totals and stay inside the header's envelope 1e-9 + K / r at every k;
+      * STRICT and both FAST kernels converge to the odeint curves at SECOND order inside the bounds of
+        tests/refine_common.py -- the same bounds tests/test_oracle_golden.py holds the oracle to: the film's worst
+        deviation shrinks >= 2.8x, then >= 3.5x per halving of dt, to <= 1e-4 on every column and <= 3e-6 at 20 ns at
+        dt / 16 (measured 5.1e-5 / 1.0e-6)."""
+    import refine_common as R
+    g = golden("tester_refine")
+    L, T, Time = int(g["L"]), int(g["T"]), float(g["time"])
+    rec = {}
+    for f in range(len(g["lengths"])):
+        X, length, dN = R.film_inputs(g, f)
+        ode = g["plI_odeint"][f]
+        scale = excess_scale(X, length, L)
+        K = ENVELOPE_K[length]
+        devs = {"strict": {}, "single": {}, "pair": {}}
+        for k in R.REFINE_K:
+            ref = oracle.pvsim(X[:, :-1], length, Time, L, T * k, dN, plT=k, nthreads=nthreads())
+            assert not ref["status"].any()
+            pl, st, it, _ = gpu.solve_pl(X[:, :-1], length, Time, L, T * k, dN, plT=k, strict=True)
+            assert not st.any() and np.array_equal(it, ref["iters_total"]), (f, k)
+            assert pl.shape == ode.shape and pl.tobytes() == ref["plI"].tobytes(), (f, k)
+            devs["strict"][k] = R.deviation(pl, ode)
+            r = ref["plI"] / scale[:, None]
+            for kernel in ("single", "pair"):
+                plf, stf, itf, _ = gpu.solve_pl(X[:, :-1], length, Time, L, T * k, dN, plT=k, kernel=kernel)
+                assert not stf.any()
+                follows_iteration_path(itf, ref["iters_total"], "film %d, k = %d, %s" % (f, k, kernel))
+                dev = np.abs(plf / ref["plI"] - 1)
+                assert (dev <= 1e-9 + K / r).all(), (f, k, kernel, float(np.max(dev * r)))
+                devs[kernel][k] = R.deviation(plf, ode)
+        for name, d in devs.items():
+            worst, end = R.check_refinement(d, label="film %d, %s" % (f, name))
+            rec["film%d_%s" % (f, name)] = {"worst": worst, "end": end}
+    record("tester_refine", rec)
 
 
 def test_whole_curve_parity_with_legacy_pvsim_under_the_bdf_order_cap(gpu, oracle, golden):
@@ -117,8 +162,8 @@ def test_whole_curve_parity_with_legacy_pvsim_under_the_bdf_order_cap(gpu, oracl
         K = ENVELOPE_K[length]
         for kernel in ("single", "pair"):
             plf, stf, itf, _ = gpu.solve_pl(X[:, :-1], length, Time, L, T, dN, kernel=kernel, bdf_order=2)
-            dit = np.abs(itf - ref["iters_total"])                      # the oracle's totals (at most one knife-edge decision apart)
-            assert not stf.any() and dit.max() <= 1 and (dit != 0).sum() <= 1, (f, kernel, dit)
+            assert not stf.any()
+            follows_iteration_path(itf, ref["iters_total"], "film %d, %s" % (f, kernel))     # the oracle's totals
             dev = np.abs(plf / ref["plI"] - 1)
             assert (dev <= 1e-9 + K / r).all(), (f, kernel, float(np.max(dev * r)))
             devL = np.abs(plf[:, cols] / g["plI"][f] - 1)
@@ -346,8 +391,7 @@ def test_twothick_bench_window_against_the_oracle(gpu, twothick_window, mode):
             assert np.max(np.abs(info["sse"][c] - g["sse"][c]) / g["sse"][c]) < 1e-12
             continue
         # iteration totals: the oracle's (a knife-edge convergence decision may flip on one system of the 32, by one)
-        differ = it != want["iters_total"]
-        assert differ.sum() <= 1 and np.abs(it - want["iters_total"]).max() <= 1, (c, int(differ.sum()))
+        follows_iteration_path(it, want["iters_total"], "curve %d" % c)
         assert np.array_equal(info["iters_total"][c], it)                  # fused and PL-storing launches agree
         r = want["plI"] / scale[:, None]
         dev = np.abs(pl / want["plI"] - 1)

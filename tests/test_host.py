@@ -122,6 +122,72 @@ def test_simulate_control_flow_with_standin_compute(trpl, monkeypatch):
                      dict(flags, load_PL_from_file=True), {"sims_per_gpu": 3, "num_gpus": 1}, 0, st, et, mt)
 
 
+def test_unfused_overlap_is_bounded_by_host_bytes(trpl, monkeypatch):
+    """gpu_info["max_host_bytes"] bounds the PL results the unfused overlapped path holds at once (bayeslib.py:131-137 holds
+    one; round 5's overlap held two blocks' curves whatever their size).  A re-entrant stand-in model counts the PL buffers
+    alive (created, not yet garbage-collected) at each of its calls; P is the same for every budget."""
+    import gc
+    import threading
+    import weakref
+    drv = trpl.driver
+    S, L, T, Time, C = 24, 8, 40, 2.0, 3
+    rng = np.random.default_rng(5)
+    X = rng.uniform(1, 2, (S, 13))
+    ini = rng.uniform(1, 2, (C, L))
+    sim_t = np.linspace(0, Time, T + 1)
+    lock = threading.Lock()
+    state = {"live": 0, "peak": 0, "calls": 0}
+
+    def gone():
+        with lock:
+            state["live"] -= 1
+
+    def model(plI, plN, plP, plE, matPar, simPar, iniPar, TPB, BPG, mspb, init_mode="exp"):
+        gc.collect()
+        with lock:
+            state["live"] += 1
+            state["calls"] += 1
+            state["peak"] = max(state["peak"], state["live"])
+        weakref.finalize(plI, gone)
+        plI[:] = (matPar[:, :1] * iniPar.sum() * np.exp(-sim_t))[:, :T + 1]
+        return 0.5
+    model.reentrant = True
+
+    def fake_fastlog(plI, MIN, device=0):
+        plI[:] = np.log10(np.maximum(plI, MIN))
+        return 0.25
+
+    def fake_prob(P, plI, values, unc, mag, device=0):
+        P -= np.sum((plI.astype(np.float64) + mag[:, None] - values) ** 2, axis=1)
+        return 0.125
+
+    monkeypatch.setattr(drv, "fastlog", fake_fastlog)
+    monkeypatch.setattr(drv, "prob", fake_prob)
+    e_data = [([sim_t] * C, [np.zeros(T + 1)] * C), ([sim_t[:9] + 0.01] * C, [np.ones(9)] * C)]
+    flags = {"load_PL_from_file": False, "log_pl": True, "self_normalize": False}
+    group = 4                                                    # 6 blocks x 3 curves = 18 results
+    per = drv.unfused_curve_bytes(group, T + 1, np.float32, [0] * C + [9] * C, C)
+    assert per == group * ((T + 1) * 4 + 9 * 8)
+    results = {}
+    for label, info, bound in (("serial", {"overlap_curves": False}, 1), ("one", {"max_host_bytes": per}, 1),
+                               ("three", {"max_host_bytes": 3 * per + per // 2}, 3), ("default", {}, 2 * C)):
+        state.update(live=0, peak=0, calls=0)
+        P = np.zeros((2, S))
+        st, et, mt = np.zeros(1), np.zeros(1), np.zeros(1)
+        plI, plI_int = [None], [None]
+        drv.simulate(model, e_data, P, X, plI, plI_int, C, [100.0, Time, L, T, 1, (0,), 7, 50], ini, flags,
+                     dict({"sims_per_gpu": group, "num_gpus": 1}, **info), 0, st, et, mt)
+        assert state["calls"] == 18 and state["peak"] <= bound, (label, state)
+        if label == "default":
+            assert state["peak"] > 3                                        # the default budget does overlap two blocks
+        assert plI[0].shape == (group, T + 1) and plI_int[0].shape == (group, 9)      # the last matrices stay, as in the reference
+        results[label] = P
+        del plI, plI_int
+        gc.collect()
+    for label in ("one", "three", "default"):
+        assert np.array_equal(results[label], results["serial"]), label
+
+
 def test_csv_ingestion_matches_reference(trpl, golden, tmp_path):
     """dataio.get_initpoints / get_data on data files cut from the reference's shipped examples
     against the arrays the reference's own bayes_io produced from them (bayes_io.py:15-119)."""

@@ -256,6 +256,28 @@ def test_whole_curve_against_legacy_pvsim_with_the_bdf_order_capped_at_two(oracl
     assert np.array_equal(oracle.pvsim(X[:1, :-1], length, 100 * 0.025, L, 100, dN, max_order=9)["plI"], e5)
 
 
+def test_time_step_refinement_converges_to_pv_tester2_odeint(oracle, golden):
+    """The THIRD solver north_star names, as a convergence target: Testing/PV_tester2.dydt (:13-49) + scipy odeint (:91-93)
+    is the time-converged solution of the spatial scheme pvSimPCR.py steps at fixed dt.  tests/golden/tester_refine.npz
+    (oracle/gen_golden.py case_tester_refine: the reference's dydt, rtol 1e-10; 9 samples x the three Power_scan excitations
+    on a 2000 nm film + the strongest on a 311 nm film; 20 ns stored every 0.025 ns).  The oracle with T * k steps and
+    plT = k, k = 1, 2, 4, 8, 16, approaches those curves at second order -- the film's worst deviation shrinks 2.9x, then
+    3.8 .. 4.0x per halving of dt, to <= 1e-4 on every column (5.1e-5 measured, at step 1: the Euler start of
+    pvSimPCR.py:241-242) and <= 3e-6 at 20 ns (1.0e-6) at dt / 16.  Bounds: tests/refine_common.py."""
+    import refine_common as R
+    g = golden("tester_refine")
+    assert float(g["ode_conv"].max()) < R.ODE_CONV and not g["negative"].any()      # PV_tester2.py:101: no negative density
+    L, T, Time = int(g["L"]), int(g["T"]), float(g["time"])
+    for f in range(len(g["lengths"])):
+        X, length, dN = R.film_inputs(g, f)
+        devs = {}
+        for k in R.REFINE_K:
+            r = oracle.pvsim(X[:, :-1], length, Time, L, T * k, dN, plT=k, nthreads=4)
+            assert not r["status"].any() and r["plI"].shape == (len(X), T + 1)
+            devs[k] = R.deviation(r["plI"], g["plI_odeint"][f])
+        R.check_refinement(devs, label="film %d" % f)
+
+
 def test_scipy_port_matches_the_reference_cpu_path_on_configs0(golden):
     """BASELINE.json configs[0] as worded -- Power_scan (3 excitations, 128 nodes) x 64 random samples through the reference's own
     CPU path -- is the fixture tests/golden/fallback64.npz: bayeslib.bayes(pvSim_fallback.pvSim_cpu_fallback, ...) with has_GPU

@@ -66,7 +66,9 @@ for k, d in traffic.items():
               "hbm_write_bytes_per_launch": write * 1024,
               "hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024}
 # what the PMC passes ran (bench.py reads this back to label `traffic`)
+# ... and WHICH library: bench.py's attach_traffic flags the quotation as stale when the loaded library's hash differs
 out["_meta"] = {"tag": tag, "T": bench["config"].get("T"), "workload": bench["config"].get("workload"),
+                "srchash": (bench.get("library") or {}).get("srchash"),
                 "command": "bench.py --no-cpu-baseline --no-full-length (tools/profile_round.sh)"}
 json.dump(out, open(os.path.join(dst, tag + "_hbm_traffic.json"), "w"), indent=1)
 print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in out.items() if k != "_meta"}, indent=1))
