@@ -532,9 +532,9 @@ int trpl_solve_pl_resume(const double *matpar, int64_t S, double length_nm, doub
                          int32_t *status, int64_t *iters_total, const int64_t *snap_steps, int32_t n_snap, double *plN,
                          double *plP, double *plE, uint32_t flags, int32_t device, double *seconds)
 {
+    ProfRange range("trpl_solve_pl_resume (pvSim, init_mode continue)");
     if (!resN || !resP || !resE) return api_fail(TRPL_ERR_ARG, "resN, resP and resE must not be NULL");
     if (t0 < 4 || t0 > T) return api_fail(TRPL_ERR_ARG, "t0=%lld must be in [4, T]: a resume needs five BDF levels", (long long)t0);
-    ProfRange range("trpl_solve_pl_resume (pvSim, init_mode continue)");
     return solve_pl_host_impl(matpar, S, length_nm, time_ns, L, T, plT, tol_exp, max_iter, nullptr, t0, resN, resP, resE, plI,
                               pl_elem_bytes, pl_ld, status, iters_total, snap_steps, n_snap, plN, plP, plE, flags, device,
                               seconds);
@@ -566,13 +566,13 @@ int trpl_log10_clamp_dev(void *x, int32_t elem_bytes, int64_t rows, int64_t cols
 int trpl_log10_clamp(void *x, int32_t elem_bytes, int64_t rows, int64_t cols, int64_t ld, double min,
                      int32_t device, double *seconds)
 {
+    ProfRange range("trpl_log10_clamp (fastlog)");
     if (elem_bytes != 4 && elem_bytes != 8) return api_fail(TRPL_ERR_ARG, "elem_bytes must be 4 or 8");
     if (rows < 0 || cols < 0 || ld < cols) return api_fail(TRPL_ERR_ARG, "bad shape");
     if (seconds) *seconds = 0.0;
     if (rows == 0 || cols == 0) return TRPL_OK;
     if (!x) return api_fail(TRPL_ERR_ARG, "x must not be NULL");
     if (int rc = select_device(device)) return rc;
-    ProfRange range("trpl_log10_clamp (fastlog)");
     HostPin pin;
     CallScope cs;
     HIP_TRY(cs.open());
@@ -606,13 +606,13 @@ int trpl_sse_accumulate_dev(double *P, const void *plI, int32_t elem_bytes, int6
 int trpl_sse_accumulate(double *P, const void *plI, int32_t elem_bytes, int64_t rows, int64_t n_obs, int64_t ld,
                         const double *values, const double *mag, int32_t device, double *seconds)
 {
+    ProfRange range("trpl_sse_accumulate (prob)");
     if (elem_bytes != 4 && elem_bytes != 8) return api_fail(TRPL_ERR_ARG, "elem_bytes must be 4 or 8");
     if (rows < 0 || n_obs < 0 || ld < n_obs) return api_fail(TRPL_ERR_ARG, "bad shape");
     if (seconds) *seconds = 0.0;
     if (rows == 0) return TRPL_OK;
     if (!P || !mag || (n_obs && (!plI || !values))) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");
     if (int rc = select_device(device)) return rc;
-    ProfRange range("trpl_sse_accumulate (prob)");
     HostPin pin;
     CallScope cs;
     HIP_TRY(cs.open());
@@ -808,8 +808,8 @@ int trpl_loglik_obs(const double *X, int64_t S, int32_t C, const double *lengths
                     const int64_t *n_obs, double *P, double *sse, int32_t *status, int64_t *iters_total,
                     int32_t *floor_col, uint32_t flags, int32_t device, double *seconds)
 {
-    if (!obs_hi || !obs_dx || !obs_h) return api_fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h must not be NULL");
     ProfRange range("trpl_loglik_obs (pvSim + fastlog + griddata + prob, fused)");
+    if (!obs_hi || !obs_dx || !obs_h) return api_fail(TRPL_ERR_ARG, "obs_hi, obs_dx and obs_h must not be NULL");
     return loglik_host_impl(X, S, C, lengths_nm, time_ns, L, T, 1, tol_exp, max_iter, dN, obs, obs_hi, obs_dx, obs_h,
                             obs_ld, n_obs, P, sse, status, iters_total, floor_col, flags, device, seconds);
 }

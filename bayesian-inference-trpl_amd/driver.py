@@ -86,17 +86,37 @@ def bracket_times(sim_t, times):
     return hi.astype(np.int32), times - sim_t[lo], sim_t[hi] - sim_t[lo]
 
 
-DEFAULT_MAX_HOST_BYTES = 16 << 30      # gpu_info["max_host_bytes"]: PL results the unfused overlapped path may hold at once
+DEFAULT_MAX_HOST_BYTES = 32 << 30      # gpu_info["max_host_bytes"]: what the results of the unfused overlapped path may hold at once
 
 
 def unfused_curve_bytes(size, ncol, pl_dtype, n_interp, num_curves):
-    """Host bytes ONE (block, curve) result of the unfused path holds: the block's PL matrix (size x ncol in the caller's
-    PL dtype, bayeslib.py:137) + a float64 interpolated copy (size x n_obs) per experiment whose times are off the grid
-    (:184-191).  n_interp: the n_obs of every (experiment, curve) that is interpolated, 0 for the others, experiment-major;
-    the largest curve counts."""
+    """Host bytes of ONE (block, curve) result of the unfused path, as (full, done).  full: while it is being made -- the
+    block's PL matrix (size x ncol in the caller's PL dtype, bayeslib.py:137) + a float64 interpolated copy (size x n_obs) per
+    experiment whose times are off the grid (:184-191).  done: once it waits for prob() -- the same, minus the PL matrix when
+    no experiment compares this curve on the grid (the matrix is then dropped as soon as it has been interpolated).
+    n_interp: the n_obs of every (experiment, curve) that is interpolated, 0 for those compared on the grid,
+    experiment-major; the largest curve counts."""
     n_interp = np.asarray(n_interp, dtype=np.int64).reshape(-1, max(int(num_curves), 1))
-    worst = int(n_interp.sum(axis=0).max()) if n_interp.size else 0
-    return int(size) * (int(ncol) * np.dtype(pl_dtype).itemsize + 8 * worst)
+    pl = int(ncol) * np.dtype(pl_dtype).itemsize
+    if not n_interp.size:
+        return int(size) * pl, int(size) * pl
+    interp = 8 * n_interp.sum(axis=0)                                     # per curve
+    keeps_pl = (n_interp == 0).any(axis=0)                                # some experiment reads the PL matrix itself
+    full = int(size) * int((pl + interp).max())
+    done = int(size) * int(np.where(keeps_pl, pl + interp, interp).max())
+    return full, done
+
+
+def overlap_window(full, done, budget, num_curves):
+    """How many (block, curve) results the overlapped unfused path may hold at once -- being made by a worker thread, waiting
+    for prob(), or being consumed -- and how many worker threads make them: the largest window <= 2 * num_curves (this block's
+    curves + the next block's) whose bytes, workers * full + (window - workers) * done, fit the budget.  (0, 0): not even two
+    results fit -- the path then runs inline, one result at a time, like the reference (bayeslib.py:137)."""
+    for w in range(2 * int(num_curves), 1, -1):
+        workers = min(int(num_curves), 8, w - 1)
+        if workers * full + (w - workers) * done <= budget:
+            return w, workers
+    return 0, 0
 
 
 def loglik(X, init_params, lengths, Time, L, T, obs, tol=7, MAX=10000, plT=1, P=None, pl_f32=False,
@@ -335,12 +355,21 @@ def simulate(model, e_data, P, X, plI, plI_int, num_curves, sim_params, init_par
     obs_times = [[np.asarray(exp[0][c], dtype=float) for c in range(num_curves)] for exp in e_data]
     on_grid = [[almost_equal(sim_t, t) for t in per_curve] for per_curve in obs_times]        # :173,:182-183
 
-    def process_curve(ic_num, blk, size):
+    # gpu_info["kernel"] = "pair" / "single" pins the FAST stepper of every pvSim launch (measurements; default None: the
+    # library picks per launch -- the one-system kernel for the reference's 1024-sample blocks.  Pinning the paired kernel for
+    # the overlapped launches was measured and rejected: three worker threads keep 3 x 1024 systems in flight, which under-fills
+    # it -- production shape 126 s against 119 s, profiles/r6_e2e_production_ab.json)
+    model_kw = {}
+    if model is pvSim and gpu_info.get("kernel") is not None and int(gpu_info.get("max_sims_per_block", 1)) == 1:
+        model_kw["kernel"] = gpu_info["kernel"]
+    reads_pl = [any(on_grid[e][c] for e in range(len(e_data))) for c in range(num_curves)]
+
+    def process_curve(ic_num, blk, size, last=True):
         par = list(sim_params)
         par[0] = thicknesses[ic_num]                                      # :119
         buf = np.empty((size, ncol), dtype=pl_dtype)                      # :137
         sec = model(buf, None, None, None, X[blk:blk + size, :-1], par, init_params[ic_num], None, None,
-                    int(gpu_info.get("max_sims_per_block", 1)), init_mode="points")      # :93,:146
+                    int(gpu_info.get("max_sims_per_block", 1)), init_mode="points", **model_kw)      # :93,:146
         misc = 0.0
         if NORMALIZE:                                                     # :150-154
             buf /= buf[:, :1].copy()
@@ -354,34 +383,38 @@ def simulate(model, e_data, P, X, plI, plI_int, num_curves, sim_params, init_par
                 clock0 = time.perf_counter()
                 ints.append(interp_rows(sim_t, buf, obs_times[e][ic_num]))
                 misc += time.perf_counter() - clock0
-        return buf, ints, sec, misc
+        # the PL matrix itself is only read again when an experiment compares this curve on the grid; otherwise it is let go
+        # here, while the result waits for prob() (the run's LAST result keeps it: plI[gpu_id] ends up holding the last PL
+        # matrix, as in the reference)
+        return (buf if (reads_pl[ic_num] or last) else None), ints, sec, misc
 
     blocks = list(range(gpu_id * group, len(X), num_gpus * group))        # :131
     tasks = [(blk, min(group, len(X) - blk), c) for blk in blocks for c in range(num_curves)]   # the order P receives them in
-    # Host memory of the overlapped path is bounded by BYTES, not by a block count: at most `window` (block, curve) results
-    # exist at once -- being solved, waiting for their turn at prob(), or still referenced by plI[gpu_id] -- and the window is
-    # what gpu_info["max_host_bytes"] (default 16 GiB) holds of unfused_curve_bytes(), capped at two blocks' curves (the
-    # round-5 schedule: this block's curves + the next block prefetched).  Below two results the path runs inline, one result
-    # at a time -- what the reference holds (bayeslib.py:137).
-    per_curve = unfused_curve_bytes(min(group, len(X)) if len(X) else 0, ncol, pl_dtype,
-                                    [0 if on_grid[e][c] else len(obs_times[e][c]) for e in range(len(e_data))
-                                     for c in range(num_curves)], num_curves)
-    budget = int(gpu_info.get("max_host_bytes", DEFAULT_MAX_HOST_BYTES))
-    window = min(2 * num_curves, budget // max(per_curve, 1))
+    # Host memory of the overlapped path is bounded by BYTES (gpu_info["max_host_bytes"], default 32 GiB), not by a block
+    # count: overlap_window() picks how many results may exist at once -- at most two blocks' curves, the round-5 schedule --
+    # and how many worker threads make them.
+    full, done = unfused_curve_bytes(min(group, len(X)) if len(X) else 0, ncol, pl_dtype,
+                                     [0 if on_grid[e][c] else len(obs_times[e][c]) for e in range(len(e_data))
+                                      for c in range(num_curves)], num_curves)
+    window, workers = overlap_window(full, done, int(gpu_info.get("max_host_bytes", DEFAULT_MAX_HOST_BYTES)), num_curves)
     if window < 2:
         overlap = False
     pool = None
     if overlap:
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(max_workers=min(num_curves, 8, window - 1))
+        pool = ThreadPoolExecutor(max_workers=workers)
     try:
         nxt, queue = 0, None
+
+        def submit_next():
+            b2, s2, c2 = tasks[nxt]
+            queue.append(pool.submit(process_curve, c2, b2, s2, nxt == len(tasks) - 1))
+
         if overlap:
             queue = deque()
-            while nxt < len(tasks) and len(queue) < window - 1:          # + the result plI[gpu_id] keeps = window
-                blk, size, c = tasks[nxt]
-                queue.append(pool.submit(process_curve, c, blk, size))
+            while nxt < len(tasks) and len(queue) < window - 1:          # + the result being consumed = window
+                submit_next()
                 nxt += 1
         for blk, size, ic_num in tasks:
             if ic_num == 0:
@@ -401,10 +434,9 @@ def simulate(model, e_data, P, X, plI, plI_int, num_curves, sim_params, init_par
             for e, exp in enumerate(e_data):
                 plI_int[gpu_id] = ints[e]
                 err_sq_time[gpu_id] += prob(P[e, blk:blk + size], ints[e], exp[1][ic_num], None, mag, device=device)
-            del ints                                                      # plI[gpu_id] / plI_int[gpu_id] keep the last matrices, as there
+            del ints                                                      # plI_int[gpu_id] keeps the last matrix, as there
             if overlap and nxt < len(tasks):                              # the previous result is gone: the window has room
-                b2, s2, c2 = tasks[nxt]
-                queue.append(pool.submit(process_curve, c2, b2, s2))
+                submit_next()
                 nxt += 1
     finally:
         if pool is not None:

@@ -100,7 +100,7 @@ def _snapshot_target(arr, S, n, width):
 
 
 def pvSim(plI_main, plN_main, plP_main, plE_main, matPar, simPar, iniPar, TPB=None, BPG=None,
-          max_sims_per_block=1, init_mode="exp", strict=False, device=0, info=None):
+          max_sims_per_block=1, init_mode="exp", strict=False, device=0, info=None, kernel=None):
     """pvSimPCR.pvSim (pvSimPCR.py:309).  TPB and BPG (CUDA launch shape) are accepted and ignored: one wavefront owns
     one system (or two).  max_sims_per_block = 2 .. 4 (2 .. 16 on grids of up to 64 nodes) -- neighbouring samples
     sharing one convergence test -- is honoured (bit for bit with strict=True).  init_mode "continue" (a stub in the reference,
@@ -109,7 +109,8 @@ def pvSim(plI_main, plN_main, plP_main, plE_main, matPar, simPar, iniPar, TPB=No
     :169-171), are FILLED when they are float64 arrays of shape (S, len(pT), L) / (S, len(pT), L+1): the
     densities (nm^-3) and the field (nm^-1) of the state at the time steps pT = simPar[5]; anything else
     (None, the dummies bayeslib passes) is ignored as before.  `info`, if a dict, receives 'status' and
-    'iters_total'."""
+    'iters_total'.  kernel: None (the library picks the FAST stepper by launch size) | "pair" | "single" (TRPL_FLAG_KERNEL_*;
+    driver.simulate pins it for the launches it overlaps)."""
     Length, Time, L, T, plT, pT, tol, MAX = simPar
     # max_sims_per_block > 1 couples the convergence of neighbouring samples in the reference (pvSimPCR.py:213-216):
     # honoured up to 4 per bundle from L = 128 on and 16 up to L = 64 (strict: any L, bit for bit; otherwise L <= 128, to
@@ -144,6 +145,7 @@ def pvSim(plI_main, plN_main, plP_main, plE_main, matPar, simPar, iniPar, TPB=No
     _, status, iters, sec = solve_pl(matPar, Length, Time, int(L), int(T), dN, plT=int(plT), tol=int(tol),
                                      MAX=int(MAX), out=plI_main, strict=strict, device=device,
                                      resume=tuple(iniPar) if init_mode == "continue" else None, bundle=bundle,
+                                     kernel=kernel if (bundle == 1 and not strict and int(L) == 128) else None,
                                      snap_steps=steps if want else None, **(snaps if want else {}))
     if info is not None:
         info["status"] = status

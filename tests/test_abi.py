@@ -400,3 +400,55 @@ def test_kernel_name_refuses_what_a_launch_refuses(trpl):
         assert name in have, (name, L, hex(flags), snap, steps)
         named += 1
     assert named > 100 and refused > 1000, (named, refused)
+
+
+def test_roctx_ranges_bracket_the_host_buffer_calls_when_a_profiler_provides_them(trpl, tmp_path):
+    """ABI 5: the host-buffer entry points open a ROCTx range named after the reference callable they replace (pvSim /
+    fastlog / prob: pvSimPCR.py:378-381, probs.py:79-84, :51-61) -- bound at run time from whatever the process exports (no
+    link dependency; `rocprofv3 --marker-trace` preloads librocprofiler-sdk-roctx.so), a no-op otherwise.  A child process
+    with tests/mock_roctx preloaded calls the three callables' entry points without a device: each call returns its
+    ordinary status (TRPL_ERR_NODEVICE here, TRPL_OK for an empty batch) and has pushed and popped exactly one range;
+    without the preload the same calls behave identically and nothing is pushed.  (On the GPU box the real marker trace is
+    taken with tools/marker_probe.py -> profiles/r6_marker_trace.txt.)"""
+    import subprocess
+    so = str(tmp_path / "libmock_roctx.so")
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-O1", "-o", so, os.path.join(ROOT, "tests", "mock_roctx", "mock_roctx.c")])
+    code = r"""
+import ctypes as C, os, sys
+sys.path.insert(0, %r)
+import numpy as np
+import trpl_amd
+A = trpl_amd._abi
+lib = A.lib()
+nodev = lib.trpl_device_count() == 0
+x = np.ones((4, 8), dtype=np.float32)
+P = np.zeros(4); vals = np.zeros(8); mag = np.zeros(4)
+X = np.ones((4, 12)); dN = np.ones(128); pl = np.empty((4, 3)); st = np.zeros(4, dtype=np.int32)
+sec = C.c_double()
+rcs = [lib.trpl_log10_clamp(A.ptr(x), 4, 4, 8, 8, 1e-300, 0, C.byref(sec)),
+       lib.trpl_sse_accumulate(A.ptr(P), A.ptr(x), 4, 4, 8, 8, A.ptr(vals), A.ptr(mag), 0, C.byref(sec)),
+       lib.trpl_solve_pl(A.ptr(X), 4, 2000.0, 0.05, 128, 2, 1, 7, 100, A.ptr(dN), A.ptr(pl), 8, 3, A.ptr(st), None, 0, 0, C.byref(sec)),
+       lib.trpl_log10_clamp(A.ptr(x), 4, 0, 8, 8, 1e-300, 0, C.byref(sec))]          # an empty batch: TRPL_OK, still one range
+want = ([A.ERR_NODEVICE] * 3 if nodev else [A.OK] * 3) + [A.OK]
+assert rcs == want, (rcs, want)
+m = os.environ.get("MOCK_ROCTX")
+if m:
+    mock = C.CDLL(m)
+    mock.mock_roctx_name.restype = C.c_char_p
+    n = mock.mock_roctx_pushes()
+    print("RANGES", n, mock.mock_roctx_pops(), mock.mock_roctx_depth(), mock.mock_roctx_max_depth(),
+          "|".join(mock.mock_roctx_name(i).decode() for i in range(n)))
+else:
+    print("RANGES none")
+""" % ROOT
+    env = dict(os.environ, TRPL_AUTOBUILD="0")
+    env.pop("LD_PRELOAD", None)
+    plain = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert plain.returncode == 0 and "RANGES none" in plain.stdout, plain.stderr[-2000:]
+    traced = subprocess.run([sys.executable, "-c", code], env=dict(env, LD_PRELOAD=so, MOCK_ROCTX=so), capture_output=True,
+                            text=True, timeout=300)
+    assert traced.returncode == 0, traced.stderr[-2000:]
+    line = [ln for ln in traced.stdout.splitlines() if ln.startswith("RANGES")][0].split(" ", 5)
+    assert line[1:5] == ["4", "4", "0", "1"], line                       # four calls: four ranges, all closed, never nested
+    assert line[5].split("|") == ["trpl_log10_clamp (fastlog)", "trpl_sse_accumulate (prob)", "trpl_solve_pl (pvSim)",
+                                  "trpl_log10_clamp (fastlog)"]

@@ -127,3 +127,59 @@ def test_floor_col_of_a_flagged_system_is_the_sentinel(gpu, mode):
     assert flagged.any() and not flagged.all()
     assert (info["floor_col"][flagged] == -2).all() and np.isinf(info["sse"][flagged]).all()
     assert (info["floor_col"][~flagged] >= -1).all() and np.isfinite(info["sse"][~flagged]).all()
+
+
+def test_full_size_bench_batch_fast_against_strict(gpu):
+    """BASELINE configs[1] IN FULL SIZE at the window bench.py times -- Power_scan x 65 536 samples x 3 curves = 196 608
+    systems, T = 8000, device-resident, the launch of the headline number -- FAST (the paired kernel the library picks)
+    against STRICT (the reference's arithmetic: bit-identical to the oracle on every golden and on the 64-sample oracle
+    batch of this window).  What include/trpl.h promises for FAST, on every system of the batch:
+      * status: nothing flagged in either arithmetic;
+      * iteration path: iteration totals EQUAL on all 196 608 systems but at most two, which may differ by one (measured 0
+        here; 8 of 196 608 over the reference's T = 80 000 window, profiles/r5_validate_*);
+      * floor_col identical on every system;
+      * every floor-free sample's likelihood within 1e-8 of STRICT's (measured 1.2e-9), and every sample whose likelihood
+        differs by more than 1e-6 is flagged by floor_col >= 0.
+    ~20 s (STRICT is 6.4 x slower than FAST).  The same comparison over T = 80 000 stays a tool
+    (tools/validate_fast_vs_strict.py, ~3 min)."""
+    import torch
+    from trpl_amd import device as tdev
+    w = gpu.workloads
+    S, T, L = 65536, 8000, 128
+    Time = T * DT
+    dev = torch.device("cuda", 0)
+    ini, lens = w.power_scan(L)
+    C = len(lens)
+    X = torch.from_numpy(w.samples(S)).to(dev)
+    ini_d = torch.from_numpy(ini).to(dev)
+    mark = torch.from_numpy((w.MARKED_POINT * gpu.UNIT_CONVERSIONS)[None, :-1].copy()).to(dev)
+    obs = torch.empty((C, T + 1), dtype=torch.float64, device=dev)
+    for c in range(C):
+        pl = torch.empty((1, T + 1), dtype=torch.float64, device=dev)
+        tdev.solve_pl_device(mark, lens[c], Time, L, T, ini_d[c].contiguous(), pl, flags=gpu.FLAG_STRICT)
+        obs[c] = torch.log10(pl[0])
+    assert gpu._abi.lib().trpl_kernel_variant(S * C, L, T, 0) == gpu._abi.KERNEL_FAST_PAIR
+    res = {}
+    for name, flags in (("fast", 0), ("strict", gpu.FLAG_STRICT)):
+        P = torch.zeros(S, dtype=torch.float64, device=dev)
+        sse = torch.empty((C, S), dtype=torch.float64, device=dev)
+        st = torch.empty((C, S), dtype=torch.int32, device=dev)
+        it = torch.empty((C, S), dtype=torch.int64, device=dev)
+        fc = torch.empty((C, S), dtype=torch.int32, device=dev)
+        tdev.loglik_device(X, ini_d, lens, Time, L, T, obs, [T + 1] * C, P, sse, st, it, flags=flags, floor_col=fc)
+        torch.cuda.synchronize()
+        res[name] = (P.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy(), fc.cpu().numpy())
+    (Pf, sf, itf, fcf), (Ps, ss, its, fcs) = res["fast"], res["strict"]
+    assert not sf.any() and not ss.any()
+    d = np.abs(itf - its)
+    assert (d != 0).sum() <= 2 and d.max() <= 1, (int((d != 0).sum()), int(d.max()), np.argwhere(d != 0)[:4].tolist())
+    assert np.array_equal(fcf, fcs)
+    clear = (fcs == -1).all(axis=0)
+    assert clear.mean() > 0.9
+    rel = np.abs(Pf - Ps) / np.abs(Ps)
+    assert rel[clear].max() < 1e-8, float(rel[clear].max())
+    assert not (rel[clear] > 1e-6).any() and ((rel > 1e-6) <= ~clear).all()
+    from gpu_common import record
+    record("full_size_fast_vs_strict_T8000", {"systems": int(itf.size), "iteration_totals_differ": int((d != 0).sum()),
+                                               "floor_free_samples": int(clear.sum()), "max_gap_floor_free": float(rel[clear].max()),
+                                               "samples_above_1e-6": int((rel > 1e-6).sum()), "max_gap": float(rel.max())})

@@ -469,6 +469,48 @@ def test_offgrid_observations_dense_sparse_and_on_the_window_edges(gpu, kernel):
             assert np.max(np.abs(info["sse"][c] / want - 1)) < 1e-11, c
 
 
+@pytest.mark.parametrize("kernel", ["single", "pair"])
+def test_offgrid_observations_with_systems_flagged_in_the_middle_of_the_window(gpu, kernel):
+    """The batched off-grid emission when a system is FLAGGED (status = 1 + t, pvSimPCR.py:269) at a step t > 0: its
+    parked columns are flushed up to the failing step only (PlSink::flush_batch with n = status - 1 - base), its squared
+    error is +inf, floor_col -2, the sample's likelihood -inf -- and its wavefront partner (paired kernel: the flagged
+    system is parked as a benign one beside a live one) and every other system are untouched.  Every iteration-capped
+    system of the reference's parameter box is flagged at step 0 (tools/flag_step_probe.py: 12 batches, 24 000 systems),
+    so the inputs are hostile on purpose: every other sample gets a NEGATIVE radiative coefficient (-100 x its B), whose
+    dn/dt = +|B| n p blows up in finite time -- flags at steps 2 .. 366 of a 400-step window, before, inside and after the
+    first 64-column batch, on one, two or all three curves of a sample (tools/flag_step_probe2.py).  Reference: STRICT with
+    the same off-grid times (the serial column-by-column emission)."""
+    w = gpu.workloads
+    ini, lens = w.power_scan(128)
+    S, T = 24, 400
+    Time = T * DT
+    X = w.samples(S, seed=23)
+    X[::2, 4] *= -100.0
+    rng = np.random.default_rng(3)
+    times = [np.sort(rng.uniform(0.0, Time, 300)) for _ in range(3)]
+    obs = [np.full(len(t), 18.0) - 0.2 * t for t in times]
+    info, ref = {}, {}
+    P = gpu.loglik(X, ini, lens, Time, 128, T, obs, times=times, kernel=kernel, MAX=200, info=info)
+    Ps = gpu.loglik(X, ini, lens, Time, 128, T, obs, times=times, strict=True, MAX=200, info=ref)
+    st = ref["status"]
+    flagged = st != 0
+    assert (st[flagged] > 1).sum() >= 10 and (st[flagged] > 65).sum() >= 4 and (st[flagged] == 1).sum() >= 1, st.tolist()
+    assert not flagged[:, 1::2].any()                                        # the untouched samples all converge
+    assert np.array_equal(info["status"], st)                                # flagged at the same step
+    assert np.array_equal(info["iters_total"], ref["iters_total"])          # the iterations up to the failing step included
+    for i in (info, ref):
+        assert np.isposinf(i["sse"][flagged]).all() and (i["floor_col"][flagged] == -2).all()
+        assert (i["floor_col"][~flagged] != -2).all()
+    dead = flagged.any(axis=0)
+    assert np.isneginf(P[dead]).all() and np.isneginf(Ps[dead]).all()
+    clear = ~flagged & (ref["floor_col"] == -1) & np.isfinite(ref["sse"])
+    assert clear[:, 1::2].all()                                              # every curve of every untouched sample
+    assert np.array_equal(info["floor_col"][~flagged], ref["floor_col"][~flagged])
+    assert np.max(np.abs(info["sse"][clear] / ref["sse"][clear] - 1)) < 1e-9
+    alive = ~dead & np.isfinite(Ps)
+    assert alive[1::2].all() and np.max(np.abs(P[alive] / Ps[alive] - 1)) < 1e-9
+
+
 def test_driver_levels_agree_on_grid_prefix_observations_across_blocks(gpu, oracle):
     """The production shape in small (tools/e2e_production.py): observation times that are a PREFIX of the simulation grid, of
     different lengths per curve, S not a multiple of sims_per_gpu.  driver.bayes through (A) the fused level -- which routes grid

@@ -391,7 +391,7 @@ def test_twothick_bench_window_against_the_oracle(gpu, twothick_window, mode):
             assert np.max(np.abs(info["sse"][c] - g["sse"][c]) / g["sse"][c]) < 1e-12
             continue
         # iteration totals: the oracle's (a knife-edge convergence decision may flip on one system of the 32, by one)
-        follows_iteration_path(it, want["iters_total"], "curve %d" % c)
+        n_differ = follows_iteration_path(it, want["iters_total"], "curve %d" % c)
         assert np.array_equal(info["iters_total"][c], it)                  # fused and PL-storing launches agree
         r = want["plI"] / scale[:, None]
         dev = np.abs(pl / want["plI"] - 1)
@@ -407,7 +407,7 @@ def test_twothick_bench_window_against_the_oracle(gpu, twothick_window, mode):
         clear = want_col < 0
         gap = np.abs(info["sse"][c] - g["sse"][c]) / g["sse"][c]
         assert gap[clear].max() < SSE_GATE[length], (c, length, float(gap[clear].max()))
-        rec["curve%d" % c] = dict(length=length, iteration_totals_differ=int(differ.sum()), worst_over_bound=worst,
+        rec["curve%d" % c] = dict(length=length, iteration_totals_differ=n_differ, worst_over_bound=worst,
                                   max_dev_above_floor=float(dev[above].max()), envelope_k_measured=k_meas,
                                   floor_free=int(clear.sum()), max_sse_gap_floor_free=float(gap[clear].max()))
     if not mode.get("strict"):

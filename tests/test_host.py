@@ -166,26 +166,50 @@ def test_unfused_overlap_is_bounded_by_host_bytes(trpl, monkeypatch):
     e_data = [([sim_t] * C, [np.zeros(T + 1)] * C), ([sim_t[:9] + 0.01] * C, [np.ones(9)] * C)]
     flags = {"load_PL_from_file": False, "log_pl": True, "self_normalize": False}
     group = 4                                                    # 6 blocks x 3 curves = 18 results
-    per = drv.unfused_curve_bytes(group, T + 1, np.float32, [0] * C + [9] * C, C)
-    assert per == group * ((T + 1) * 4 + 9 * 8)
+    full, done = drv.unfused_curve_bytes(group, T + 1, np.float32, [0] * C + [9] * C, C)
+    assert full == done == group * ((T + 1) * 4 + 9 * 8)         # experiment 0 reads the PL matrix itself: nothing to drop
+    assert drv.overlap_window(full, done, 3 * full + full // 2, C) == (3, 2) and drv.overlap_window(full, done, full, C) == (0, 0)
+    assert drv.overlap_window(full, done, drv.DEFAULT_MAX_HOST_BYTES, C) == (2 * C, C)
     results = {}
-    for label, info, bound in (("serial", {"overlap_curves": False}, 1), ("one", {"max_host_bytes": per}, 1),
-                               ("three", {"max_host_bytes": 3 * per + per // 2}, 3), ("default", {}, 2 * C)):
+
+    def run(label, info, bound, data):
         state.update(live=0, peak=0, calls=0)
         P = np.zeros((2, S))
         st, et, mt = np.zeros(1), np.zeros(1), np.zeros(1)
         plI, plI_int = [None], [None]
-        drv.simulate(model, e_data, P, X, plI, plI_int, C, [100.0, Time, L, T, 1, (0,), 7, 50], ini, flags,
+        drv.simulate(model, data, P, X, plI, plI_int, C, [100.0, Time, L, T, 1, (0,), 7, 50], ini, flags,
                      dict({"sims_per_gpu": group, "num_gpus": 1}, **info), 0, st, et, mt)
         assert state["calls"] == 18 and state["peak"] <= bound, (label, state)
-        if label == "default":
-            assert state["peak"] > 3                                        # the default budget does overlap two blocks
         assert plI[0].shape == (group, T + 1) and plI_int[0].shape == (group, 9)      # the last matrices stay, as in the reference
         results[label] = P
+        peak = state["peak"]
         del plI, plI_int
         gc.collect()
+        return peak
+
+    run("serial", {"overlap_curves": False}, 1, e_data)
+    run("one", {"max_host_bytes": full}, 1, e_data)
+    run("three", {"max_host_bytes": 3 * full + full // 2}, 3, e_data)
+    assert run("default", {}, 2 * C, e_data) > 3                 # the default budget does overlap two blocks
     for label in ("one", "three", "default"):
         assert np.array_equal(results[label], results["serial"]), label
+    # every experiment off the grid (the production shape: observation times that are not the full grid): a result waiting for
+    # prob() has let its PL matrix go -- only the worker threads' matrices (and the run's last one) are alive, whatever the window
+    off = [([sim_t[:9] + 0.01] * C, [np.ones(9)] * C), ([sim_t[:7] + 0.02] * C, [np.zeros(7)] * C)]
+    full2, done2 = drv.unfused_curve_bytes(group, T + 1, np.float32, [9] * C + [7] * C, C)
+    assert full2 == group * ((T + 1) * 4 + 16 * 8) and done2 == group * 16 * 8
+    assert drv.overlap_window(full2, done2, C * full2 + C * done2, C) == (2 * C, C)
+    state.update(live=0, peak=0, calls=0)
+    P = np.zeros((2, S))
+    plI, plI_int = [None], [None]
+    drv.simulate(model, off, P, X, plI, plI_int, C, [100.0, Time, L, T, 1, (0,), 7, 50], ini, flags,
+                 {"sims_per_gpu": group, "num_gpus": 1}, 0, np.zeros(1), np.zeros(1), np.zeros(1))
+    assert state["calls"] == 18 and state["peak"] <= C + 1, state
+    assert plI[0] is not None and plI[0].shape == (group, T + 1) and plI_int[0].shape == (group, 7)
+    Ps = np.zeros((2, S))
+    drv.simulate(model, off, Ps, X, [None], [None], C, [100.0, Time, L, T, 1, (0,), 7, 50], ini, flags,
+                 {"sims_per_gpu": group, "num_gpus": 1, "overlap_curves": False}, 0, np.zeros(1), np.zeros(1), np.zeros(1))
+    assert np.array_equal(P, Ps)
 
 
 def test_csv_ingestion_matches_reference(trpl, golden, tmp_path):

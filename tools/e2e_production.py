@@ -63,7 +63,8 @@ def main():
     ap.add_argument("--levels", default="A,B1024,B16384")
     ap.add_argument("--oracle-samples", type=int, default=256)
     ap.add_argument("--no-strict", action="store_true")
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r5", "e2e_production.json"))
+    ap.add_argument("--max-host-gib", type=float, default=None, help="gpu_info['max_host_bytes'] of the unfused levels (default: the driver's)")
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r6", "e2e_production.json"))
     a = ap.parse_args()
 
     import trpl_amd
@@ -95,9 +96,15 @@ def main():
     results = {}
     for level in a.levels.split(","):
         fused = level == "A"
-        group = a.S if fused else int(level[1:])
+        digits = "".join(ch for ch in level[1:] if ch.isdigit())
+        forced = level[1 + len(digits):] or None                            # "B1024single" / "B1024pair": gpu_info["kernel"]
+        group = a.S if fused else int(digits)
         gpu_info = {"sims_per_gpu": group, "num_gpus": 1, "has_GPU": True, "threads_per_block": (128,), "max_sims_per_block": 1,
                     "fused": fused}
+        if forced:
+            gpu_info["kernel"] = forced
+        if a.max_host_gib is not None and not fused:
+            gpu_info["max_host_bytes"] = int(a.max_host_gib * 2 ** 30)
         h = ListHandler()
         logger = logging.getLogger("e2e_" + level)
         logger.setLevel(logging.INFO)
@@ -124,7 +131,7 @@ def main():
         files = sorted(os.listdir(out_dir))
         rec = {"integration": "driver.bayes, fused launch per block" if fused else
                "reference call sequence pvSim -> fastlog -> griddata -> prob (drop-in callables)",
-               "sims_per_gpu": group, "bayes_wall_s": t1 - t0, "export_s": t2 - t1, "wall_to_npy_s": t2 - t0,
+               "sims_per_gpu": group, "kernel": forced or "library's choice per launch", "max_host_bytes": gpu_info.get("max_host_bytes", trpl_amd.driver.DEFAULT_MAX_HOST_BYTES), "bayes_wall_s": t1 - t0, "export_s": t2 - t1, "wall_to_npy_s": t2 - t0,
                "likelihoods_per_s": a.S / (t2 - t0), "files": files, "finite_likelihoods": int(np.isfinite(P[0]).sum()),
                "steps_solved_per_system": [n - 1 for n in n_obs] if fused else [T] * 3}
         rec.update(timers_from(h.lines))
