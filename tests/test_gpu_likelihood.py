@@ -544,3 +544,42 @@ def test_driver_levels_agree_on_grid_prefix_observations_across_blocks(gpu, orac
     assert np.max(np.abs(res["B"] / res["A"] - 1)) < 1e-7                  # (blocks of 8 run the one-system kernel, the fused 16 x 3 too)
     want = oracle.simulate_loglik(X, ini, lens, Time, 128, T, [(e_data[0][0], e_data[0][1])], sims_per_gpu=8, nthreads=nthreads())[0]
     assert np.max(np.abs(res["B"] / want - 1)) < 2e-5 and np.max(np.abs(res["A"] / want - 1)) < 2e-5
+
+
+def test_literal_interpolation_switch_reaches_the_multi_experiment_branch(gpu, oracle, monkeypatch):
+    """gpu_info["interpolate_prefix"] in BOTH fused branches (round-5 advisor finding: the branch that keeps a block's PL matrix in
+    HBM for several experiments always took the prefix route).  Two experiments whose observation times are prefixes of the
+    simulation grid (one curve of the first is sampled on the whole grid): by default every (experiment, curve) pass over the
+    resident PL runs the on-grid form of trpl_loglik_from_pl_dev (no brackets), with the switch every pass but the full-grid
+    one runs the interpolating form -- seen by a spy on the device wrapper -- and the likelihoods agree to 1e-13 (interpolating AT a node returns the node's value to one rounding)."""
+    w, sm = gpu.workloads, gpu.sampler
+    ini, lens = w.power_scan(128)
+    T, Time, S = 240, 6.0, 21
+    sim_t = np.linspace(0, Time, T + 1)
+    mark = (w.MARKED_POINT * gpu.UNIT_CONVERSIONS)[None, :-1]
+    pl = [oracle.pvsim(mark, lens[c], Time, 128, T, ini[c])["plI"][0] for c in range(3)]
+    e_data = [([sim_t[:n] for n in (101, 161, 241)], [np.log10(pl[c][:n]) + 0.05 for c, n in enumerate((101, 161, 241))], [None] * 3),
+              ([sim_t[:61]] * 3, [np.log10(pl[c][:61]) - 0.03 for c in range(3)], [None] * 3)]
+    X = w.samples(S, seed=3)
+    flags = {"load_PL_from_file": False, "log_pl": True, "self_normalize": False}
+    seen = []
+    real = gpu.device.loglik_from_pl_device
+
+    def spy(*a, **kw):
+        seen.append(kw.get("obs_hi") is not None)
+        return real(*a, **kw)
+    monkeypatch.setattr(gpu.device, "loglik_from_pl_device", spy)
+    res = {}
+    for name, extra in (("prefix", {}), ("literal", {"interpolate_prefix": True})):
+        del seen[:]
+        P = np.zeros((2, S))
+        z = np.zeros(1)
+        gpu.simulate(gpu.pvSim, e_data, P, X, [None], [None], 3, [2000.0, Time, 128, T, 1, (0,), 7, 10000], ini, flags,
+                     dict({"sims_per_gpu": 8, "num_gpus": 1, "fused": True, "pl_dtype": np.float64}, **extra), 0, z.copy(), z.copy(), z.copy())
+        # per block: curves -> experiments (bayeslib.py:117,:171).  Curve 2 of experiment 0 is sampled on the FULL grid: the
+        # reference's own bypass (bayeslib.py:182-183), on the grid under either rule
+        want = [name == "literal" and not (e == 0 and c == 2) for _blk in range(3) for c in range(3) for e in range(2)]
+        assert seen == want, (name, seen)
+        res[name] = P
+    assert np.isfinite(res["prefix"]).all() and (res["prefix"] < 0).all()
+    assert np.max(np.abs(res["literal"] / res["prefix"] - 1)) < 1e-13

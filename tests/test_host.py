@@ -122,6 +122,23 @@ def test_simulate_control_flow_with_standin_compute(trpl, monkeypatch):
                      dict(flags, load_PL_from_file=True), {"sims_per_gpu": 3, "num_gpus": 1}, 0, st, et, mt)
 
 
+def test_fused_routing_rule_and_its_literal_switch(trpl):
+    """driver.observations_on_grid / fused_entry_point: ONE rule for both fused branches of simulate() (one experiment per
+    call, several experiments over a resident PL block).  Default: observation times that are a prefix of the simulation grid
+    are compared on the grid (trpl_loglik); literal = gpu_info["interpolate_prefix"]: the reference's own test -- only the FULL
+    grid bypasses the interpolation (bayeslib.py:173,:182-183), a prefix is interpolated like any other set (trpl_loglik_obs)."""
+    drv = trpl.driver
+    sim_t = np.linspace(0, 2.0, 81)
+    full, prefix, off = sim_t, sim_t[:33], sim_t[:33] + 1e-3
+    for times, default, literal in ((full, True, True), (prefix, True, False), (off, False, False), (sim_t[::2], False, False)):
+        assert drv.observations_on_grid(times, sim_t) is default
+        assert drv.observations_on_grid(times, sim_t, literal=True) is literal
+    assert drv.fused_entry_point([prefix, full, prefix], sim_t, 3) == "trpl_loglik"
+    assert drv.fused_entry_point([prefix, full, prefix], sim_t, 3, literal=True) == "trpl_loglik_obs"
+    assert drv.fused_entry_point([full, full], sim_t, 2, literal=True) == "trpl_loglik"
+    assert drv.fused_entry_point([prefix, off], sim_t, 2) == "trpl_loglik_obs"
+
+
 def test_unfused_overlap_is_bounded_by_host_bytes(trpl, monkeypatch):
     """gpu_info["max_host_bytes"] bounds the PL results the unfused overlapped path holds at once (bayeslib.py:131-137 holds
     one; round 5's overlap held two blocks' curves whatever their size).  A re-entrant stand-in model counts the PL buffers
