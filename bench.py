@@ -87,6 +87,10 @@ def main():
     ap.add_argument("--samples-total", type=int, default=None,
                     help="rehearsals: the logical batch, cut into --gpus contiguous shards by trpl_shard_bounds -- need not be "
                          "divisible by --gpus (default: --samples-per-gpu x --gpus, weak scaling)")
+    ap.add_argument("--rehearse-collectives", action="store_true",
+                    help="run the N > 1 code path -- process group, all-gather inside the timed step, max-over-ranks timing, the "
+                         "rccl record -- even at --gpus 1: with --backend nccl this is RCCL itself on one GPU (a one-rank "
+                         "communicator), the only part of the N > 1 line a one-GPU box can execute on hardware.  Not a measurement")
     ap.add_argument("--rehearse-on-device0", action="store_true",
                     help="--single-process only: all --gpus 'ranks' are device 0 (TRPL_MULTI_ALLOW_DUPLICATE_DEVICES) -- the "
                          "N-rank logic on a one-GPU box; RCCL refuses duplicate devices, so TRPL_RCCL_LIBRARY must name a stand-in "
@@ -133,6 +137,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    multi = world > 1 or args.rehearse_collectives            # the collective code path (see --rehearse-collectives)
 
     import trpl_amd
     from trpl_amd import workloads as wl
@@ -161,8 +166,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = dev if args.backend == "nccl" else torch.device("cpu")      # where collectives run
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:                   # --rehearse-collectives outside a launcher
+            import socket
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -210,7 +220,7 @@ def main():
         if record:
             e1.record()
             ev.append((e0, e1))
-        if world > 1:
+        if multi:
             full_ = trpl_amd.dist.gather_likelihoods(P[None, :].to(cdev), S_total)
             if record and args.backend == "nccl":       # solve end -> gathered vector usable: the all-gather + the wait
                 e2 = torch.cuda.Event(enable_timing=True)     # for the slowest rank's solve
@@ -221,7 +231,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -233,7 +243,7 @@ def main():
         full = step(True)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -244,7 +254,7 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     if rank == 0 and args.dump_p:
         np.save(args.dump_p, full.detach().cpu().numpy())
-    if world > 1:
+    if multi:
         agg = torch.tensor([it_total, n_fail], dtype=torch.float64, device=cdev)
         dist.all_reduce(agg)
         it_all, fail_all = int(agg[0].item()), int(agg[1].item())
@@ -255,7 +265,7 @@ def main():
     sys_steps = S_total * C * (T + 1)                         # system-timesteps per pass, all ranks
     lost = (status > 0).to(torch.float64) * (float(T + 1) - status.to(torch.float64))     # status = 1 + failing step
     steps_lost = float(lost.sum().item())
-    if world > 1:
+    if multi:
         lt = torch.tensor([steps_lost], dtype=torch.float64, device=cdev)
         dist.all_reduce(lt)
         steps_lost = float(lt.item())
@@ -297,7 +307,7 @@ def main():
                    "arithmetic": "strict" if args.strict else "fast", "precision": "fp32 state" if args.fp32 else
                    ("fp64 state + fp32 solves" if args.mixed else "fp64"), "tol_exp": tol,
                    "samples_total": S_total, "curves": C, "L": L, "T": T, "parallelism": "sample-shard x%d" % world,
-                   "collective": "none" if world == 1 else ("RCCL all_gather" if args.backend == "nccl" else "gloo all_gather (rehearsal)")},
+                   "collective": "none" if not multi else ("RCCL all_gather" if args.backend == "nccl" else "gloo all_gather (rehearsal)")},
         "value_n1_equiv": value / world,              # per-GPU rate: what this job's N = 1 line reports as `value`
         "likelihoods_per_s_at_T": S_total * args.steps / elapsed,
         "likelihoods_per_s_at_T80000_equiv": value / (C * 80001),
@@ -323,7 +333,7 @@ def main():
         out["roofline"]["wavefront_pairs"] = ("adjacent samples of one curve" if n_tab <= 0 or (flags & trpl_amd._abi.FLAG_PAIR_ADJACENT) else
                                               [{"curves": [int(tab[0][k]), int(tab[2][k])], "sample_offsets": [int(tab[1][k]), int(tab[3][k])]}
                                                for k in range(n_tab)])
-    if world > 1:
+    if multi:
         out["rccl"] = rccl_record(torch, dist, trpl_amd, args, rank, world, local_rank, dev, cdev, S_total, ev_ag)
     if rank == 0 and world == 1 and not args.no_other_configs and args.workload == "power_scan" and L == 128 \
             and not (args.fp32 or args.mixed or args.strict):
@@ -343,7 +353,7 @@ def main():
         out["library"] = library_record(trpl_amd)
         attach_traffic(out, args.traffic_profile)
     out.update(cpu_legs)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -297,6 +297,28 @@ def test_single_process_bench_with_eight_ranks_on_one_device(gpu, tmp_path, S_to
     assert r.returncode != 0 and "TRPL_RCCL_LIBRARY" in r.stderr
 
 
+def test_bench_collective_path_over_real_rccl_on_one_gpu(gpu, tmp_path):
+    """Everything of bench.py's N > 1 line that one GPU can execute ON HARDWARE: `--gpus 1 --rehearse-collectives --backend
+    nccl` runs the collective code path -- process group on the nccl backend (= RCCL), the all-gather inside the timed step
+    with its event pair, the max-over-ranks all-reduce, the iteration / failure all-reduces, rccl_record's all_gather_object
+    and its 20 isolated all-gathers -- on a one-rank communicator.  The 2- and 3-rank rehearsals above run the same code over
+    gloo; this pins the RCCL calls themselves before the driver's first multi-GPU run.  The gathered vector equals the plain
+    run's bit for bit."""
+    env = {k: v for k, v in dict(os.environ, TRPL_AUTOBUILD="0").items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p1, p2 = str(tmp_path / "p1.npy"), str(tmp_path / "p2.npy")
+    one = _bench(["--gpus", "1", "--samples-total", "4099", "--dump-p", p1] + REHEARSAL, env)
+    rc1 = _bench(["--gpus", "1", "--rehearse-collectives", "--backend", "nccl", "--samples-total", "4099", "--dump-p", p2] + REHEARSAL, env)
+    assert "rccl" not in one and one["config"]["collective"] == "none"
+    assert rc1["config"]["collective"] == "RCCL all_gather" and rc1["n_gpus"] == 1
+    r = rc1["rccl"]
+    assert r["world"] == 1 and r["backend"] == "nccl" and r["allgather_bytes"] == 4099 * 8 and r["distinct_devices"] == 1
+    assert r["allgather_us_in_loop_incl_rank_skew"] is not None and r["allgather_us_in_loop_incl_rank_skew"] > 0
+    assert r["allgather_us_isolated"] > 0 and r["devices"][0]["device"] == 0
+    assert rc1["nonconverged_systems"] == 0 and abs(rc1["value_n1_equiv"] - rc1["value"]) < 1e-9 * rc1["value"]
+    assert np.array_equal(np.load(p1), np.load(p2))
+
+
 def test_rank_driver_gathers_over_rccl_on_a_one_rank_group(gpu, tmp_path):
     """The one-process-per-GPU driver with the REAL collective backend: a child process joins a 1-rank
     torch.distributed group on the `nccl` backend (= RCCL on ROCm), computes its shard with the fused call and
