@@ -20,7 +20,7 @@ namespace trpl {
 // per row (interleaved layout, NR * sizeof(T) > 16: the line is gone before the second instruction asks for
 // its other half).  So: one wave per workgroup everywhere, non-temporal loads only where an instruction
 // consumes whole lines: directly for 16-byte chunks, through an LDS transpose for wider rows (L = 512 fp64 5.72 -> 5.97 TB/s,
-// L = 256 fp64 / L = 512 fp32 +1 %).  (These were build switches TRPL_PCRB_WAVES / _NT / _STAGE / _CAP until round 5.)
+// L = 256 fp64 / L = 512 fp32 +1 %); since round 6 the wide rows' RESULT takes the same route back (pcrb_store_row).  (These were build switches TRPL_PCRB_WAVES / _NT / _STAGE / _CAP until round 5.)
 constexpr int kPcrbGridCap = 256 * 256;     // workgroups; beyond that a wave loops over systems
 
 template <bool NT, typename T> __device__ __forceinline__ T pcrb_load(const T *p)
@@ -85,6 +85,35 @@ __device__ __forceinline__ void pcrb_transpose_row(const T (&stage)[NR], T *buf,
     }
 }
 
+// The result row the other way round (round 6): the lane's NR adjacent elements parked in LDS, read back in node order and
+// stored with fully coalesced 16-byte-per-lane NON-TEMPORAL stores -- a wave-instruction writes 1 KiB of whole lines, where the
+// direct form writes 16 bytes out of every NR * sizeof(T) per instruction.  Same-box A/B, three alternating repetitions
+// (profiles/r6_pcr_store_ab.txt): L = 512 fp64 5.92 -> 6.13 TB/s (+3.6 %), L = 512 fp32 6.01 -> 6.13 (+2.0 %), L = 256 fp64
+// 5.99 -> 6.12 (+2.2 %); through LDS with ordinary stores -0.5 %; non-temporal stores on the rows that are already one
+// 16-byte chunk per lane (L = 128 fp64, L = 256 fp32): no difference.
+template <typename T, int L, int NR>
+__device__ __forceinline__ void pcrb_store_row(const T (&v)[NR], T *buf, int lane, T *row)
+{
+    constexpr int PER = 16 / sizeof(T), CH = L / (64 * PER);
+    typedef T vec16 __attribute__((ext_vector_type(PER), aligned(16)));
+    typedef T gvec16 __attribute__((ext_vector_type(PER), aligned(sizeof(T))));
+#pragma unroll
+    for (int k = 0; k < NR / PER; k++) {
+        vec16 t;
+#pragma unroll
+        for (int e = 0; e < PER; e++) t[e] = v[k * PER + e];
+        reinterpret_cast<vec16 *>(buf)[lane * (NR / PER) + k] = t;
+    }
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+        const vec16 t = reinterpret_cast<const vec16 *>(buf)[k * 64 + lane];
+        gvec16 g;
+#pragma unroll
+        for (int e = 0; e < PER; e++) g[e] = t[e];
+        __builtin_nontemporal_store(g, reinterpret_cast<gvec16 *>(row) + k * 64 + lane);
+    }
+}
+
 template <typename T, int L, bool STRICT>
 __global__ void __launch_bounds__(64) pcr_batched_kernel(const T *__restrict__ ld, const T *__restrict__ d,
                                                           const T *__restrict__ ud, const T *__restrict__ b,
@@ -121,8 +150,12 @@ __global__ void __launch_bounds__(64) pcr_batched_kernel(const T *__restrict__ l
                 pcrb_load_row<NT>(ud + o, vu); pcrb_load_row<NT>(b + o, vb);
             }
             cr_pcr_solve<T, NR>(vl, vd, vu, vb, vx, lane, xch);
+            if constexpr (STAGE) {
+                pcrb_store_row<T, L, NR>(vx, rowbuf, lane, x + base);
+            } else {
 #pragma unroll
-            for (int j = 0; j < NR; j++) x[base + NR * lane + j] = vx[j];
+                for (int j = 0; j < NR; j++) x[base + NR * lane + j] = vx[j];
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < NR; j++) {

@@ -341,6 +341,13 @@ def main():
     if rank == 0 and not args.no_pcr:
         out["roofline_hbm_pcr"] = bench_pcr(torch, tdev, dev, flags & trpl_amd.FLAG_STRICT, L=L,
                                             dtype=torch.float32 if args.fp32 else torch.float64)
+    if rank == 0 and world == 1 and not args.no_pcr and not args.no_other_configs and L == 128 and not (args.fp32 or args.strict):
+        # U1 at configs[4]'s grid ("LDS-pressure / bandwidth stress"): rows of 2 KB (fp32, the config's dtype) and 4 KB (fp64) -- a
+        # lane holds 8 adjacent rows, loaded in node order and transposed through LDS (pcr_batched_impl.hpp)
+        torch.cuda.empty_cache()
+        out["roofline_hbm_pcr_L512"] = [dict(config="configs[4] grid, %s" % name, **bench_pcr(torch, tdev, dev, 0, L=512, dtype=dt))
+                                        for name, dt in (("fp32", torch.float32), ("fp64", torch.float64))]
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_full_length and args.full_length_T != T:
         out["full_length"] = full_length_pass(torch, tdev, trpl_amd, dev, X, ini_d, mark, lens, L, args.full_length_T, dt_ns,
                                               flags, tol, C, args.fp32)
