@@ -25,12 +25,20 @@ imported torch or touched the GPU; rank 0's JSON line is relayed and the exit st
 line carries `rccl`: the world RCCL saw, every rank's device, the bytes and the time of the one all-gather.
 
 At N = 1 the line also carries `other_configs` -- ONE event-timed pass each of BASELINE configs[2] (Twothick x 65 536
-samples x 6 curves) and of one GPU's share of configs[4] (L = 512 x 32 768 of 262 144 samples, fp64 at tol 1e-7 and 1e-6) -- `host_api_block` -- the reference's own call sequence (pvSim -> fastlog -> prob per
+samples x 6 curves) and of one GPU's share of configs[4] (L = 512 x 32 768 of 262 144 samples: fp64 at tol 1e-7 and 1e-6, and the config
+as worded -- fp32 state, labelled "screening", with its PL error against fp64) -- `roofline_hbm_pcr_L512` -- U1 on configs[4]'s 512-node
+rows, fp32 and fp64 -- `library` -- which libtrpl_hip.so was measured (source hash; `roofline.traffic_source_stale` says whether the quoted
+PMC profile is of that library) -- `host_api_block` -- the reference's own call sequence (pvSim -> fastlog -> prob per
 curve, host buffers) on one reference-shaped 1024-sample block, PCIe included -- and `full_length`: ONE extra pass at the production length T = 80 000 over the
 same resident batch (event-timed, ~26 s), so that the full-length rate is measured by every driver run.
 
 `--single-process --gpus N` runs the same step with ONE process driving all N devices through
 trpl_loglik_multi_dev (RCCL ncclCommInitAll + one ncclAllGather; P left resident on every device).
+
+Rehearsals of the N > 1 path on a one-GPU box (tests/test_gpu_multi.py; none is a measurement): `--samples-total S` (a logical batch
+that --gpus need not divide), `--backend gloo` (ranks share the GPU, host-staged collectives), `--rehearse-collectives` (the collective
+code path over real RCCL on a one-rank communicator), `--single-process --rehearse-on-device0` (N ranks of one process on device 0
+against a stand-in collective library).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline      the dominant kernel (the fused time-stepper): achieved fp64 FLOP/s from the
