@@ -102,6 +102,7 @@ SIGNATURES = {
                         _vp, _vp, _vp, _vp, _u32, _i32, _pd],
     "trpl_loglik_obs_dev": [_vp, _i64, _i32, _vp, _f64, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp,
                             _vp, _vp, _vp, _vp, _vp, _u32, _vp],
+    "trpl_interp_rows": [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _i64],
     "trpl_loglik_from_pl_dev": [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _u32, _vp],
     "trpl_loglik_multi": [_vp, _i64, _i32, _vp, _f64, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64,
                           _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _i32, _pd],

@@ -267,4 +267,34 @@ hipError_t launch_pl_loglik(const void *pl, int elem_bytes, int64_t rows, int64_
     return hipGetLastError();
 }
 
+// ---- host-side time interpolation of the unfused call sequence (bayeslib.py:184-191) ----
+// out[r][i] = ((pl[r][hi_i] - pl[r][hi_i - 1]) / h_i) * dx_i + pl[r][hi_i - 1]: the arithmetic of scipy's interp1d / griddata as
+// the reference applies it row by row -- the difference in the matrix's own type (float32 for the reference's buffer), then
+// float64, two roundings, no fused multiply-add (this translation unit is compiled with -ffp-contract=off) -- bit for bit what
+// driver.interp_rows computed with NumPy, without the interpreter lock: the worker threads of driver.simulate run it side by side
+// (NumPy's fancy indexing serialised them: 0.21 s of a 0.60 s task, profiles/r6_levelb_task_phases.txt).  Plain host code.
+template <typename T>
+static void interp_rows_host(const T *pl, int64_t rows, int64_t ld, const int32_t *hi, const double *dx, const double *h,
+                             int64_t n_obs, double *out, int64_t out_ld)
+{
+    for (int64_t r = 0; r < rows; r++) {
+        const T *p = pl + r * ld;
+        double *o = out + r * out_ld;
+        for (int64_t i = 0; i < n_obs; i++) {
+            const T lo = p[hi[i] - 1];
+            const T d = p[hi[i]] - lo;
+            const double slope = (double)d / h[i];
+            const double prod = slope * dx[i];
+            o[i] = prod + (double)lo;
+        }
+    }
+}
+
+void interp_rows_any(const void *pl, int elem_bytes, int64_t rows, int64_t ld, const int32_t *hi, const double *dx,
+                     const double *h, int64_t n_obs, double *out, int64_t out_ld)
+{
+    if (elem_bytes == 4) interp_rows_host<float>((const float *)pl, rows, ld, hi, dx, h, n_obs, out, out_ld);
+    else interp_rows_host<double>((const double *)pl, rows, ld, hi, dx, h, n_obs, out, out_ld);
+}
+
 }  // namespace trpl

@@ -814,6 +814,20 @@ int trpl_loglik_obs(const double *X, int64_t S, int32_t C, const double *lengths
                             obs_ld, n_obs, P, sse, status, iters_total, floor_col, flags, device, seconds);
 }
 
+/* ------------------------------------------------------------------ host interpolation --- */
+int trpl_interp_rows(const void *pl, int32_t elem_bytes, int64_t rows, int64_t ncol, int64_t ld, const int32_t *hi,
+                     const double *dx, const double *h, int64_t n_obs, double *out, int64_t out_ld)
+{
+    if (elem_bytes != 4 && elem_bytes != 8) return api_fail(TRPL_ERR_ARG, "elem_bytes must be 4 or 8");
+    if (rows < 0 || n_obs < 0 || ncol < 2 || ld < ncol || out_ld < n_obs) return api_fail(TRPL_ERR_ARG, "bad shape");
+    if (rows == 0 || n_obs == 0) return TRPL_OK;
+    if (!pl || !hi || !dx || !h || !out) return api_fail(TRPL_ERR_ARG, "NULL pointer argument");
+    for (int64_t i = 0; i < n_obs; i++)
+        if (hi[i] < 1 || hi[i] >= ncol) return api_fail(TRPL_ERR_ARG, "hi[%lld]=%d must be in [1, ncol - 1]", (long long)i, hi[i]);
+    trpl::interp_rows_any(pl, elem_bytes, rows, ld, hi, dx, h, n_obs, out, out_ld);
+    return TRPL_OK;
+}
+
 /* ------------------------------------------------------------------ posterior core ------ */
 int64_t trpl_posterior_workspace_bytes(int32_t D) { return (int64_t)trpl::posterior_workspace_bytes(D); }
 

@@ -88,6 +88,9 @@ __device__ __forceinline__ void bdf_row(int32_t row, T &a0, T &a1, T &a2, T &a3,
 }
 
 // Launchers (one translation unit per arithmetic mode, see stepper_strict.hip / stepper_fast.hip).
+// host-side row interpolation of the unfused call sequence (likelihood.hip; -ffp-contract=off)
+void interp_rows_any(const void *pl, int elem_bytes, int64_t rows, int64_t ld, const int32_t *hi, const double *dx,
+                     const double *h, int64_t n_obs, double *out, int64_t out_ld);
 hipError_t launch_stepper_strict(const StepArgs &a, hipStream_t stream);
 hipError_t launch_stepper_fast(const StepArgs &a, hipStream_t stream);
 hipError_t launch_stepper_f32(const StepArgs &a, hipStream_t stream);   // stepper_f32.hip, L >= 128

@@ -58,18 +58,34 @@ def fused_entry_point(exp_times, sim_t, num_curves, literal=False):
     return "trpl_loglik" if on else "trpl_loglik_obs"
 
 
-def interp_rows(sim_t, pl, times):
-    """Vectorised 1-D linear interpolation of every row of `pl` from sim_t onto `times`; the
-    arithmetic of scipy's interp1d/griddata, which the reference applies row by row
-    (bayeslib.py:186-189): slope = (y_hi - y_lo) / (x_hi - x_lo) with the difference taken in
-    pl's own dtype (float32 for the reference's buffer), then slope * (x - x_lo) + y_lo in
-    float64; NaN outside the grid.  Returns float64."""
-    sim_t = np.asarray(sim_t, dtype=float)
-    times = np.asarray(times, dtype=float)
+def _interp_rows_numpy(sim_t, pl, times):
+    """interp_rows in NumPy: the arithmetic trpl_interp_rows restates (and the route for matrices it does not take)."""
     hi = np.clip(np.searchsorted(sim_t, times), 1, len(sim_t) - 1)
     lo = hi - 1
     slope = (pl[:, hi] - pl[:, lo]) / (sim_t[hi] - sim_t[lo])[None, :]
-    out = np.ascontiguousarray(slope * (times - sim_t[lo])[None, :] + pl[:, lo], dtype=np.float64)
+    return np.ascontiguousarray(slope * (times - sim_t[lo])[None, :] + pl[:, lo], dtype=np.float64)
+
+
+def interp_rows(sim_t, pl, times):
+    """1-D linear interpolation of every row of `pl` from sim_t onto `times`; the arithmetic of scipy's interp1d / griddata,
+    which the reference applies row by row (bayeslib.py:186-189): slope = (y_hi - y_lo) / (x_hi - x_lo) with the difference
+    taken in pl's own dtype (float32 for the reference's buffer), then slope * (x - x_lo) + y_lo in float64; NaN outside the
+    grid.  Returns float64.  Row-contiguous float32 / float64 matrices go through trpl_interp_rows -- the same operations in
+    plain host C++, bit for bit, without the interpreter lock, so the worker threads of simulate() interpolate side by side."""
+    sim_t = np.asarray(sim_t, dtype=float)
+    times = np.asarray(times, dtype=float)
+    if (isinstance(pl, np.ndarray) and pl.ndim == 2 and pl.dtype in (np.float32, np.float64) and pl.shape[0] > 0
+            and pl.strides[1] == pl.itemsize and pl.strides[0] % pl.itemsize == 0 and pl.strides[0] >= pl.shape[1] * pl.itemsize
+            and pl.shape[1] == len(sim_t) and len(sim_t) >= 2 and len(times) > 0):
+        hi, dx, h = bracket_times(sim_t, times)
+        hi = np.ascontiguousarray(hi, dtype=np.int32)
+        dx = np.ascontiguousarray(dx, dtype=np.float64)
+        h = np.ascontiguousarray(h, dtype=np.float64)
+        out = np.empty((pl.shape[0], len(times)), dtype=np.float64)
+        _abi.check(_abi.lib().trpl_interp_rows(_abi.ptr(pl), pl.itemsize, pl.shape[0], pl.shape[1], pl.strides[0] // pl.itemsize,
+                                               _abi.ptr(hi), _abi.ptr(dx), _abi.ptr(h), len(times), _abi.ptr(out), out.shape[1]))
+    else:
+        out = _interp_rows_numpy(sim_t, pl, times)
     outside = (times < sim_t[0]) | (times > sim_t[-1])
     out[:, outside] = np.nan
     return out
@@ -367,7 +383,11 @@ def simulate(model, e_data, P, X, plI, plI_int, num_curves, sim_params, init_par
     def process_curve(ic_num, blk, size, last=True):
         par = list(sim_params)
         par[0] = thicknesses[ic_num]                                      # :119
-        buf = np.empty((size, ncol), dtype=pl_dtype)                      # :137
+        # a FRESH matrix per task, like the reference (:137).  Reusing the matrices of consumed results was measured and
+        # rejected: at sims_per_gpu = 1024 the reused address ranges -- page-locked and released again by every pvSim and
+        # fastlog call -- serialise the worker threads' launches (production shape / 4: 33 s against 27.5 s, shared or
+        # per-thread reuse alike; profiles/r6_levelb_task_phases.txt)
+        buf = np.empty((size, ncol), dtype=pl_dtype)
         sec = model(buf, None, None, None, X[blk:blk + size, :-1], par, init_params[ic_num], None, None,
                     int(gpu_info.get("max_sims_per_block", 1)), init_mode="points", **model_kw)      # :93,:146
         misc = 0.0

@@ -36,7 +36,7 @@ extern "C" {
 
 #define TRPL_ABI_VERSION 5   /* 5 (round 6): trpl_has_experimental(); TRPL_FLAG_MIXED / TRPL_FLAG_HIST32 exist only in a library built with
                                 `make EXPERIMENTAL=1` (the default library answers TRPL_ERR_UNSUPPORTED); trpl_kernel_name validates like a
-                                launch; roctx ranges around the host-buffer calls when libroctx64.so is loadable.
+                                launch; roctx ranges around the host-buffer calls when libroctx64.so is loadable; trpl_interp_rows (host).
                                 4 (round 5): TRPL_FLAG_BDF_ORDER, TRPL_FLAG_PAIR_ALWAYS_SEAM / _PAIR_ADJACENT / _MULTI_FORCE_PAD (were
                                 process-wide environment switches), trpl_multi_create_ex, TRPL_PL_ENVELOPE_K_L512; floor_col = -2 for
                                 flagged systems, T <= 2^30 - 16, up to TRPL_MAX_CURVES curves and TRPL_FLAG_HIST32 (round 4, then
@@ -284,6 +284,19 @@ int trpl_sse_accumulate(double *P, const void *plI, int32_t elem_bytes, int64_t 
 int trpl_sse_accumulate_dev(double *P, const void *plI, int32_t elem_bytes, int64_t rows,
                             int64_t n_obs, int64_t ld, const double *values, const double *mag,
                             void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * trpl_interp_rows -- the time interpolation of the UNFUSED call sequence, bayeslib.py:184-191 (a Python loop of
+ * scipy.interpolate.griddata over the rows of plI): every row of the host matrix pl [rows][ld] (fp32 / fp64, elem_bytes), of which
+ * ncol columns are valid, is interpolated linearly onto n_obs observation times given as brackets -- hi[i] in [1, ncol - 1] the
+ * column right of time i, dx[i] = t_i - t[hi[i] - 1], h[i] = t[hi[i]] - t[hi[i] - 1] (trpl_loglik_obs's convention) -- into
+ * out [rows][out_ld] fp64:  out = ((pl[hi] - pl[hi - 1]) / h) * dx + pl[hi - 1], the difference in pl's own type, the rest in fp64,
+ * no fused multiply-add: scipy's interp1d form, bit for bit.  PLAIN HOST CODE (no device, no stream; callable from several threads
+ * at once): it exists so that the worker threads of an unfused driver do not serialise on an interpreter lock; the fused entry
+ * points interpolate in the kernel.
+ * ------------------------------------------------------------------------------------- */
+int trpl_interp_rows(const void *pl, int32_t elem_bytes, int64_t rows, int64_t ncol, int64_t ld, const int32_t *hi,
+                     const double *dx, const double *h, int64_t n_obs, double *out, int64_t out_ld);
 
 /* ---------------------------------------------------------------------------------------
  * trpl_loglik_from_pl_dev -- log-likelihood of PL rows that are ALREADY in device memory (the output of

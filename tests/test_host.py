@@ -122,6 +122,42 @@ def test_simulate_control_flow_with_standin_compute(trpl, monkeypatch):
                      dict(flags, load_PL_from_file=True), {"sims_per_gpu": 3, "num_gpus": 1}, 0, st, et, mt)
 
 
+def test_host_interpolation_entry_point_is_the_numpy_arithmetic_bit_for_bit(trpl):
+    """trpl_interp_rows (plain host C++, no device) against the NumPy form it replaces in driver.interp_rows -- the reference's
+    row-by-row griddata (bayeslib.py:184-191; interp1d's slope * (x - x_lo) + y_lo with the difference in the matrix's own
+    dtype): float32 and float64 matrices, observation times that are grid nodes, off-grid, repeated, at both window edges and
+    outside the window (NaN), a matrix whose rows are strided (ld > ncol), and the inputs the entry point does not take
+    (integer matrix, empty time list) through the NumPy route.  Bit patterns, NaNs included."""
+    import ctypes as C
+    drv, A = trpl.driver, trpl._abi
+    rng = np.random.default_rng(4)
+    sim_t = np.linspace(0.0, 50.0, 2001)
+    times_sets = [sim_t[:321], np.sort(rng.uniform(0.0, 50.0, 777)),
+                  np.array([0.0, 0.0, 50.0, 49.999999, 0.0125, 0.0125, -1.0, 51.0, 25.0])]
+    for dt in (np.float32, np.float64):
+        wide = np.log10(rng.lognormal(-3, 2, (37, 2001 + 5))).astype(dt)
+        for pl in (np.ascontiguousarray(wide[:, :2001]), wide[:, 3:2004]):          # contiguous, and row-strided (ld = 2006)
+            for times in times_sets:
+                got = drv.interp_rows(sim_t, pl, times)
+                want = drv._interp_rows_numpy(sim_t, pl, times)
+                want[:, (times < sim_t[0]) | (times > sim_t[-1])] = np.nan
+                assert got.dtype == np.float64 and got.shape == want.shape
+                assert np.array_equal(got.view(np.int64), want.view(np.int64)), (dt, len(times))
+                assert np.isnan(got[:, times < 0]).all() and np.isnan(got[:, times > 50]).all()
+    ints = rng.integers(0, 9, (4, 2001))
+    assert np.array_equal(drv.interp_rows(sim_t, ints, sim_t[:5] + 0.001), drv._interp_rows_numpy(sim_t, ints, sim_t[:5] + 0.001))
+    assert drv.interp_rows(sim_t, wide[:, :2001], np.zeros(0)).shape == (37, 0)
+    # the entry point validates its brackets and shapes; nothing is written on a refusal
+    lib = A.lib()
+    pl = np.zeros((2, 10), dtype=np.float32); out = np.full((2, 3), 7.0)
+    hi = np.array([1, 10, 2], dtype=np.int32); one = np.ones(3)
+    assert lib.trpl_interp_rows(A.ptr(pl), 4, 2, 10, 10, A.ptr(hi), A.ptr(one), A.ptr(one), 3, A.ptr(out), 3) == A.ERR_ARG
+    assert b"hi[1]" in lib.trpl_last_error() and (out == 7.0).all()
+    assert lib.trpl_interp_rows(A.ptr(pl), 2, 2, 10, 10, A.ptr(hi), A.ptr(one), A.ptr(one), 3, A.ptr(out), 3) == A.ERR_ARG
+    assert lib.trpl_interp_rows(A.ptr(pl), 4, 2, 10, 9, A.ptr(hi), A.ptr(one), A.ptr(one), 3, A.ptr(out), 3) == A.ERR_ARG
+    assert lib.trpl_interp_rows(None, 4, 0, 10, 10, None, None, None, 3, None, 3) == A.OK            # empty batch
+
+
 def test_fused_routing_rule_and_its_literal_switch(trpl):
     """driver.observations_on_grid / fused_entry_point: ONE rule for both fused branches of simulate() (one experiment per
     call, several experiments over a resident PL block).  Default: observation times that are a prefix of the simulation grid
@@ -141,8 +177,9 @@ def test_fused_routing_rule_and_its_literal_switch(trpl):
 
 def test_unfused_overlap_is_bounded_by_host_bytes(trpl, monkeypatch):
     """gpu_info["max_host_bytes"] bounds the PL results the unfused overlapped path holds at once (bayeslib.py:131-137 holds
-    one; round 5's overlap held two blocks' curves whatever their size).  A re-entrant stand-in model counts the PL buffers
-    alive (created, not yet garbage-collected) at each of its calls; P is the same for every budget."""
+    one; round 5's overlap held two blocks' curves whatever their size).  A re-entrant stand-in model counts the PL matrices
+    in existence (in use or waiting in the path's reuse pool; not yet garbage-collected) at each of its calls; P is the same for
+    every budget."""
     import gc
     import threading
     import weakref
@@ -153,19 +190,18 @@ def test_unfused_overlap_is_bounded_by_host_bytes(trpl, monkeypatch):
     ini = rng.uniform(1, 2, (C, L))
     sim_t = np.linspace(0, Time, T + 1)
     lock = threading.Lock()
-    state = {"live": 0, "peak": 0, "calls": 0}
-
-    def gone():
-        with lock:
-            state["live"] -= 1
+    state = {"peak": 0, "calls": 0}
+    alive = {}                                                   # id -> True of every PL matrix that exists (in use or pooled)
 
     def model(plI, plN, plP, plE, matPar, simPar, iniPar, TPB, BPG, mspb, init_mode="exp"):
         gc.collect()
+        key = id(plI)
         with lock:
-            state["live"] += 1
+            if key not in alive:                                 # a reused matrix is the same object: counted once
+                alive[key] = True
+                weakref.finalize(plI, alive.pop, key, None)
             state["calls"] += 1
-            state["peak"] = max(state["peak"], state["live"])
-        weakref.finalize(plI, gone)
+            state["peak"] = max(state["peak"], len(alive))
         plI[:] = (matPar[:, :1] * iniPar.sum() * np.exp(-sim_t))[:, :T + 1]
         return 0.5
     model.reentrant = True
@@ -190,7 +226,8 @@ def test_unfused_overlap_is_bounded_by_host_bytes(trpl, monkeypatch):
     results = {}
 
     def run(label, info, bound, data):
-        state.update(live=0, peak=0, calls=0)
+        gc.collect()
+        state.update(peak=0, calls=0)
         P = np.zeros((2, S))
         st, et, mt = np.zeros(1), np.zeros(1), np.zeros(1)
         plI, plI_int = [None], [None]
@@ -216,7 +253,8 @@ def test_unfused_overlap_is_bounded_by_host_bytes(trpl, monkeypatch):
     full2, done2 = drv.unfused_curve_bytes(group, T + 1, np.float32, [9] * C + [7] * C, C)
     assert full2 == group * ((T + 1) * 4 + 16 * 8) and done2 == group * 16 * 8
     assert drv.overlap_window(full2, done2, C * full2 + C * done2, C) == (2 * C, C)
-    state.update(live=0, peak=0, calls=0)
+    gc.collect()
+    state.update(peak=0, calls=0)
     P = np.zeros((2, S))
     plI, plI_int = [None], [None]
     drv.simulate(model, off, P, X, plI, plI_int, C, [100.0, Time, L, T, 1, (0,), 7, 50], ini, flags,
